@@ -1,0 +1,205 @@
+/*
+ * ponderv2_hip.h -- C ABI of libponderv2_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary of the PonderV2 pre-training hot path.  The reference has no C
+ * ABI of its own: its native layer is pybind11-on-torch::Tensor (libs/smooth-sampler) plus two
+ * out-of-tree pip wheels (spconv 2.x, torch_scatter).  Every entry point below names the
+ * reference interface it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns all memory (PyTorch's caching allocator on the Python side);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises;
+ *   - return value: 0 on success, otherwise a hipError_t (launch error) or a negative PV2_E_*
+ *     argument error; pv2_last_error() gives a static description for the calling thread;
+ *   - float tensors are fp32 unless the function name ends in _f64;
+ *   - feature matrices are row-major [rows, channels].
+ */
+#ifndef PONDERV2_HIP_H
+#define PONDERV2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pv2_stream_t; /* hipStream_t */
+
+#define PV2_OK 0
+#define PV2_E_BADARG (-1)
+#define PV2_E_UNSUPPORTED (-2)
+#define PV2_E_WORKSPACE (-3)
+
+int pv2_abi_version(void);
+const char* pv2_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Rulebook ("indice pair") generation.
+ * Replaces spconv 2.x's hash table + generate_subm_conv_inds / generate_conv_inds, reached in
+ * the reference through spconv.SubMConv3d / SparseConv3d / SparseInverseConv3d at
+ * ponder/models/sparse_unet/spconv_unet_v1m1_base.py:41,47,58,112,135,171.
+ *
+ * coords      int32 [n,4] rows (b,x,y,z), 0 <= b < 65536, 0 <= x,y,z < 65504.
+ * Kernel offset index k = ((ix*K)+iy)*K+iz over the K^3 window, spatial dims in the order they
+ * appear in `coords` (first spatial dim slowest), matching a dense conv3d weight [.,kx,ky,kz,.].
+ *
+ * Canonical order (what "bit-exact rulebook" means in this project, mirrored by oracle/):
+ *   pairs are grouped by k ascending and, inside a group, sorted by output row ascending;
+ *   strided-conv output voxels are sorted by (b,x,y,z) lexicographically.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Build an open-addressing hash  (b,x,y,z) -> row.  table_size must be a power of two and
+ * >= 2*n.  Duplicate coordinates keep the smallest row. */
+int pv2_hash_build(const int32_t* coords, int64_t n, uint64_t* table_keys, int32_t* table_vals,
+                   int64_t table_size, pv2_stream_t stream);
+
+/* Submanifold neighbour table: nbr[k*n + i] = row of voxel coords[i] + (offset k - K/2), or -1.
+ * ksize is odd (1,3,5,...).  nbr has ksize^3 * n entries. */
+int pv2_subm_neighbor_table(const int32_t* coords, int64_t n, int ksize,
+                            const uint64_t* table_keys, const int32_t* table_vals,
+                            int64_t table_size, int32_t* nbr, pv2_stream_t stream);
+
+/* Strided (kernel == stride, no padding) sparse conv, step 1: unique output voxels.
+ * keys_tmp, keys_sorted: uint64 [n]; out_coords: int32 [n,4] (first *n_out rows valid);
+ * n_out: int32 [1] (device).  out_shape: host int32[3], outputs with a coordinate >= out_shape
+ * are dropped like spconv does.  workspace: device scratch of pv2_downsample_workspace_bytes(n). */
+size_t pv2_downsample_workspace_bytes(int64_t n);
+int pv2_downsample_unique(const int32_t* coords, int64_t n, int stride, const int32_t* out_shape,
+                          uint64_t* keys_tmp, uint64_t* keys_sorted, int32_t* out_coords,
+                          int32_t* n_out, void* workspace, size_t workspace_bytes,
+                          pv2_stream_t stream);
+
+/* Step 2: table tbl[k*n_cap + o] = input row that maps to output row o through offset k, or -1
+ * (k = ((x%s)*s + y%s)*s + z%s).  n_cap is the row stride of tbl (>= *n_out; normally n). */
+int pv2_downsample_table(const int32_t* coords, int64_t n, int stride, const int32_t* out_shape,
+                         const uint64_t* keys_sorted, const int32_t* n_out, int32_t* tbl,
+                         int64_t n_cap, pv2_stream_t stream);
+
+/* Ordered compaction of a [K, n] table (entries >= 0 are valid) into pair lists.
+ * Phase 1 writes kstart[K+1] (exclusive prefix of per-k counts; kstart[K] = total pairs) and
+ * block_sums (int32 [K * ceil(n/PV2_SCAN_CHUNK)]).  Phase 2 (after the caller has sized the
+ * outputs from kstart[K]) writes pair_other[p] = table value, pair_row[p] = column index,
+ * ordered by (k, column).  `n_rows_dev`, when not NULL, is a device int32 holding the number of
+ * valid columns (<= n); columns beyond it are ignored. */
+#define PV2_SCAN_CHUNK 2048
+int pv2_table_count(const int32_t* tbl, int K, int64_t n, const int32_t* n_rows_dev,
+                    int32_t* block_sums, int32_t* kstart, pv2_stream_t stream);
+int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_rows_dev,
+                      const int32_t* block_sums, int32_t* pair_other, int32_t* pair_row,
+                      pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution arithmetic (gather -> MFMA f32 GEMM -> scatter-add, one launch per conv).
+ * Replaces spconv 2.x's ops.indice_conv / indice_conv_backward (same call sites as above).
+ *
+ *   out[pair_out[p], :] += W[k(p)] * in[pair_in[p], :]       for every pair p
+ *
+ * weight      fp32 [c_out, K, c_in]  (spconv 2.x layout [Cout, kD, kH, kW, Cin], flattened)
+ * kstart      int32 [K+1] device prefix of pairs per offset (from pv2_table_count)
+ * tile_start  int32 [K+1] device prefix of ceil(count_k / PV2_PAIR_TILE)
+ * n_tiles     tile_start[K] (host value)
+ * `out` must be pre-initialised (zeros, or a bias/residual to accumulate onto).
+ * ------------------------------------------------------------------------------------------ */
+#define PV2_PAIR_TILE 32
+int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                       int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                       const int32_t* kstart, const int32_t* tile_start, int64_t n_tiles,
+                       float* out_feat, int64_t n_out, pv2_stream_t stream);
+
+/* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
+ * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count tiles of
+ * PV2_WGRAD_TILE pairs (prefix of ceil(count_k / PV2_WGRAD_TILE)). */
+#define PV2_WGRAD_TILE 512
+int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,
+                               int64_t n_out, int c_out, int K, const int32_t* pair_in,
+                               const int32_t* pair_out, const int32_t* kstart,
+                               const int32_t* tile_start, int64_t n_tiles, float* dweight,
+                               pv2_stream_t stream);
+/* (grad wrt input is pv2_spconv_forward with pair_in/pair_out swapped and weight transposed to
+ *  [c_in, K, c_out].) */
+
+/* ------------------------------------------------------------------------------------------
+ * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,
+ * reduce="mean"|"sum", out=...) at ponder/models/ponder/ponder_indoor_base.py:214 and
+ * ponder_outdoor_base.py:204.
+ * ------------------------------------------------------------------------------------------ */
+/* out[index[i], :] += src[i, :];  count[index[i]] += 1.   index: int64 [m], values in [0, g). */
+int pv2_scatter_add(const float* src, const int64_t* index, int64_t m, int c, float* out,
+                    float* count, int64_t g, pv2_stream_t stream);
+/* out[r, :] /= max(count[r], 1) */
+int pv2_scatter_mean_finish(float* out, const float* count, int64_t g, int c, pv2_stream_t stream);
+/* backward: dsrc[i, :] = dout[index[i], :] / max(count[index[i]], 1)   (count may be NULL: sum) */
+int pv2_scatter_backward(const float* dout, const int64_t* index, const float* count, int64_t m,
+                         int c, float* dsrc, int64_t g, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Trilinear ("smooth") grid sampler, forward / backward / backward-of-backward.
+ * Replaces smooth_sampler._C.forward / backward / backward_backward
+ * (libs/smooth-sampler/smooth_sampler/csrc/smooth_sampler.cpp:36-98, kernels
+ * smooth_sampler_kernel.cu:39-153, 155-356, 358-619).
+ *
+ * Shapes follow torch grid_sample for 5-D input: input (N,C,D,H,W), grid (N,Do,Ho,Wo,3) with
+ * grid[...,0] -> W axis.  The grid and every 3-vector tensor are dense [P,3] with
+ * P = N*Do*Ho*Wo points, `points_per_n` = Do*Ho*Wo.  Volume-shaped tensors are addressed with
+ * explicit ELEMENT strides so that both NCDHW and channels-last (NDHWC) storage work; tensors
+ * shaped like the output (N,C,Do,Ho,Wo) are addressed as  n*o_sn + c*o_sc + q*o_sp  with q the
+ * point index inside batch item n.
+ *
+ * padding_mode: 0 zeros, 1 border, 2 reflection (ATen GridSamplerPadding).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pv2_volume_desc {
+  int64_t n, c, d, h, w;       /* sizes */
+  int64_t sn, sc, sd, sh, sw;  /* element strides */
+} pv2_volume_desc;
+
+typedef struct pv2_points_desc {
+  int64_t n_points;     /* P = N * points_per_n */
+  int64_t points_per_n; /* Do*Ho*Wo */
+  int64_t o_sn, o_sc, o_sp;
+} pv2_points_desc;
+
+int pv2_trilinear_forward_f32(const float* input, const pv2_volume_desc* vol, const float* grid,
+                              const pv2_points_desc* pts, float* output, int padding_mode,
+                              int align_corners, int apply_smoothstep, pv2_stream_t stream);
+int pv2_trilinear_forward_f64(const double* input, const pv2_volume_desc* vol, const double* grid,
+                              const pv2_points_desc* pts, double* output, int padding_mode,
+                              int align_corners, int apply_smoothstep, pv2_stream_t stream);
+
+/* grad_input (may be NULL to skip; otherwise ZERO-initialised, same strides as `vol`) and
+ * grad_grid [P,3] given grad_output (output-shaped, strides from `pts`). */
+int pv2_trilinear_backward_f32(const float* grad_output, const float* input,
+                               const pv2_volume_desc* vol, const float* grid,
+                               const pv2_points_desc* pts, float* grad_input, float* grad_grid,
+                               int padding_mode, int align_corners, int apply_smoothstep,
+                               pv2_stream_t stream);
+int pv2_trilinear_backward_f64(const double* grad_output, const double* input,
+                               const pv2_volume_desc* vol, const double* grid,
+                               const pv2_points_desc* pts, double* grad_input, double* grad_grid,
+                               int padding_mode, int align_corners, int apply_smoothstep,
+                               pv2_stream_t stream);
+
+/* Backward of backward.  Inputs: g_ginput (grad wrt the grad_input output; may be NULL = zeros;
+ * strides of `vol`), g_ggrid [P,3] (grad wrt the grad_grid output), and the saved input / grid /
+ * grad_output.  Outputs: grad_input2 (may be NULL; ZERO-initialised), grad_grid2 [P,3],
+ * grad_grad_output (output-shaped, fully written). */
+int pv2_trilinear_backward_backward_f32(const float* g_ginput, const float* g_ggrid,
+                                        const float* input, const pv2_volume_desc* vol,
+                                        const float* grid, const float* grad_output,
+                                        const pv2_points_desc* pts, float* grad_input2,
+                                        float* grad_grid2, float* grad_grad_output,
+                                        int padding_mode, int align_corners, int apply_smoothstep,
+                                        pv2_stream_t stream);
+int pv2_trilinear_backward_backward_f64(const double* g_ginput, const double* g_ggrid,
+                                        const double* input, const pv2_volume_desc* vol,
+                                        const double* grid, const double* grad_output,
+                                        const pv2_points_desc* pts, double* grad_input2,
+                                        double* grad_grid2, double* grad_grad_output,
+                                        int padding_mode, int align_corners, int apply_smoothstep,
+                                        pv2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PONDERV2_HIP_H */

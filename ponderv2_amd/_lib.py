@@ -1,0 +1,84 @@
+"""ctypes binding of libponderv2_hip.so (the C ABI declared in include/ponderv2_hip.h).
+
+There is no CPU fallback: if the shared library is missing the import of any op fails loudly
+with instructions to build it (``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libponderv2_hip.so")
+
+PAIR_TILE = 32      # PV2_PAIR_TILE
+WGRAD_TILE = 512    # PV2_WGRAD_TILE
+SCAN_CHUNK = 2048   # PV2_SCAN_CHUNK
+
+
+class VolumeDesc(Structure):
+    _fields_ = [(k, c_int64) for k in ("n", "c", "d", "h", "w", "sn", "sc", "sd", "sh", "sw")]
+
+
+class PointsDesc(Structure):
+    _fields_ = [(k, c_int64) for k in ("n_points", "points_per_n", "o_sn", "o_sc", "o_sp")]
+
+
+_P = c_void_p  # every device pointer travels as void*
+
+# name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
+SIGNATURES = {
+    "pv2_abi_version": (c_int, []),
+    "pv2_last_error": (c_char_p, []),
+    "pv2_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
+    "pv2_subm_neighbor_table": (c_int, [_P, c_int64, c_int, _P, _P, c_int64, _P, _P]),
+    "pv2_downsample_workspace_bytes": (c_size_t, [c_int64]),
+    "pv2_downsample_unique": (
+        c_int, [_P, c_int64, c_int, POINTER(c_int32), _P, _P, _P, _P, _P, c_size_t, _P]),
+    "pv2_downsample_table": (
+        c_int, [_P, c_int64, c_int, POINTER(c_int32), _P, _P, _P, c_int64, _P]),
+    "pv2_table_count": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P]),
+    "pv2_table_compact": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, _P]),
+    "pv2_spconv_forward": (
+        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P]),
+    "pv2_spconv_backward_weight": (
+        c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int64, _P, _P]),
+    "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
+    "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+}
+for _sfx in ("f32", "f64"):
+    SIGNATURES["pv2_trilinear_forward_" + _sfx] = (
+        c_int, [_P, POINTER(VolumeDesc), _P, POINTER(PointsDesc), _P, c_int, c_int, c_int, _P])
+    SIGNATURES["pv2_trilinear_backward_" + _sfx] = (
+        c_int, [_P, _P, POINTER(VolumeDesc), _P, POINTER(PointsDesc), _P, _P,
+                c_int, c_int, c_int, _P])
+    SIGNATURES["pv2_trilinear_backward_backward_" + _sfx] = (
+        c_int, [_P, _P, _P, POINTER(VolumeDesc), _P, _P, POINTER(PointsDesc), _P, _P, _P,
+                c_int, c_int, c_int, _P])
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`make -C ponderv2_amd/csrc` (or __graft_entry__.build()). There is no CPU "
+                "fallback for the ponderv2_amd ops.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().pv2_last_error()
+        raise RuntimeError(f"libponderv2_hip: {what} failed with status {status}: "
+                           f"{msg.decode() if msg else ''}")

@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of libponderv2_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ponderv2_hip.h"
+
+namespace pv2 {
+
+void set_error(const char* msg);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(hipGetErrorString(e));
+    (void)what;
+    return (int)e;
+  }
+  return PV2_OK;
+}
+
+inline int hip_status(hipError_t e) {
+  if (e != hipSuccess) {
+    set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  return PV2_OK;
+}
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// Grid size for a grid-stride elementwise launch: enough blocks to fill 256 CUs x 8, no more.
+inline int grid_for(int64_t work_items, int block) {
+  int64_t b = (work_items + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > 256 * 8) b = 256 * 8;
+  return (int)b;
+}
+
+}  // namespace pv2
+
+#define PV2_REQUIRE(cond, msg)   \
+  do {                           \
+    if (!(cond)) {               \
+      pv2::set_error(msg);       \
+      return PV2_E_BADARG;       \
+    }                            \
+  } while (0)

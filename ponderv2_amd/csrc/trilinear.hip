@@ -1,0 +1,400 @@
+// Twice-differentiable trilinear grid sampler for gfx950 (forward, backward, backward-of-backward).
+//
+// Stands in for libs/smooth-sampler (smooth_sampler_kernel.cu:39-153 forward, :155-356 backward,
+// :358-619 backward-backward; bindings smooth_sampler.cpp:36-98).  The maths is re-derived from
+// the separable weight model below rather than transliterated:
+//
+//   per axis a: source coordinate x_a = T_a(g_a) (un-normalise, then clip / reflect by padding
+//   mode) with slope m_a = dT_a/dg_a; t_a = x_a - floor(x_a); s_a = S(t_a) where S is identity or
+//   smoothstep; corner bit b in {0,1} has weight om_a(b) = b ? s_a : 1 - s_a,
+//   d om_a(b)/dg_a = (2b-1) S'(t_a) m_a,  d2 om_a(b)/dg_a^2 = (2b-1) S''(t_a) m_a^2.
+//   corner weight w_c = om_x(cx) om_y(cy) om_z(cz).
+//
+//   forward :  out[ch]   = sum_c w_c V[ch,c]
+//   backward:  gV[ch,c] += w_c gO[ch]            gG_a = sum_ch gO[ch] sum_c (d_a w_c) V[ch,c]
+//   bwd-bwd (upstream hV for gV, hG for gG), with D_c = sum_a hG_a d_a w_c:
+//     ggO[ch]   = sum_c (hV[ch,c] w_c + V[ch,c] D_c)
+//     gV2[ch,c]+= gO[ch] D_c
+//     gG2_b     = sum_ch gO[ch] sum_c ( hV[ch,c] d_b w_c + V[ch,c] sum_a hG_a d_a d_b w_c )
+//
+// Mapping to the machine: ONE WAVE PER SAMPLE POINT, lanes run along the channel axis.  With a
+// channels-last (NDHWC) volume each of the 8 corners is one contiguous C*4-byte read (512 B at
+// C=128) and the volume-gradient atomics are contiguous too; with the reference's NCDHW layout the
+// same kernels still work through the stride descriptor, just uncoalesced.  The three grid
+// gradients are wave-reduced with cross-lane shuffles, no LDS.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct Axis {
+  T w0, w1;   // om(0), om(1)
+  T dw;       // d om(1) / dg   (d om(0)/dg = -dw)
+  T d2w;      // d2 om(1) / dg2
+  int64_t i0; // floor(x)
+};
+
+template <typename T>
+__device__ __forceinline__ T reflect_coord(T x, int64_t twice_low, int64_t twice_high, T* mult) {
+  if (twice_low == twice_high) {
+    *mult = T(0);
+    return T(0);
+  }
+  const T lo = T(twice_low) / T(2);
+  const T span = T(twice_high - twice_low) / T(2);
+  T v = x - lo;
+  T sgn = T(1);
+  if (v < T(0)) {
+    v = -v;
+    sgn = T(-1);
+  }
+  const T extra = fmod(v, span);
+  const int64_t flips = (int64_t)floor(v / span);
+  if ((flips & 1) == 0) {
+    *mult = sgn;
+    return extra + lo;
+  }
+  *mult = -sgn;
+  return span - extra + lo;
+}
+
+template <typename T>
+__device__ __forceinline__ T clip_coord(T x, int64_t size, T* mult) {
+  if (x <= T(0)) {
+    *mult = T(0);
+    return T(0);
+  }
+  const T hi = T(size - 1);
+  if (x >= hi) {
+    *mult = T(0);
+    return hi;
+  }
+  *mult = T(1);
+  return x;
+}
+
+template <typename T>
+__device__ __forceinline__ Axis<T> make_axis(T g, int64_t size, int padding, bool align,
+                                             bool smooth) {
+  T x, m;
+  if (align) {
+    x = ((g + T(1)) / T(2)) * T(size - 1);
+    m = T(size - 1) / T(2);
+  } else {
+    x = ((g + T(1)) * T(size) - T(1)) / T(2);
+    m = T(size) / T(2);
+  }
+  if (padding == 1) {
+    T cm;
+    x = clip_coord(x, size, &cm);
+    m *= cm;
+  } else if (padding == 2) {
+    T rm, cm;
+    if (align) x = reflect_coord(x, 0, 2 * (size - 1), &rm);
+    else x = reflect_coord(x, -1, 2 * size - 1, &rm);
+    x = clip_coord(x, size, &cm);
+    m *= rm * cm;
+  }
+  Axis<T> a;
+  const T fl = floor(x);
+  a.i0 = (int64_t)fl;
+  const T t = x - fl;
+  T s = t, sp = T(1), spp = T(0);
+  if (smooth) {
+    s = t * t * (T(3) - T(2) * t);
+    sp = T(6) * t * (T(1) - t);
+    spp = T(6) - T(12) * t;
+  }
+  a.w1 = s;
+  a.w0 = T(1) - s;
+  a.dw = sp * m;
+  a.d2w = spp * m * m;
+  return a;
+}
+
+struct Geom {
+  int64_t off[8];
+  bool inb[8];
+};
+
+template <typename T>
+struct Point {
+  Axis<T> ax, ay, az;
+  Geom g;
+};
+
+template <typename T>
+__device__ __forceinline__ Point<T> make_point(const T* __restrict__ grid, int64_t pt,
+                                               const pv2_volume_desc& v, int padding, bool align,
+                                               bool smooth) {
+  Point<T> p;
+  p.ax = make_axis<T>(grid[pt * 3 + 0], v.w, padding, align, smooth);
+  p.ay = make_axis<T>(grid[pt * 3 + 1], v.h, padding, align, smooth);
+  p.az = make_axis<T>(grid[pt * 3 + 2], v.d, padding, align, smooth);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int64_t ix = p.ax.i0 + (c & 1), iy = p.ay.i0 + ((c >> 1) & 1), iz = p.az.i0 + (c >> 2);
+    p.g.inb[c] = ix >= 0 && ix < v.w && iy >= 0 && iy < v.h && iz >= 0 && iz < v.d;
+    p.g.off[c] = iz * v.sd + iy * v.sh + ix * v.sw;
+  }
+  return p;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// corner order: x fastest, then y, then z (the reference's tnw,tne,tsw,tse,bnw,... order)
+#define PV2_CORNER_WEIGHTS(p, w)                                        \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                       \
+    const T wx = (c & 1) ? p.ax.w1 : p.ax.w0;                           \
+    const T wy = (c & 2) ? p.ay.w1 : p.ay.w0;                           \
+    const T wz = (c & 4) ? p.az.w1 : p.az.w0;                           \
+    w[c] = wx * wy * wz;                                                \
+  }
+
+template <typename T>
+__global__ __launch_bounds__(256) void tri_fwd_kernel(const T* __restrict__ in, pv2_volume_desc v,
+                                                      const T* __restrict__ grid,
+                                                      pv2_points_desc pd, T* __restrict__ out,
+                                                      int padding, int align, int smooth) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
+    const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
+    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
+    T w[8];
+    PV2_CORNER_WEIGHTS(p, w)
+    const T* base = in + n * v.sn;
+    T* obase = out + n * pd.o_sn + q * pd.o_sp;
+    for (int64_t ch = lane; ch < v.c; ch += 64) {
+      const T* src = base + ch * v.sc;
+      T acc = T(0);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (p.g.inb[c]) acc += src[p.g.off[c]] * w[c];
+      obase[ch * pd.o_sc] = acc;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tri_bwd_kernel(const T* __restrict__ gout,
+                                                      const T* __restrict__ in, pv2_volume_desc v,
+                                                      const T* __restrict__ grid,
+                                                      pv2_points_desc pd, T* __restrict__ gin,
+                                                      T* __restrict__ ggrid, int padding,
+                                                      int align, int smooth) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
+    const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
+    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
+    T w[8], dx[8], dy[8], dz[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const T wx = (c & 1) ? p.ax.w1 : p.ax.w0, sx = (c & 1) ? p.ax.dw : -p.ax.dw;
+      const T wy = (c & 2) ? p.ay.w1 : p.ay.w0, sy = (c & 2) ? p.ay.dw : -p.ay.dw;
+      const T wz = (c & 4) ? p.az.w1 : p.az.w0, sz = (c & 4) ? p.az.dw : -p.az.dw;
+      w[c] = wx * wy * wz;
+      dx[c] = sx * wy * wz;
+      dy[c] = wx * sy * wz;
+      dz[c] = wx * wy * sz;
+    }
+    const T* base = in + n * v.sn;
+    T* gbase = gin ? gin + n * v.sn : nullptr;
+    const T* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    T gx = T(0), gy = T(0), gz = T(0);
+    for (int64_t ch = lane; ch < v.c; ch += 64) {
+      const T go = gobase[ch * pd.o_sc];
+      const T* src = base + ch * v.sc;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (p.g.inb[c]) {
+          const T val = src[p.g.off[c]];
+          gx += go * val * dx[c];
+          gy += go * val * dy[c];
+          gz += go * val * dz[c];
+          if (gbase) unsafeAtomicAdd(gbase + ch * v.sc + p.g.off[c], w[c] * go);
+        }
+      }
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    gz = wave_sum(gz);
+    if (lane == 0) {
+      ggrid[pt * 3 + 0] = gx;
+      ggrid[pt * 3 + 1] = gy;
+      ggrid[pt * 3 + 2] = gz;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tri_bwdbwd_kernel(
+    const T* __restrict__ hV, const T* __restrict__ hG, const T* __restrict__ in,
+    pv2_volume_desc v, const T* __restrict__ grid, const T* __restrict__ gout, pv2_points_desc pd,
+    T* __restrict__ gin2, T* __restrict__ ggrid2, T* __restrict__ ggout, int padding, int align,
+    int smooth) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
+    const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
+    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
+    const T hx = hG[pt * 3 + 0], hy = hG[pt * 3 + 1], hz = hG[pt * 3 + 2];
+    T w[8], dx[8], dy[8], dz[8], D[8], ex[8], ey[8], ez[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const T sgx = (c & 1) ? T(1) : T(-1), sgy = (c & 2) ? T(1) : T(-1),
+              sgz = (c & 4) ? T(1) : T(-1);
+      const T wx = (c & 1) ? p.ax.w1 : p.ax.w0, sx = sgx * p.ax.dw, cx = sgx * p.ax.d2w;
+      const T wy = (c & 2) ? p.ay.w1 : p.ay.w0, sy = sgy * p.ay.dw, cy = sgy * p.ay.d2w;
+      const T wz = (c & 4) ? p.az.w1 : p.az.w0, sz = sgz * p.az.dw, cz = sgz * p.az.d2w;
+      w[c] = wx * wy * wz;
+      dx[c] = sx * wy * wz;
+      dy[c] = wx * sy * wz;
+      dz[c] = wx * wy * sz;
+      D[c] = hx * dx[c] + hy * dy[c] + hz * dz[c];
+      // E_b = sum_a hG_a d_a d_b w_c
+      ex[c] = hx * (cx * wy * wz) + hy * (sx * sy * wz) + hz * (sx * wy * sz);
+      ey[c] = hx * (sx * sy * wz) + hy * (wx * cy * wz) + hz * (wx * sy * sz);
+      ez[c] = hx * (sx * wy * sz) + hy * (wx * sy * sz) + hz * (wx * wy * cz);
+    }
+    const T* base = in + n * v.sn;
+    const T* hbase = hV ? hV + n * v.sn : nullptr;
+    T* gbase = gin2 ? gin2 + n * v.sn : nullptr;
+    const T* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    T* ggobase = ggout + n * pd.o_sn + q * pd.o_sp;
+    T gx = T(0), gy = T(0), gz = T(0);
+    for (int64_t ch = lane; ch < v.c; ch += 64) {
+      const T go = gobase[ch * pd.o_sc];
+      const int64_t choff = ch * v.sc;
+      T ggo = T(0);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (p.g.inb[c]) {
+          const T val = base[choff + p.g.off[c]];
+          const T hv = hbase ? hbase[choff + p.g.off[c]] : T(0);
+          ggo += val * D[c] + hv * w[c];
+          gx += go * (hv * dx[c] + val * ex[c]);
+          gy += go * (hv * dy[c] + val * ey[c]);
+          gz += go * (hv * dz[c] + val * ez[c]);
+          if (gbase) unsafeAtomicAdd(gbase + choff + p.g.off[c], go * D[c]);
+        }
+      }
+      ggobase[ch * pd.o_sc] = ggo;
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    gz = wave_sum(gz);
+    if (lane == 0) {
+      ggrid2[pt * 3 + 0] = gx;
+      ggrid2[pt * 3 + 1] = gy;
+      ggrid2[pt * 3 + 2] = gz;
+    }
+  }
+}
+
+int check_desc(const pv2_volume_desc* vol, const pv2_points_desc* pts) {
+  PV2_REQUIRE(vol != nullptr && pts != nullptr, "trilinear: null descriptor");
+  PV2_REQUIRE(vol->c >= 1 && vol->d >= 1 && vol->h >= 1 && vol->w >= 1, "trilinear: empty volume");
+  PV2_REQUIRE(pts->points_per_n >= 1 || pts->n_points == 0, "trilinear: bad points_per_n");
+  return PV2_OK;
+}
+
+template <typename T>
+int run_fwd(const T* input, const pv2_volume_desc* vol, const T* grid, const pv2_points_desc* pts,
+            T* output, int padding, int align, int smooth, pv2_stream_t stream) {
+  if (int e = check_desc(vol, pts)) return e;
+  PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
+  if (pts->n_points == 0) return PV2_OK;
+  hipLaunchKernelGGL((tri_fwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)), dim3(256),
+                     0, (hipStream_t)stream, input, *vol, grid, *pts, output, padding, align,
+                     smooth);
+  return pv2::check_launch("trilinear_forward");
+}
+
+template <typename T>
+int run_bwd(const T* gout, const T* input, const pv2_volume_desc* vol, const T* grid,
+            const pv2_points_desc* pts, T* gin, T* ggrid, int padding, int align, int smooth,
+            pv2_stream_t stream) {
+  if (int e = check_desc(vol, pts)) return e;
+  PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
+  if (pts->n_points == 0) return PV2_OK;
+  hipLaunchKernelGGL((tri_bwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)), dim3(256),
+                     0, (hipStream_t)stream, gout, input, *vol, grid, *pts, gin, ggrid, padding,
+                     align, smooth);
+  return pv2::check_launch("trilinear_backward");
+}
+
+template <typename T>
+int run_bwdbwd(const T* hV, const T* hG, const T* input, const pv2_volume_desc* vol, const T* grid,
+               const T* gout, const pv2_points_desc* pts, T* gin2, T* ggrid2, T* ggout,
+               int padding, int align, int smooth, pv2_stream_t stream) {
+  if (int e = check_desc(vol, pts)) return e;
+  PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
+  if (pts->n_points == 0) return PV2_OK;
+  hipLaunchKernelGGL((tri_bwdbwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)),
+                     dim3(256), 0, (hipStream_t)stream, hV, hG, input, *vol, grid, gout, *pts,
+                     gin2, ggrid2, ggout, padding, align, smooth);
+  return pv2::check_launch("trilinear_backward_backward");
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_trilinear_forward_f32(const float* input, const pv2_volume_desc* vol, const float* grid,
+                              const pv2_points_desc* pts, float* output, int padding_mode,
+                              int align_corners, int apply_smoothstep, pv2_stream_t stream) {
+  return run_fwd<float>(input, vol, grid, pts, output, padding_mode, align_corners,
+                        apply_smoothstep, stream);
+}
+int pv2_trilinear_forward_f64(const double* input, const pv2_volume_desc* vol, const double* grid,
+                              const pv2_points_desc* pts, double* output, int padding_mode,
+                              int align_corners, int apply_smoothstep, pv2_stream_t stream) {
+  return run_fwd<double>(input, vol, grid, pts, output, padding_mode, align_corners,
+                         apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_f32(const float* grad_output, const float* input,
+                               const pv2_volume_desc* vol, const float* grid,
+                               const pv2_points_desc* pts, float* grad_input, float* grad_grid,
+                               int padding_mode, int align_corners, int apply_smoothstep,
+                               pv2_stream_t stream) {
+  return run_bwd<float>(grad_output, input, vol, grid, pts, grad_input, grad_grid, padding_mode,
+                        align_corners, apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_f64(const double* grad_output, const double* input,
+                               const pv2_volume_desc* vol, const double* grid,
+                               const pv2_points_desc* pts, double* grad_input, double* grad_grid,
+                               int padding_mode, int align_corners, int apply_smoothstep,
+                               pv2_stream_t stream) {
+  return run_bwd<double>(grad_output, input, vol, grid, pts, grad_input, grad_grid, padding_mode,
+                         align_corners, apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_backward_f32(const float* g_ginput, const float* g_ggrid,
+                                        const float* input, const pv2_volume_desc* vol,
+                                        const float* grid, const float* grad_output,
+                                        const pv2_points_desc* pts, float* grad_input2,
+                                        float* grad_grid2, float* grad_grad_output,
+                                        int padding_mode, int align_corners, int apply_smoothstep,
+                                        pv2_stream_t stream) {
+  return run_bwdbwd<float>(g_ginput, g_ggrid, input, vol, grid, grad_output, pts, grad_input2,
+                           grad_grid2, grad_grad_output, padding_mode, align_corners,
+                           apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_backward_f64(const double* g_ginput, const double* g_ggrid,
+                                        const double* input, const pv2_volume_desc* vol,
+                                        const double* grid, const double* grad_output,
+                                        const pv2_points_desc* pts, double* grad_input2,
+                                        double* grad_grid2, double* grad_grad_output,
+                                        int padding_mode, int align_corners, int apply_smoothstep,
+                                        pv2_stream_t stream) {
+  return run_bwdbwd<double>(g_ginput, g_ggrid, input, vol, grid, grad_output, pts, grad_input2,
+                            grad_grid2, grad_grad_output, padding_mode, align_corners,
+                            apply_smoothstep, stream);
+}
+
+}  // extern "C"

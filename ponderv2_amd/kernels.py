@@ -1,0 +1,355 @@
+"""Tensor-level wrappers over the C ABI: rulebook construction, sparse-conv arithmetic, dense
+scatter and the trilinear sampler.  Everything here runs on the current HIP stream of a CUDA
+(ROCm) device; CPU tensors are rejected - there is deliberately no fallback path.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PAIR_TILE, SCAN_CHUNK, WGRAD_TILE, PointsDesc, VolumeDesc
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "ponderv2_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+# --------------------------------------------------------------------------------------------
+# Rulebooks
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Rulebook:
+    """Indice pairs of one sparse conv, in canonical (offset k, output row) order."""
+
+    K: int
+    n_in: int
+    n_out: int
+    pair_in: torch.Tensor    # int32 [P]
+    pair_out: torch.Tensor   # int32 [P]
+    kstart: torch.Tensor     # int32 [K+1] device
+    kstart_host: np.ndarray  # int64 [K+1]
+    _tiles: dict = field(default_factory=dict)
+
+    @property
+    def n_pairs(self) -> int:
+        return int(self.kstart_host[-1])
+
+    def tiles(self, tile: int):
+        """(device prefix int32[K+1], total) of ceil(count_k / tile)."""
+        if tile not in self._tiles:
+            counts = np.diff(self.kstart_host)
+            pre = np.zeros(self.K + 1, dtype=np.int64)
+            np.cumsum((counts + tile - 1) // tile, out=pre[1:])
+            dev = torch.from_numpy(pre.astype(np.int32)).to(self.kstart.device, non_blocking=True)
+            self._tiles[tile] = (dev, int(pre[-1]))
+        return self._tiles[tile]
+
+    def transposed(self) -> "Rulebook":
+        """Same pairs with the roles of input and output swapped (inverse conv / grad-input)."""
+        rb = Rulebook(self.K, self.n_out, self.n_in, self.pair_out, self.pair_in, self.kstart,
+                      self.kstart_host)
+        rb._tiles = self._tiles
+        return rb
+
+
+def _compact(tbl: torch.Tensor, K: int, n: int, n_rows_dev: Optional[torch.Tensor]):
+    """Ordered compaction of a [K, n] table; one host sync to size the pair arrays."""
+    L = _lib.lib()
+    dev = tbl.device
+    nchunks = max(1, (n + SCAN_CHUNK - 1) // SCAN_CHUNK)
+    block_sums = torch.empty(K * nchunks, dtype=torch.int32, device=dev)
+    kstart = torch.empty(K + 1, dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_table_count(_ptr(tbl), K, n, _ptr(n_rows_dev), _ptr(block_sums),
+                                 _ptr(kstart), _stream(tbl)), "pv2_table_count")
+    kstart_host = kstart.cpu().numpy().astype(np.int64)  # the one sync of a rulebook build
+    P = int(kstart_host[-1])
+    pair_other = torch.empty(P, dtype=torch.int32, device=dev)
+    pair_row = torch.empty(P, dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_table_compact(_ptr(tbl), K, n, _ptr(n_rows_dev), _ptr(block_sums),
+                                   _ptr(pair_other), _ptr(pair_row), _stream(tbl)),
+               "pv2_table_compact")
+    return pair_other, pair_row, kstart, kstart_host
+
+
+def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
+    """coords int32 [N,4] (b,x,y,z) -> rulebook of a submanifold conv with an odd cubic kernel."""
+    _require_device(coords)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+    coords = coords.contiguous()
+    n = coords.shape[0]
+    dev = coords.device
+    K = ksize ** 3
+    if ksize == 1:
+        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        kh = np.array([0, n], dtype=np.int64)
+        return Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh)
+    L = _lib.lib()
+    tsize = 1 << max(4, int(2 * max(n, 1) - 1).bit_length())
+    keys = torch.empty(tsize, dtype=torch.int64, device=dev)
+    vals = torch.empty(tsize, dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_hash_build(_ptr(coords), n, _ptr(keys), _ptr(vals), tsize, _stream(coords)),
+               "pv2_hash_build")
+    nbr = torch.empty(K * max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_subm_neighbor_table(_ptr(coords), n, ksize, _ptr(keys), _ptr(vals), tsize,
+                                         _ptr(nbr), _stream(coords)), "pv2_subm_neighbor_table")
+    pair_in, pair_out, kstart, kstart_host = _compact(nbr, K, n, None)
+    return Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host)
+
+
+def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List[int]):
+    """Strided conv with kernel == stride, no padding.  Returns (rulebook, out_coords int32 [M,4]);
+    out_coords are sorted by (b,x,y,z)."""
+    _require_device(coords)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+    coords = coords.contiguous()
+    n = coords.shape[0]
+    dev = coords.device
+    L = _lib.lib()
+    K = stride ** 3
+    shape_c = (ctypes.c_int32 * 3)(*[int(s) for s in out_shape])
+    keys_a = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    keys_b = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    out_coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = int(L.pv2_downsample_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = _stream(coords)
+    _lib.check(L.pv2_downsample_unique(_ptr(coords), n, stride, shape_c, _ptr(keys_a),
+                                       _ptr(keys_b), _ptr(out_coords), _ptr(n_out_dev), _ptr(ws),
+                                       ws_bytes, st), "pv2_downsample_unique")
+    tbl = torch.empty(K * max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_downsample_table(_ptr(coords), n, stride, shape_c, _ptr(keys_b),
+                                      _ptr(n_out_dev), _ptr(tbl), n, st), "pv2_downsample_table")
+    pair_in, pair_out, kstart, kstart_host = _compact(tbl, K, n, n_out_dev)
+    n_out = int(n_out_dev.item())
+    rb = Rulebook(K, n, n_out, pair_in, pair_out, kstart, kstart_host)
+    return rb, out_coords[:n_out]
+
+
+# --------------------------------------------------------------------------------------------
+# Sparse conv arithmetic
+# --------------------------------------------------------------------------------------------
+def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[pair_out] += W[k] . feats[pair_in].  weight_okc: fp32 [c_out, K, c_in] contiguous."""
+    _require_device(feats, weight_okc)
+    assert feats.dtype == torch.float32 and weight_okc.dtype == torch.float32
+    feats = feats.contiguous()
+    weight_okc = weight_okc.contiguous()
+    c_out, K, c_in = weight_okc.shape
+    assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
+    if out is None:
+        out = torch.zeros((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
+    tile_start, n_tiles = rb.tiles(PAIR_TILE)
+    _lib.check(_lib.lib().pv2_spconv_forward(
+        _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
+        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), n_tiles, _ptr(out), rb.n_out,
+        _stream(feats)), "pv2_spconv_forward")
+    return out
+
+
+def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rulebook,
+                           c_out: int) -> torch.Tensor:
+    """dW [c_out, K, c_in] for out = conv(feats, W)."""
+    _require_device(feats, grad_out)
+    feats = feats.contiguous()
+    grad_out = grad_out.contiguous()
+    c_in = feats.shape[1]
+    assert grad_out.shape == (rb.n_out, c_out) and feats.shape[0] == rb.n_in
+    dw = torch.zeros((c_out, rb.K, c_in), dtype=torch.float32, device=feats.device)
+    tile_start, n_tiles = rb.tiles(WGRAD_TILE)
+    _lib.check(_lib.lib().pv2_spconv_backward_weight(
+        _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, rb.K, _ptr(rb.pair_in),
+        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), n_tiles, _ptr(dw),
+        _stream(feats)), "pv2_spconv_backward_weight")
+    return dw
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """Differentiable sparse conv on a fixed rulebook (features and weight get gradients)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight_okc, rb: Rulebook):
+        ctx.rb = rb
+        ctx.save_for_backward(feats, weight_okc)
+        return spconv_forward(feats, weight_okc, rb)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, weight_okc = ctx.saved_tensors
+        rb = ctx.rb
+        grad_out = grad_out.contiguous()
+        g_feats = g_w = None
+        if ctx.needs_input_grad[0]:
+            w_t = weight_okc.permute(2, 1, 0).contiguous()  # [c_in, K, c_out]
+            g_feats = spconv_forward(grad_out, w_t, rb.transposed())
+        if ctx.needs_input_grad[1]:
+            g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
+        return g_feats, g_w, None
+
+
+# --------------------------------------------------------------------------------------------
+# Dense scatter (to_dense)
+# --------------------------------------------------------------------------------------------
+class ScatterRowsFunction(torch.autograd.Function):
+    """out[index[i]] (+)= src[i], optionally averaged over the rows landing in each bin."""
+
+    @staticmethod
+    def forward(ctx, src, index, out, mean: bool):
+        _require_device(src, index, out)
+        src = src.contiguous()
+        index = index.reshape(-1).contiguous()
+        assert src.dtype == torch.float32 and index.dtype == torch.int64
+        assert out.is_contiguous() and out.dim() == 2 and out.shape[1] == src.shape[1]
+        m, c = src.shape
+        g = out.shape[0]
+        L = _lib.lib()
+        count = torch.zeros(g, dtype=torch.float32, device=src.device) if mean else None
+        _lib.check(L.pv2_scatter_add(_ptr(src), _ptr(index), m, c, _ptr(out), _ptr(count), g,
+                                     _stream(src)), "pv2_scatter_add")
+        if mean:
+            _lib.check(L.pv2_scatter_mean_finish(_ptr(out), _ptr(count), g, c, _stream(src)),
+                       "pv2_scatter_mean_finish")
+        ctx.save_for_backward(index, count if mean else index)
+        ctx.mean = mean
+        ctx.shape = (m, c, g)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        index, count = ctx.saved_tensors
+        m, c, g = ctx.shape
+        grad_out = grad_out.contiguous()
+        dsrc = torch.empty((m, c), dtype=torch.float32, device=grad_out.device)
+        _lib.check(_lib.lib().pv2_scatter_backward(
+            _ptr(grad_out), _ptr(index), _ptr(count) if ctx.mean else None, m, c, _ptr(dsrc), g,
+            _stream(grad_out)), "pv2_scatter_backward")
+        return dsrc, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# Trilinear sampler
+# --------------------------------------------------------------------------------------------
+_PADDING = {"zeros": 0, "border": 1, "reflection": 2}
+
+
+def _vol_desc(x: torch.Tensor) -> VolumeDesc:
+    n, c, d, h, w = x.shape
+    sn, sc, sd, sh, sw = x.stride()
+    return VolumeDesc(n, c, d, h, w, sn, sc, sd, sh, sw)
+
+
+def _dense_like(x: torch.Tensor) -> bool:
+    """True when x's storage is a permutation of a dense block (no overlap, no holes)."""
+    return x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def _out_layout(n, c, do, ho, wo, like: torch.Tensor, channels_last: bool):
+    """Allocate an (N,C,Do,Ho,Wo) tensor; channels-last storage keeps a point's channels adjacent
+    so the kernels' per-point lane sweep is contiguous."""
+    if channels_last:
+        buf = torch.empty((n, do, ho, wo, c), dtype=like.dtype, device=like.device)
+        return buf.permute(0, 4, 1, 2, 3)
+    return torch.empty((n, c, do, ho, wo), dtype=like.dtype, device=like.device)
+
+
+def _pts_desc(out_like: torch.Tensor) -> PointsDesc:
+    n, c, do, ho, wo = out_like.shape
+    sn, sc, sd, sh, sw = out_like.stride()
+    ppn = do * ho * wo
+    # point q = (d*Ho + h)*Wo + w must be addressable with a single stride
+    assert _single_point_stride(out_like), "output-shaped tensor needs a uniform point stride"
+    return PointsDesc(n * ppn, ppn, sn, sc, sw)
+
+
+def _single_point_stride(t: torch.Tensor) -> bool:
+    n, c, do, ho, wo = t.shape
+    sn, sc, sd, sh, sw = t.stride()
+    ok_h = ho == 1 or sh == sw * wo
+    ok_d = do == 1 or sd == sw * wo * ho
+    return ok_h and ok_d
+
+
+def _fn(name: str, dtype: torch.dtype):
+    if dtype == torch.float32:
+        return getattr(_lib.lib(), name + "_f32")
+    if dtype == torch.float64:
+        return getattr(_lib.lib(), name + "_f64")
+    raise TypeError(f"trilinear sampler supports float32/float64, got {dtype}")
+
+
+def trilinear_forward(inp, grid, padding_mode="zeros", align_corners=True, smooth=False):
+    _require_device(inp, grid)
+    assert inp.dim() == 5 and grid.dim() == 5 and grid.shape[-1] == 3 and grid.shape[0] == inp.shape[0]
+    if not _dense_like(inp):
+        inp = inp.contiguous()
+    grid = grid.contiguous()
+    n, c = inp.shape[:2]
+    _, do, ho, wo, _ = grid.shape
+    out = _out_layout(n, c, do, ho, wo, inp, channels_last=True)
+    vd, pd = _vol_desc(inp), _pts_desc(out)
+    _lib.check(_fn("pv2_trilinear_forward", inp.dtype)(
+        _ptr(inp), ctypes.byref(vd), _ptr(grid), ctypes.byref(pd), _ptr(out),
+        _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
+        "pv2_trilinear_forward")
+    return out
+
+
+def trilinear_backward(grad_out, inp, grid, padding_mode, align_corners, smooth, need_input_grad):
+    _require_device(grad_out, inp, grid)
+    if not _dense_like(inp):
+        inp = inp.contiguous()
+    grid = grid.contiguous()
+    if not _single_point_stride(grad_out):
+        grad_out = grad_out.contiguous()
+    grad_grid = torch.empty_like(grid)
+    grad_in = torch.zeros_like(inp) if need_input_grad else None  # preserves inp's strides
+    if grad_in is not None:
+        assert grad_in.stride() == inp.stride()
+    vd, pd = _vol_desc(inp), _pts_desc(grad_out)
+    _lib.check(_fn("pv2_trilinear_backward", inp.dtype)(
+        _ptr(grad_out), _ptr(inp), ctypes.byref(vd), _ptr(grid), ctypes.byref(pd), _ptr(grad_in),
+        _ptr(grad_grid), _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
+        "pv2_trilinear_backward")
+    return grad_in, grad_grid
+
+
+def trilinear_backward_backward(g_ginput, g_ggrid, inp, grid, grad_out, padding_mode,
+                                align_corners, smooth, need_input_grad):
+    _require_device(g_ggrid, inp, grid, grad_out)
+    if not _dense_like(inp):
+        inp = inp.contiguous()
+    grid = grid.contiguous()
+    g_ggrid = g_ggrid.contiguous()
+    if not _single_point_stride(grad_out):
+        grad_out = grad_out.contiguous()
+    if g_ginput is not None and g_ginput.stride() != inp.stride():
+        tmp = torch.empty_like(inp)
+        tmp.copy_(g_ginput)
+        g_ginput = tmp
+    grad_in2 = torch.zeros_like(inp) if need_input_grad else None
+    grad_grid2 = torch.empty_like(grid)
+    gg_out = torch.empty_like(grad_out)  # same strides as grad_out (dense permutation)
+    assert gg_out.stride() == grad_out.stride()
+    vd, pd = _vol_desc(inp), _pts_desc(grad_out)
+    _lib.check(_fn("pv2_trilinear_backward_backward", inp.dtype)(
+        _ptr(g_ginput), _ptr(g_ggrid), _ptr(inp), ctypes.byref(vd), _ptr(grid), _ptr(grad_out),
+        ctypes.byref(pd), _ptr(grad_in2), _ptr(grad_grid2), _ptr(gg_out),
+        _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
+        "pv2_trilinear_backward_backward")
+    return grad_in2, grad_grid2, gg_out

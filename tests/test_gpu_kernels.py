@@ -1,0 +1,225 @@
+"""GPU parity tests of the C-ABI kernels against oracle/ (run with -m gpu on an MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import away_from_kinks, random_voxels
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ rulebooks (bit exact)
+@pytest.mark.parametrize("ksize", [3, 5])
+@pytest.mark.parametrize("seed,batch,n", [(0, 2, 1500), (1, 1, 5000), (2, 3, 37)])
+def test_subm_rulebook_bit_exact(device, ksize, seed, batch, n):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    coords = random_voxels(seed, batch=batch, n_per_batch=n)
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), ksize)
+    pin, pout, ks = orb.subm_rulebook(coords, ksize)
+    assert np.array_equal(rb.kstart_host, ks)
+    assert np.array_equal(_np(rb.pair_in), pin)
+    assert np.array_equal(_np(rb.pair_out), pout)
+
+
+def test_subm_rulebook_edge_cases(device):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    for coords in (np.zeros((0, 4), np.int32), np.array([[0, 0, 0, 0]], np.int32),
+                   np.array([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 0, 0]], np.int32)):
+        rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), 3)
+        pin, pout, ks = orb.subm_rulebook(coords, 3)
+        assert np.array_equal(rb.kstart_host, ks)
+        assert np.array_equal(_np(rb.pair_in), pin) and np.array_equal(_np(rb.pair_out), pout)
+
+
+@pytest.mark.parametrize("seed,batch,n", [(0, 2, 1500), (3, 1, 6000), (4, 2, 5)])
+def test_downsample_rulebook_bit_exact(device, seed, batch, n):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    coords = random_voxels(seed, batch=batch, n_per_batch=n)
+    shape = [(s - 2) // 2 + 1 for s in (40 + 96, 36 + 96, 20 + 96)]
+    rb, oc = K.build_downsample_rulebook(torch.from_numpy(coords).to(device), 2, shape)
+    ooc, pin, pout, ks = orb.downsample_rulebook(coords, 2, shape)
+    assert np.array_equal(_np(oc), ooc)
+    assert np.array_equal(rb.kstart_host, ks)
+    assert np.array_equal(_np(rb.pair_in), pin)
+    assert np.array_equal(_np(rb.pair_out), pout)
+    # chained levels: the next level is built from device-produced coordinates
+    rb2, oc2 = K.build_downsample_rulebook(oc, 2, [(s - 2) // 2 + 1 for s in shape])
+    ooc2, pin2, pout2, ks2 = orb.downsample_rulebook(ooc, 2, [(s - 2) // 2 + 1 for s in shape])
+    assert np.array_equal(_np(oc2), ooc2) and np.array_equal(_np(rb2.pair_in), pin2)
+
+
+def test_downsample_drops_out_of_shape(device):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    coords = np.array([[0, 0, 0, 0], [0, 4, 0, 0], [0, 1, 1, 1], [0, 3, 3, 3]], np.int32)
+    shape = [2, 2, 2]  # spatial 5 -> (5-2)//2+1 = 2 : the voxel at x=4 has no output
+    rb, oc = K.build_downsample_rulebook(torch.from_numpy(coords).to(device), 2, shape)
+    ooc, pin, pout, ks = orb.downsample_rulebook(coords, 2, shape)
+    assert np.array_equal(_np(oc), ooc) and rb.n_pairs == 3
+    assert np.array_equal(_np(rb.pair_in), pin) and np.array_equal(_np(rb.pair_out), pout)
+
+
+# ------------------------------------------------------------------ conv arithmetic
+def _oracle_conv(feats, w, pin, pout, ks, n_out):
+    from oracle.sparse_ops import sparse_conv
+
+    return sparse_conv(feats, w, torch.from_numpy(pin.astype(np.int64)),
+                       torch.from_numpy(pout.astype(np.int64)), ks, n_out)
+
+
+@pytest.mark.parametrize("c_in,c_out,ksize", [(6, 32, 5), (32, 32, 3), (32, 64, 3), (96, 96, 3),
+                                               (128, 96, 1), (384, 256, 3), (256, 256, 3), (64, 7, 3)])
+def test_spconv_forward_backward_vs_oracle(device, c_in, c_out, ksize):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(c_in * 1000 + c_out)
+    coords = random_voxels(5, batch=2, n_per_batch=700)
+    n = len(coords)
+    feats = torch.randn(n, c_in)
+    w = torch.randn(c_out, ksize ** 3, c_in) * 0.1
+    gout = torch.randn(n, c_out)
+    pin, pout, ks = orb.subm_rulebook(coords, ksize)
+
+    f_ref = feats.double().requires_grad_(True)
+    w_ref = w.double().requires_grad_(True)
+    ref = _oracle_conv(f_ref, w_ref, pin, pout, ks, n)
+    ref.backward(gout.double())
+
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), ksize)
+    f_dev = feats.to(device).requires_grad_(True)
+    w_dev = w.to(device).requires_grad_(True)
+    out = K.SparseConvFunction.apply(f_dev, w_dev, rb)
+    out.backward(gout.to(device))
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+    assert rel(out, ref.detach()) < 1e-5
+    assert rel(f_dev.grad, f_ref.grad) < 1e-5
+    assert rel(w_dev.grad, w_ref.grad) < 1e-5
+
+
+def test_spconv_down_and_inverse_vs_oracle(device):
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(7)
+    coords = random_voxels(6, batch=2, n_per_batch=2500)
+    n = len(coords)
+    shape = [68, 66, 58]
+    ooc, pin, pout, ks = orb.downsample_rulebook(coords, 2, shape)
+    m = len(ooc)
+    c_in, c_out = 32, 64
+    feats, w = torch.randn(n, c_in), torch.randn(c_out, 8, c_in) * 0.1
+    w_inv = torch.randn(c_in, 8, c_out) * 0.1
+    rb, oc = K.build_downsample_rulebook(torch.from_numpy(coords).to(device), 2, shape)
+    down = K.spconv_forward(feats.to(device), w.to(device), rb)
+    ref_down = _oracle_conv(feats.double(), w.double(), pin, pout, ks, m)
+    assert (down.double().cpu() - ref_down).abs().max() < 1e-4 * ref_down.abs().max()
+    up = K.spconv_forward(down, w_inv.to(device), rb.transposed())
+    ref_up = _oracle_conv(ref_down, w_inv.double(), pout, pin, ks, n)
+    assert (up.double().cpu() - ref_up).abs().max() < 1e-4 * ref_up.abs().max()
+
+
+# ------------------------------------------------------------------ scatter mean
+def test_scatter_mean_vs_oracle(device):
+    from oracle.scatter import scatter as oscatter
+    from ponderv2_amd.torch_scatter import scatter
+
+    torch.manual_seed(0)
+    m, c, g = 5000, 96, 700
+    src = torch.randn(m, c)
+    idx = torch.randint(0, g, (m, 1))
+    gout = torch.randn(g, c)
+    s_ref = src.double().requires_grad_(True)
+    ref = oscatter(s_ref, idx, dim=0, reduce="mean", out=torch.zeros(g, c, dtype=torch.double))
+    ref.backward(gout.double())
+    s_dev = src.to(device).requires_grad_(True)
+    out = scatter(s_dev, idx.to(device), dim=0, reduce="mean", out=torch.zeros(g, c, device=device))
+    out.backward(gout.to(device))
+    assert (out.double().cpu() - ref.detach()).abs().max() < 1e-5
+    assert (s_dev.grad.double().cpu() - s_ref.grad).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------ trilinear sampler
+@pytest.mark.parametrize("padding_mode", ["zeros", "border", "reflection"])
+@pytest.mark.parametrize("align_corners", [True, False])
+def test_sampler_matches_grid_sample(device, padding_mode, align_corners):
+    """The reference's own pin: libs/smooth-sampler/smooth_sampler/modules.py:104-130."""
+    from ponderv2_amd.smooth_sampler import SmoothSampler
+
+    torch.manual_seed(3)
+    inp = torch.rand(2, 2, 2, 3, 11, device=device, requires_grad=True)
+    grid = (torch.rand(2, 2, 1, 5, 3, device=device) * 2 - 1).requires_grad_(True)
+    out1 = SmoothSampler.apply(inp, grid, padding_mode, align_corners, False)
+    out2 = torch.nn.functional.grid_sample(inp, grid, padding_mode=padding_mode,
+                                           align_corners=align_corners)
+    assert torch.allclose(out1, out2, atol=1e-6)
+    g1 = torch.autograd.grad(out1, [inp, grid], torch.ones_like(out1), create_graph=True)
+    g2 = torch.autograd.grad(out2, [inp, grid], torch.ones_like(out2))
+    assert torch.allclose(g1[0], g2[0], atol=1e-5)
+    assert torch.allclose(g1[1], g2[1], atol=1e-4)
+
+
+@pytest.mark.parametrize("padding_mode", ["zeros", "border", "reflection"])
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("smooth", [True, False])
+def test_sampler_gradcheck_fp64(device, padding_mode, align_corners, smooth):
+    """modules.py:132-156: gradcheck + gradgradcheck in float64 (eps 1e-4, atol 1e-3, rtol 1e-2)."""
+    from ponderv2_amd.smooth_sampler import SmoothSampler
+
+    torch.manual_seed(11)
+    inp = torch.rand(2, 2, 2, 3, 11, dtype=torch.double, device=device).requires_grad_(True)
+    grid = torch.rand(2, 2, 1, 5, 3, dtype=torch.double) * 2 - 1
+    if padding_mode == "zeros":
+        grid = grid * 1.2  # exercise out-of-volume corners too
+    grid = away_from_kinks(grid, (11, 3, 2), align_corners).to(device).requires_grad_(True)
+    fn = lambda a, b: SmoothSampler.apply(a, b, padding_mode, align_corners, smooth)  # noqa: E731
+    torch.autograd.gradcheck(fn, [inp, grid], eps=1e-4, atol=1e-3, rtol=1e-2, nondet_tol=1e-9)
+    torch.autograd.gradgradcheck(fn, [inp, grid], eps=1e-4, atol=1e-3, rtol=1e-2, nondet_tol=1e-9)
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_sampler_second_order_vs_oracle_f32(device, channels_last):
+    """fp32, hot-path configuration (zeros / align_corners / no smoothstep), C=128, both layouts;
+    a scalar loss that uses d(out)/d(grid) exercises backward-of-backward like the eikonal term."""
+    from oracle.sampler import SmoothSampler as OSampler
+    from ponderv2_amd.smooth_sampler import SmoothSampler
+
+    torch.manual_seed(5)
+    C, D, H, W, R, S = 128, 6, 9, 10, 37, 11
+    vol = torch.randn(1, C, D, H, W)
+    grid = away_from_kinks(torch.rand(1, 1, R, S, 3) * 2.3 - 1.15, (W, H, D), True)
+    proj = torch.randn(C)
+
+    def run(sampler, vol_t, grid_t):
+        vol_t = vol_t.requires_grad_(True)
+        grid_t = grid_t.requires_grad_(True)
+        out = sampler.apply(vol_t, grid_t, "zeros", True, False)
+        feat = out.squeeze(0).squeeze(1).permute(1, 2, 0)  # (R,S,C)
+        sdf = torch.tanh(feat @ proj.to(feat))
+        (gp,) = torch.autograd.grad(sdf.sum(), grid_t, create_graph=True)
+        loss = ((gp.norm(dim=-1) - 1) ** 2).mean() + (feat ** 2).mean() + sdf.mean()
+        gv, gg = torch.autograd.grad(loss, [vol_t, grid_t])
+        return out.detach(), gp.detach(), gv, gg
+
+    ref = run(OSampler, vol.double(), grid.double())
+    v_dev = vol.to(device)
+    if channels_last:
+        v_dev = v_dev.contiguous(memory_format=torch.channels_last_3d)
+    got = run(SmoothSampler, v_dev, grid.to(device))
+    for name, a, b in zip(("out", "dgrid", "gvol", "ggrid"), got, ref):
+        err = (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        assert err < 2e-4, (name, err)
