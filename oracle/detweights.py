@@ -1,0 +1,34 @@
+"""Closed-form "random-looking" tensors keyed by a name, so the reference model and the product
+model get IDENTICAL parameters without sharing an RNG stream or a checkpoint file."""
+import math
+import zlib
+
+import torch
+
+
+def formula_tensor(name, shape, scale=1.0, dtype=torch.float32):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    phase = (zlib.crc32(name.encode()) % 100003) / 100003.0 * 2 * math.pi
+    idx = torch.arange(n, dtype=torch.float64)
+    vals = torch.sin(idx * 0.7391 + phase) * torch.cos(idx * 0.0137 + 2 * phase)
+    return (vals * scale).reshape(*shape).to(dtype)
+
+
+def fill_deterministic(module):
+    """Overwrite every parameter with >1 element: weights ~ U-ish(+-sqrt(3/fan_in)) * 0.8,
+    norm scales 1 +- 0.1, biases +- 0.05.  Scalars (variance, logit_scale, ...) keep their init."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.numel() <= 1:
+                continue
+            if p.dim() >= 2:
+                fan_in = p.numel() // p.shape[0]
+                v = formula_tensor(name, p.shape, 0.8 * math.sqrt(3.0 / fan_in) * 2.0)
+            elif name.endswith("weight"):  # norm scale
+                v = 1.0 + formula_tensor(name, p.shape, 0.2)
+            else:
+                v = formula_tensor(name, p.shape, 0.1)
+            p.copy_(v.to(p.dtype))
+    return module

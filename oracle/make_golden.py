@@ -1,0 +1,195 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own model files on the host.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it):
+    python -m oracle.make_golden
+The reference's Python is imported unmodified through oracle/ref_shims.py; its out-of-tree
+dependencies (spconv, smooth_sampler, torch_scatter) are served by the oracle restatements, so
+these vectors pin (a) our re-written model/render code against the reference's control flow and
+arithmetic and (b) the HIP kernels end to end.  Random draws made by the reference
+(torch.rand / torch.randperm) are recorded into the fixtures so tests replay them exactly.
+
+Weights are filled by a closed-form rule of the parameter NAME and element index
+(oracle/detweights.py), so neither side needs a checkpoint or a matching RNG stream.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_shims  # noqa: E402
+from oracle.detweights import fill_deterministic, formula_tensor  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+SMALL_BACKBONE = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0, base_channels=16,
+                      channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 1, 1, 1, 1, 1, 1, 1))
+
+
+class Recorder:
+    """Records every torch.rand / torch.randperm result made while active."""
+
+    def __enter__(self):
+        self.rand, self.perm = [], []
+        self._rand, self._perm = torch.rand, torch.randperm
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k)
+            self.rand.append(t.detach().cpu().clone())
+            return t
+
+        def randperm(*a, **k):
+            t = self._perm(*a, **k)
+            self.perm.append(t.detach().cpu().clone())
+            return t
+
+        torch.rand, torch.randperm = rand, randperm
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randperm = self._rand, self._perm
+
+
+def spunet_case():
+    """Reference SpUNetBase (spconv_unet_v1m1_base.py:86-278) on the oracle sparse-conv runtime,
+    float64, two small scenes."""
+    from helpers import random_voxels
+    from ponder.models.builder import MODELS
+
+    coords = random_voxels(21, batch=2, extent=(48, 40, 24), n_per_batch=900)
+    counts = np.bincount(coords[:, 0])
+    grid_coord = torch.from_numpy(coords[:, 1:].astype(np.int64))
+    n = len(coords)
+    feat = formula_tensor("spunet.feat", (n, 6), 1.0).double()
+    cfg = dict(SMALL_BACKBONE)
+    model = MODELS.build(cfg).double()
+    fill_deterministic(model)
+    model.train()
+    feat.requires_grad_(True)
+    out = model(dict(grid_coord=grid_coord, feat=feat,
+                     offset=torch.from_numpy(np.cumsum(counts)).long()))
+    probe = formula_tensor("spunet.probe", tuple(out.shape), 1.0).double()
+    (out * probe).sum().backward()
+    names = ["conv_input.0.weight", "enc.1.block0.conv1.weight", "down.2.0.weight",
+             "up.1.0.weight", "dec.0.block0.proj.0.weight", "dec.3.block0.bn2.bias"]
+    params = dict(model.named_parameters())
+    np.savez_compressed(
+        os.path.join(GOLDEN, "spunet_small.npz"), coords=coords, out=out.detach().numpy(),
+        dfeat=feat.grad.numpy(), grad_names=np.array(names),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)})
+    print("spunet_small: out", tuple(out.shape), "mean |out|", out.abs().mean().item())
+
+
+def _render_cfg():
+    from ponderv2_amd.ponder.utils.config import Config
+
+    cfg = Config.fromfile(os.path.join(ref_shims.REFERENCE_ROOT,
+                                       "configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py"))
+    return cfg
+
+
+def neus_case_impl(ConfigDict):
+    from ponder.models.ponder.render_utils import RayBundle, build_renderer
+
+    cfg = _render_cfg()
+    rcfg = ConfigDict(cfg.model.renderer.to_dict())
+    torch.manual_seed(0)
+    renderer = build_renderer(rcfg)
+    fill_deterministic(renderer)
+    renderer.train()
+    C, D, H, W, R = 128, 8, 16, 16, 40
+    volume = (formula_tensor("neus.volume", (C, D, H, W), 0.6)).requires_grad_(True)
+    # rays start outside/inside the padded unit cube and point towards its centre
+    o = formula_tensor("neus.origins", (R, 3), 0.9)
+    tgt = formula_tensor("neus.targets", (R, 3), 0.25)
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    targets = dict(depth=(formula_tensor("neus.depth", (R, 1), 0.5) + 0.45),
+                   rgb=formula_tensor("neus.rgb", (R, 3), 0.5) + 0.5,
+                   semantic=formula_tensor("neus.sem", (R, 512), 1.0))
+    targets["depth"][::7] = -0.001          # invalid-depth rays
+    targets["semantic"][3::5] = 0.0         # rays without a language target
+    torch.manual_seed(123)
+    with Recorder() as rec:
+        out = renderer(RayBundle(origins=o, directions=d), [volume])
+        losses = renderer.get_loss(out, targets)
+    loss = sum(v for k, v in losses.items() if "loss" in k)
+    loss.backward()
+    params = dict(renderer.named_parameters())
+    gnames = ["field.sdf_decoder.lin0.weight", "field.sdf_decoder.fc_c.1.weight",
+              "field.rgb_decoder.fc_c.0.weight", "field.semantic_decoder.lin0.bias",
+              "field.deviation_network.variance"]
+    keys = ["rgb", "semantic", "depth", "normal", "weights", "sdf", "gradients", "z_vals"]
+    np.savez_compressed(
+        os.path.join(GOLDEN, "neus_head.npz"),
+        origins=o.numpy(), directions=d.numpy(),
+        rand0=rec.rand[0].numpy(), rand1=rec.rand[1].numpy(), n_rand=len(rec.rand),
+        loss_names=np.array(list(losses.keys())),
+        loss_values=np.array([float(v) for v in losses.values()]),
+        dvolume=volume.grad.numpy().astype(np.float32), grad_names=np.array(gnames),
+        **{f"out_{k}": out[k].detach().numpy() for k in keys},
+        **{f"tgt_{k}": v.numpy() for k, v in targets.items()},
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    print("neus_head:", {k: round(float(v), 6) for k, v in losses.items()}, "n_rand", len(rec.rand))
+
+
+def ponder_indoor_case(ConfigDict):
+    """Reference PonderIndoor.forward (ponder_indoor_base.py:694-706) end to end on a synthetic
+    two-scene batch with a reduced backbone / grid, fp32, training mode."""
+    from ponder.models.builder import MODELS
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    cfg = _render_cfg()
+    mcfg = cfg.model.to_dict()
+    mcfg["backbone"] = dict(SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96))
+    mcfg.update(grid_shape=(32, 32, 8), ray_nsample=20)
+    torch.manual_seed(0)
+    model = MODELS.build(ConfigDict(mcfg))
+    fill_deterministic(model)
+    model.train()
+    scene_kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64))
+    batch = collate_fn([make_scene(100, **scene_kw), make_scene(101, **scene_kw)])
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(321)
+    with Recorder() as rec:
+        out = model(inp)
+    out["loss"].backward()
+    # pixels the reference picked: where(mask>0) order + randperm[:n]  (:546-551)
+    B, V, H, W = batch["depth"].shape
+    pix = np.zeros((B, V, 20, 2), dtype=np.int64)
+    it = iter(rec.perm)
+    for b in range(B):
+        for v in range(V):
+            ys, xs = torch.where(batch["depth"][b, v] > 0)
+            sel = next(it)[:20]
+            pix[b, v, :, 0], pix[b, v, :, 1] = ys[sel].numpy(), xs[sel].numpy()
+    params = dict(model.named_parameters())
+    gnames = ["backbone.conv_input.0.weight", "backbone.dec.0.block0.conv2.weight",
+              "proj_net.encoders.0.basic_module.conv.weight", "proj_net.final_conv.bias",
+              "renderer.field.sdf_decoder.lin1.weight"]
+    np.savez_compressed(
+        os.path.join(GOLDEN, "ponder_indoor_small.npz"), ray_pixels=pix,
+        rands=np.array(len(rec.rand)),
+        **{f"rand_{i}": r.numpy() for i, r in enumerate(rec.rand)},
+        out_names=np.array(list(out.keys())), out_values=np.array([float(v) for v in out.values()]),
+        grad_names=np.array(gnames),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    print("ponder_indoor_small:", {k: round(float(v), 6) for k, v in out.items()},
+          "rand draws", [tuple(r.shape) for r in rec.rand])
+
+
+def main():
+    ref_shims.install()
+    os.makedirs(GOLDEN, exist_ok=True)
+    from ponderv2_amd.ponder.utils.config import ConfigDict  # attribute dict, like addict's
+
+    spunet_case()
+    neus_case_impl(ConfigDict)
+    ponder_indoor_case(ConfigDict)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,366 @@
+"""PonderIndoor-v2: point-cloud pre-training by differentiable neural rendering (indoor RGB-D).
+
+Mirror of ponder/models/ponder/ponder_indoor_base.py (PonderIndoor :19-706).  Same constructor
+arguments, registry name, parameter names and ``forward(data_dict) -> dict(loss=..., ...)``
+contract; the data flow is re-organised for the GPU:
+
+  * ``to_unit_cube`` (:344-444), ``ray_sample`` (:499-620) and ``to_dense`` (:177-342) run as
+    batched device ops over all scenes / views at once - no Python loop per view, no
+    ``.cpu().numpy()`` round trips; rays are generated only for the sampled pixels instead of for
+    the whole 480x640 image;
+  * the sparse->dense scatter-mean writes straight into a channels-last (B,Z,Y,X,C) grid with one
+    launch for the whole batch (csrc/dense_scatter.hip), which is also the layout the trilinear
+    sampler wants for the projected volume;
+  * pixel choice is injectable (``data_dict["ray_pixels"]``) because the reference draws it with
+    the CPU generator (:548-551).
+Reference quirks preserved: class id 0 gets a zero semantic target (:594-596, Q3); ``ppt_loss`` is
+reported but not added to ``loss`` (:699-704, Q10).
+"""
+import math
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ponderv2_amd.torch_scatter import scatter
+from ..builder import MODELS, build_model
+from ..losses import build_criteria
+from ..utils import offset2batch
+from .render_utils import RayBundle, build_renderer
+
+
+def stub_text_embeddings(num_classes, dim=512, seed=0):
+    """Deterministic stand-in for CLIP text embeddings (no network / weights in this environment):
+    unit vectors from a seeded generator.  Same role as load_semantic (:85-118)."""
+    g = torch.Generator().manual_seed(seed)
+    e = torch.randn(num_classes, dim, generator=g)
+    return e / e.norm(dim=-1, keepdim=True)
+
+
+@MODELS.register_module("PonderIndoor-v2")
+class PonderIndoor(nn.Module):
+    def __init__(self, backbone, projection, renderer, mask=None, grid_shape=64, grid_size=0.02,
+                 val_ray_split=10240, ray_nsample=128, padding=0.1, backbone_out_channels=96,
+                 context_channels=256, pool_type="mean", render_semantic=False, conditions=None,
+                 template=None, clip_model=None, class_name=None, valid_index=None,
+                 ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True):
+        super().__init__()
+        self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
+        self.grid_size, self.pool_type = grid_size, pool_type
+        self.val_ray_split, self.ray_nsample = val_ray_split, ray_nsample
+        self.mask = mask
+        self.dense_channels_last = dense_channels_last
+        h = 0.5 + padding / 2
+        self.bounds = [[-h, -h, -h], [h, h, h]]
+        if mask is not None:
+            p = nn.Parameter(torch.zeros(1, mask.channel))
+            nn.init.trunc_normal_(p, mean=0, std=0.02, a=-0.02, b=0.02)
+            self.register_parameter("mtoken", p)
+        self.backbone = build_model(backbone)
+        self.proj_net = build_model(projection)
+        self.renderer = build_renderer(renderer)
+        self.render_semantic = render_semantic
+        self.conditions, self.valid_index = conditions, valid_index
+        self.embedding_table = nn.Embedding(len(conditions), context_channels)
+        self.backbone_out_channels = backbone_out_channels
+        self.ppt_loss_weight = ppt_loss_weight if render_semantic else 0.0
+        if render_semantic:
+            self.load_semantic(template, clip_model, class_name)
+        if self.ppt_loss_weight > 0:
+            assert ppt_criteria is not None, "Please provide PPT's loss function."
+            self.ppt_criteria = build_criteria(ppt_criteria)
+
+    # ------------------------------------------------------------------ language targets
+    def load_semantic(self, template, clip_model, class_name):
+        embedding = None
+        try:  # real CLIP text encoder when the package and its weights are present
+            import clip  # noqa: F401
+
+            embedding, scale = self._clip_text_embeddings(template, clip_model, class_name)
+        except Exception:
+            embedding, scale = stub_text_embeddings(len(class_name)), math.log(100.0)
+        self.register_buffer("class_embedding", embedding.float().cpu())
+        self.logit_scale = nn.Parameter(torch.tensor(float(scale)), requires_grad=False)
+        if self.ppt_loss_weight > 0:
+            self.proj_head = nn.Linear(self.backbone_out_channels, embedding.shape[1])
+
+    @staticmethod
+    def _clip_text_embeddings(template, clip_model, class_name):
+        import clip
+
+        model, _ = clip.load(clip_model, device="cpu", download_root="./.cache/clip")
+        model.requires_grad_(False)
+        templates = [template] if isinstance(template, str) else list(template)
+        prompts = [t.replace("[x]", n) for n in class_name for t in templates]
+        emb = model.encode_text(clip.tokenize(prompts))
+        emb = emb / emb.norm(dim=-1, keepdim=True)
+        if len(templates) > 1:
+            # prompts are class-major; the reference reshapes as (T, K, D) (:101-104), kept as is
+            emb = emb.reshape(len(templates), len(class_name), -1).mean(0)
+            emb = emb / emb.norm(dim=-1, keepdim=True)
+        return emb.float(), float(model.logit_scale)
+
+    def _condition_index(self, data_dict):
+        condition = data_dict["condition"][0]
+        assert condition in self.conditions
+        return self.conditions.index(condition)
+
+    # ------------------------------------------------------------------ backbone
+    def extract_feature(self, data_dict):
+        if self.mask is not None:
+            data_dict["feat"] = self._mask_blocks(data_dict)
+        if "condition" in data_dict:
+            idx = torch.tensor([self._condition_index(data_dict)], device=data_dict["coord"].device)
+            data_dict["context"] = self.embedding_table(idx)
+        data_dict["sparse_backbone_feat"] = self.backbone(data_dict)
+        return data_dict
+
+    def _mask_blocks(self, data_dict):
+        """Replace the features of a random ``ratio`` of the size^3-voxel blocks by ``mtoken``
+        (reference :133-162), per scene, without host loops."""
+        grid_coord, feat, offset = data_dict["grid_coord"], data_dict["feat"], data_dict["offset"]
+        batch = offset2batch(offset)
+        block = torch.cat([batch[:, None], torch.div(grid_coord, self.mask.size).int()], dim=-1)
+        block, inverse = block.unique(sorted=True, return_inverse=True, dim=0)
+        scene = block[:, 0].long()
+        n_scene = torch.bincount(scene, minlength=offset.numel())
+        # rank of a random key inside each scene < keep count  <=>  block is kept
+        key = torch.rand(block.shape[0], device=block.device) + scene.to(torch.float32) * 2.0
+        order = torch.argsort(key)
+        start = torch.cumsum(n_scene, 0) - n_scene
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=order.device)
+        rank = rank - start[scene]
+        keep = rank < torch.round(n_scene.to(torch.float32) * (1 - self.mask.ratio)).long()[scene]
+        feat = feat.clone()
+        feat[~keep[inverse]] = self.mtoken.to(feat.dtype)
+        return feat
+
+    # ------------------------------------------------------------------ geometry (no grad)
+    @torch.no_grad()
+    def to_unit_cube(self, data_dict, z_level=-0.5):
+        coords = data_dict["coord"]
+        offset = data_dict["offset"]
+        B = offset.numel()
+        batch = offset2batch(offset)
+        idx = batch[:, None].expand(-1, 3)
+
+        def seg_minmax(x):
+            lo = x.new_full((B, 3), float("inf")).scatter_reduce(0, idx, x, "amin")
+            hi = x.new_full((B, 3), float("-inf")).scatter_reduce(0, idx, x, "amax")
+            return lo - 1e-5, hi + 1e-5
+
+        lo, hi = seg_minmax(coords)
+        loc = (lo + hi) / 2
+        extent = (hi - lo).max(dim=1).values
+        scale = 1.0 / extent
+        tmp_z = (coords[:, 2] - loc[batch, 2]) * scale[batch]
+        z_min = tmp_z.new_full((B,), float("inf")).scatter_reduce(0, batch, tmp_z, "amin")
+
+        eye = torch.eye(4, device=coords.device).expand(B, 4, 4)
+        S_loc = eye.clone()
+        S_loc[:, :3, 3] = -loc
+        S_scale = eye * scale[:, None, None]
+        S_scale[:, 3, 3] = 1
+        S_loc2 = eye.clone()
+        S_loc2[:, 2, 3] = -z_min + z_level
+        S = S_loc2 @ S_scale @ S_loc  # (B,4,4)
+
+        Sp = S[batch]
+        new = (Sp[:, :3, :3] @ coords[:, :, None]).squeeze(-1) + Sp[:, :3, 3]
+        new = torch.clip(new, min=-0.5 + 1e-5, max=0.5 - 1e-5).float()
+
+        pose = data_dict["extrinsic"].clone().float()  # (B,V,4,4)
+        pose[:, :, 3, 3] = 1
+        data_dict["extrinsic"] = pose @ torch.linalg.inv(S.float())[:, None]
+        data_dict["depth_scale"] = scale * data_dict["depth_scale"]
+        data_dict["pc_scale"] = extent.to(data_dict["depth_scale"].dtype)
+        lo2, hi2 = seg_minmax(new)
+        pc = data_dict["pc_scale"]
+        data_dict["bbox"] = (torch.stack([lo2, hi2], dim=1) + 0.5) * pc[:, None, None]
+        data_dict["coord"] = (new + 0.5) * pc[batch][:, None]
+        return data_dict
+
+    @torch.no_grad()
+    def get_mask_at_box(self, ray_o, ray_d):
+        """Slab test of rays against the padded unit cube (reference :480-497, numpy there).
+        ray_o (...,3) one origin per view, ray_d (...,n,3)."""
+        d = ray_d / torch.linalg.norm(ray_d, dim=-1, keepdim=True)
+        d = torch.where((d < 1e-5) & (d > -1e-10), torch.full_like(d, 1e-5), d)
+        d = torch.where((d > -1e-5) & (d < 1e-10), torch.full_like(d, -1e-5), d)
+        inv = (1.0 / d).double()
+        lo = torch.tensor(self.bounds[0], dtype=torch.float64, device=d.device)
+        hi = torch.tensor(self.bounds[1], dtype=torch.float64, device=d.device)
+        o = ray_o.double()[..., None, :]
+        ta, tb = (lo - o) * inv, (hi - o) * inv
+        near = torch.minimum(ta, tb).max(dim=-1).values.clamp(min=0.1)
+        far = torch.maximum(ta, tb).min(dim=-1).values
+        return near < far
+
+    @torch.no_grad()
+    def _choose_pixels(self, valid, n):
+        """valid (B,V,H,W) bool -> flat pixel ids (B,V,n): a uniform random subset of the valid
+        pixels of every view (device-side replacement of randperm on the host)."""
+        B, V, H, W = valid.shape
+        key = torch.rand((B, V, H * W), device=valid.device)
+        key = torch.where(valid.reshape(B, V, -1), key, torch.full_like(key, 2.0))
+        return torch.topk(key, n, dim=-1, largest=False).indices
+
+    @torch.no_grad()
+    def ray_sample(self, data_dict):
+        colors = data_dict["rgb"].float()        # (B,V,H,W,3)
+        depths = data_dict["depth"].float()      # (B,V,H,W)
+        intr = data_dict["intrinsic"].float()
+        extr = data_dict["extrinsic"].float()    # (B,V,4,4) world(unit cube) -> camera
+        dscale = data_dict["depth_scale"].float()
+        B, V, H, W = depths.shape
+        n = self.ray_nsample
+        dev = depths.device
+        if intr.dim() == 3:
+            intr = intr[:, None].expand(B, V, *intr.shape[-2:])
+        Kmat = intr[..., :3, :3]
+
+        if self.render_semantic:
+            index2semantic = data_dict.get("index2semantic")
+            if "condition" in data_dict:
+                vi = list(self.valid_index[self._condition_index(data_dict)])
+                index2semantic = self.class_embedding[vi, :]
+                data_dict["index2semantic"] = index2semantic
+            if index2semantic is None:
+                index2semantic = self.class_embedding
+            index2semantic = index2semantic.to(dev)
+
+        pix = data_dict.get("ray_pixels")  # optional (B,V,n,2) [y,x] from the caller
+        if pix is None:
+            flat = self._choose_pixels(depths > 0, n)
+        else:
+            flat = (pix[..., 0].long() * W + pix[..., 1].long()).to(dev)
+        py, px = flat // W, flat % W
+
+        # camera -> world
+        RT = torch.zeros((B, V, 4, 4), device=dev)
+        RT[..., :3, :4] = extr[..., :3, :4]
+        RT[..., 3, 3] = 1
+        pose = torch.linalg.inv(RT)
+        p = torch.stack([px.float(), py.float(), torch.ones_like(px, dtype=torch.float32)], -1)
+        p = (torch.linalg.inv(Kmat)[:, :, None] @ p[..., None]).squeeze(-1)       # (B,V,n,3)
+        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+        v = (pose[:, :, None, :3, :3] @ v[..., None]).squeeze(-1)
+        ray_d = F.normalize(v, dim=-1)
+        ray_o = pose[:, :, None, :3, 3].expand_as(ray_d)
+
+        def pick(img):  # (B,V,H,W,...) -> (B,V,n,...)
+            f = img.reshape(B, V, H * W, *img.shape[4:])
+            ix = flat.reshape(B, V, n, *([1] * (f.dim() - 3))).expand(-1, -1, -1, *f.shape[3:])
+            return torch.gather(f, 2, ix)
+
+        color = pick(colors)
+        depth = pick(depths * (depths > 0).float()) * dscale[:, None, None]
+        # plane-to-plane depth -> distance along the ray
+        cam2world = torch.linalg.inv(extr)
+        ez = torch.tensor([0.0, 0.0, 1.0, 1.0], device=dev)
+        plane = (cam2world @ ez)[..., :3] - ray_o[:, :, 0]
+        plane = plane / torch.linalg.norm(plane, dim=-1, keepdim=True)
+        depth = depth / (ray_d * plane[:, :, None]).sum(-1)
+
+        inside = self.get_mask_at_box(ray_o[:, :, 0], ray_d)
+        color = torch.where(inside[..., None], color, torch.zeros_like(color))
+        depth = torch.where(inside, depth, torch.full_like(depth, -0.001))
+        ray_dict = dict(ray_o=ray_o.reshape(B, V * n, 3).float(),
+                        ray_d=ray_d.reshape(B, V * n, 3).float(),
+                        rgb=color.reshape(-1, 3).float(), depth=depth.reshape(-1, 1).float())
+        if self.render_semantic:
+            sem = pick(data_dict["semantic"])
+            sem = torch.where(inside, sem, torch.full_like(sem, -1))
+            assert index2semantic.shape[0] > 0
+            table = torch.cat([index2semantic.new_zeros((1, index2semantic.shape[1])),
+                               index2semantic], 0)
+            # class 0 and ignore (-1) -> zero row (reference uses `semantic > 0`)
+            row = torch.where(sem > 0, sem + 1, torch.zeros_like(sem)).long()
+            ray_dict["semantic"] = table[row.reshape(-1)].float()
+        return ray_dict
+
+    @torch.no_grad()
+    def prepare_ray(self, data_dict):
+        data_dict = self.to_unit_cube(data_dict)
+        return self.ray_sample(data_dict), data_dict
+
+    # ------------------------------------------------------------------ dense volume
+    def grid_sample(self, data_dict):
+        data_dict["bbox"] = (data_dict["bbox"] // self.grid_size).int()
+        data_dict["resolution"] = (data_dict["bbox"][:, 1] - data_dict["bbox"][:, 0]).max(dim=1)[0].int() + 1
+        return data_dict
+
+    def to_dense(self, data_dict):
+        """Scatter-mean the per-voxel backbone features into a (B, C, Z, Y, X) grid.  Only the
+        down-sampling branch of the reference (:199-216, scene resolution >= grid) is a device
+        path; rooms are always in it (a 0.64 m scene would be needed to leave it)."""
+        feat = data_dict["sparse_backbone_feat"]
+        batch = offset2batch(data_dict["offset"])
+        B, C = data_dict["offset"].numel(), feat.shape[1]
+        G0, G1, G2 = self.grid_shape
+        voxel = (data_dict["coord"] // self.grid_size).int()
+        res = (data_dict["resolution"] + 1).to(torch.float32)  # current_resolution, (B,)
+        if "resolution_host_checked" not in data_dict:
+            if bool((res < min(self.grid_shape)).any()):
+                raise NotImplementedError(
+                    "to_dense: a scene is smaller than the dense grid (resolution < "
+                    f"{min(self.grid_shape)}); the reference's up-sampling branches are not "
+                    "implemented on the device path")
+        shape = torch.tensor(self.grid_shape, dtype=torch.float32, device=feat.device)
+        cell = res[:, None] / shape[None, :]            # (B,3) anisotropic bin size in voxels
+        g = (voxel // cell[batch]).long()
+        if self.dense_channels_last:
+            lin = (g[:, 2] * G1 + g[:, 1]) * G0 + g[:, 0]  # memory order (Z,Y,X), channels last
+        else:
+            lin = (g[:, 0] * G1 + g[:, 1]) * G2 + g[:, 2]  # the reference's (X,Y,Z) order
+        lin = lin + batch * (G0 * G1 * G2)
+        grid = feat.new_zeros((B * G0 * G1 * G2, C))
+        grid = scatter(feat, lin[:, None], dim=0, reduce=self.pool_type, out=grid)
+        if self.dense_channels_last:
+            return grid.view(B, G2, G1, G0, C).permute(0, 4, 1, 2, 3)  # channels_last_3d view
+        return grid.view(B, G0, G1, G2, C).permute(0, 4, 3, 2, 1).contiguous()
+
+    def prepare_volume(self, data_dict):
+        data_dict = self.grid_sample(data_dict)
+        volume = self.proj_net(self.to_dense(data_dict))
+        if self.dense_channels_last:
+            volume = volume.contiguous(memory_format=torch.channels_last_3d)
+        return [volume]
+
+    # ------------------------------------------------------------------ rendering + losses
+    def render_func(self, ray_dict, volume_feature):
+        outs = []
+        for i in range(ray_dict["ray_o"].shape[0]):
+            vols = [v[i] for v in volume_feature]
+            o, d = ray_dict["ray_o"][i], ray_dict["ray_d"][i]
+            if self.training:
+                outs.append(self.renderer(RayBundle(origins=o, directions=d), vols))
+            else:
+                parts = [self.renderer(RayBundle(origins=po, directions=pd), vols)
+                         for po, pd in zip(o.split(self.val_ray_split), d.split(self.val_ray_split))]
+                outs.append({k: torch.cat([p[k].detach() for p in parts], 0) for k in parts[0]})
+        return {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
+
+    def render_loss(self, render_out, ray_dict):
+        loss_dict = self.renderer.get_loss(render_out, ray_dict)
+        return sum(v for k, v in loss_dict.items() if "loss" in k), loss_dict
+
+    def ppt_loss(self, data_dict):
+        feat = self.proj_head(data_dict["sparse_backbone_feat"])
+        feat = feat / feat.norm(dim=-1, keepdim=True)
+        vi = list(self.valid_index[self._condition_index(data_dict)])
+        sim = feat @ self.class_embedding[vi, :].t()
+        return self.ppt_criteria(self.logit_scale.exp() * sim, data_dict["segment"])
+
+    def forward(self, data_dict):
+        data_dict = self.extract_feature(data_dict)
+        ray_dict, data_dict = self.prepare_ray(data_dict)
+        volume_feature = self.prepare_volume(data_dict)
+        render_out = self.render_func(ray_dict, volume_feature)
+        loss, loss_dict = self.render_loss(render_out, ray_dict)
+        out = dict(loss=loss, **loss_dict)
+        if self.ppt_loss_weight > 0:
+            out["ppt_loss"] = self.ppt_loss(data_dict)  # reported only (reference :699-704)
+        return out

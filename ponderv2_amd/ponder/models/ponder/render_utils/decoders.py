@@ -1,0 +1,47 @@
+"""Point-feature MLP heads of the SDF field (ponder/models/ponder/render_utils/decoders.py:
+SDFDecoder :6-36 Softplus(beta=100), RGBDecoder :39-76 ReLU + sigmoid, SemanticDecoder :79-109
+ReLU).  All three share one skeleton: x = fc_p(p) * points_factor; per layer l:
+x = lin_l(x + fc_c[l](feat)), activation on all but the last layer."""
+import torch
+import torch.nn as nn
+
+
+class _ConditionedMLP(nn.Module):
+    def __init__(self, in_dim, out_dim, hidden_size, n_blocks, points_factor, activation,
+                 out_activation=None):
+        super().__init__()
+        dims = [hidden_size] * (n_blocks + 1) + [out_dim]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, f"lin{l}", nn.Linear(dims[l], dims[l + 1]))
+        self.fc_c = nn.ModuleList(nn.Linear(in_dim, hidden_size) for _ in range(self.num_layers - 1))
+        self.fc_p = nn.Linear(3, hidden_size)
+        self.activation = activation
+        self.out_activation = out_activation
+        self.points_factor = points_factor
+
+    def forward(self, points, point_feats):
+        x = self.fc_p(points) * self.points_factor
+        last = self.num_layers - 2
+        for l in range(self.num_layers - 1):
+            x = getattr(self, f"lin{l}")(x + self.fc_c[l](point_feats))
+            if l < last:
+                x = self.activation(x)
+        return x if self.out_activation is None else self.out_activation(x)
+
+
+class SDFDecoder(_ConditionedMLP):
+    def __init__(self, in_dim, out_dim, hidden_size=256, n_blocks=5, points_factor=1.0, **kwargs):
+        super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor,
+                         nn.Softplus(beta=100))
+
+
+class RGBDecoder(_ConditionedMLP):
+    def __init__(self, in_dim, out_dim=3, hidden_size=256, n_blocks=5, points_factor=1.0, **kwargs):
+        super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor, nn.ReLU(),
+                         out_activation=torch.sigmoid)
+
+
+class SemanticDecoder(_ConditionedMLP):
+    def __init__(self, in_dim, out_dim, hidden_size=256, n_blocks=5, points_factor=1.0, **kwargs):
+        super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor, nn.ReLU())

@@ -1,0 +1,36 @@
+"""Alpha-compositing reductions (ponder/models/ponder/render_utils/renderers.py: RGB :5-28,
+depth :31-51 incl. the clip to the global [min, max] of the sample starts :50, normal :54-63,
+semantic :66-75)."""
+import torch
+from torch import nn
+
+
+class RGBRenderer(nn.Module):
+    def __init__(self, background_color=(0.0, 0.0, 0.0)):
+        super().__init__()
+        self.background_color = background_color
+
+    def forward(self, rgb, weights):
+        comp = torch.sum(weights * rgb, dim=-2)
+        acc = torch.sum(weights, dim=-2)
+        comp = comp + comp.new_tensor(self.background_color) * (1.0 - acc)
+        if not self.training:
+            comp = comp.clamp(0.0, 1.0)
+        return comp
+
+
+class DepthRenderer(nn.Module):
+    def forward(self, ray_samples, weights):
+        steps = ray_samples.frustums.starts
+        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        return torch.clip(depth, steps.min(), steps.max())
+
+
+class NormalRenderer(nn.Module):
+    def forward(self, normals, weights):
+        return torch.sum(weights * normals, dim=-2)
+
+
+class SemanticRenderer(nn.Module):
+    def forward(self, semantic, weights):
+        return torch.sum(weights * semantic, dim=-2)

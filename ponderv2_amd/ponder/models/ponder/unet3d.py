@@ -1,0 +1,130 @@
+"""Dense 3-D projection networks that follow the sparse backbone: ``UNet3D-v1m2`` (indoor) and
+``SimpleConv3D-v1m1`` (outdoor).
+
+Mirror of ponder/models/ponder/unet3d.py (SimpleConv3D :16-34, create_conv :45-122, SingleConv
+:125-156, Encoder :292-356, Decoder :359-444, Upsampling :447-493, Abstract3DUNet :530-671,
+UNet3Dv1m2 :710-743) restricted to what the v1m2 variant instantiates: SingleConv levels in
+"bcr" order (BatchNorm3d -> Conv3d(no bias) -> ReLU), MaxPool3d(2) between encoder levels,
+ConvTranspose3d(k3, s2, p1, output_size=skip size) + summation joining in the decoder, and a
+final 1x1 conv.  These are stock dense convolutions: they go to MIOpen through PyTorch-ROCm
+(north_star names no custom kernel for them); parameter names match the reference.
+"""
+import torch
+import torch.nn as nn
+
+from ..builder import MODELS
+
+
+@MODELS.register_module("SimpleConv3D-v1m1")
+class SimpleConv3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, stride=1):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv3d(in_channels, out_channels, kernel_size=kernel_size, padding=padding,
+                      stride=stride),
+            nn.BatchNorm3d(out_channels), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class SingleConv(nn.Sequential):
+    """One conv level; ``order`` spells the op sequence: b(atchnorm) g(roupnorm) c(onv) r(elu)
+    l(eaky relu) e(lu).  The conv carries a bias only when no norm is present."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="bcr", num_groups=8,
+                 padding=1):
+        super().__init__()
+        assert "c" in order and order[0] not in "rle"
+        has_norm = "b" in order or "g" in order
+        for pos, op in enumerate(order):
+            before_conv = pos < order.index("c")
+            width = in_channels if before_conv else out_channels
+            if op == "c":
+                self.add_module("conv", nn.Conv3d(in_channels, out_channels, kernel_size,
+                                                  padding=padding, bias=not has_norm))
+            elif op == "b":
+                self.add_module("batchnorm", nn.BatchNorm3d(width))
+            elif op == "g":
+                groups = num_groups if width >= num_groups else 1
+                assert width % groups == 0
+                self.add_module("groupnorm", nn.GroupNorm(groups, width))
+            elif op == "r":
+                self.add_module("ReLU", nn.ReLU(inplace=True))
+            elif op == "l":
+                self.add_module("LeakyReLU", nn.LeakyReLU(0.1, inplace=True))
+            elif op == "e":
+                self.add_module("ELU", nn.ELU(inplace=True))
+            else:
+                raise ValueError(f"unsupported layer type {op!r} in order {order!r}")
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, out_channels, apply_pooling=True, order="bcr", num_groups=8):
+        super().__init__()
+        self.pooling = nn.MaxPool3d(kernel_size=(2, 2, 2)) if apply_pooling else None
+        self.basic_module = SingleConv(in_channels, out_channels, order=order,
+                                       num_groups=num_groups)
+
+    def forward(self, x):
+        if self.pooling is not None:
+            x = self.pooling(x)
+        return self.basic_module(x)
+
+
+class Upsampling(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=(2, 2, 2)):
+        super().__init__()
+        self.upsample = nn.ConvTranspose3d(in_channels, out_channels, kernel_size=kernel_size,
+                                           stride=scale_factor, padding=1)
+
+    def forward(self, encoder_features, x):
+        return self.upsample(x, encoder_features.size()[2:])
+
+
+class Decoder(nn.Module):
+    """Learned 2x upsampling, sum with the skip features, one conv level."""
+
+    def __init__(self, in_channels, out_channels, order="bcr", num_groups=8):
+        super().__init__()
+        self.upsampling = Upsampling(in_channels, out_channels)
+        self.basic_module = SingleConv(out_channels, out_channels, order=order,
+                                       num_groups=num_groups)
+
+    def forward(self, encoder_features, x):
+        return self.basic_module(encoder_features + self.upsampling(encoder_features, x))
+
+
+@MODELS.register_module("UNet3D-v1m2")
+class UNet3Dv1m2(nn.Module):
+    def __init__(self, in_channels, out_channels, final_sigmoid=False, f_maps=32,
+                 layer_order="bcr", num_groups=1, num_levels=4, is_segmentation=False,
+                 testing=False, **kwargs):
+        super().__init__()
+        if isinstance(f_maps, int):
+            f_maps = [f_maps * 2 ** k for k in range(num_levels)]
+        self.testing = testing
+        widths = [in_channels] + list(f_maps)
+        self.encoders = nn.ModuleList(
+            Encoder(widths[i], widths[i + 1], apply_pooling=i > 0, order=layer_order,
+                    num_groups=num_groups) for i in range(len(f_maps)))
+        rev = list(reversed(f_maps))
+        self.decoders = nn.ModuleList(
+            Decoder(rev[i], rev[i + 1], order=layer_order, num_groups=num_groups)
+            for i in range(len(rev) - 1))
+        self.final_conv = nn.Conv3d(f_maps[0], out_channels, 1)
+        self.final_activation = None
+        if is_segmentation:
+            self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
+
+    def forward(self, x):
+        skips = []
+        for encoder in self.encoders:
+            x = encoder(x)
+            skips.insert(0, x)
+        for decoder, skip in zip(self.decoders, skips[1:]):
+            x = decoder(skip, x)
+        x = self.final_conv(x)
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x)
+        return x

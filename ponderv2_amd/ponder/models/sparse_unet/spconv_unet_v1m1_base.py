@@ -1,0 +1,146 @@
+"""SpUNet-v1m1: the sparse 3-D U-Net backbone of PonderV2, on the MI355X sparse-conv runtime.
+
+Mirror of ponder/models/sparse_unet/spconv_unet_v1m1_base.py (BasicBlock :21-83, SpUNetBase
+:86-278).  Module names and parameter shapes are kept so reference checkpoints load: stem
+SubMConv k5 -> 4 x (SparseConv k2 s2 + residual blocks) -> 4 x (SparseInverseConv k2 + skip concat
++ residual blocks); BatchNorm1d(eps=1e-3, momentum=0.01) and ReLU after every conv.
+"""
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ponderv2_amd.spconv import pytorch as spconv
+from ..builder import MODELS
+from ..utils import offset2batch
+
+
+def trunc_normal_(tensor, std=0.02):
+    # timm.models.layers.trunc_normal_(std=.02) == torch's, truncated at +-2 absolute
+    return nn.init.trunc_normal_(tensor, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class BasicBlock(spconv.SparseModule):
+    """conv-bn-relu-conv-bn, plus the (optionally 1x1-projected) input, then relu."""
+
+    expansion = 1
+
+    def __init__(self, in_channels, embed_channels, stride=1, norm_fn=None, indice_key=None,
+                 bias=False):
+        super().__init__()
+        assert norm_fn is not None
+        if in_channels == embed_channels:
+            self.proj = spconv.SparseSequential(nn.Identity())
+        else:
+            self.proj = spconv.SparseSequential(
+                spconv.SubMConv3d(in_channels, embed_channels, kernel_size=1, bias=False),
+                norm_fn(embed_channels))
+        conv = partial(spconv.SubMConv3d, kernel_size=3, stride=stride, padding=1, bias=bias,
+                       indice_key=indice_key)
+        self.conv1 = conv(in_channels, embed_channels)
+        self.bn1 = norm_fn(embed_channels)
+        self.relu = nn.ReLU()
+        self.conv2 = conv(embed_channels, embed_channels)
+        self.bn2 = norm_fn(embed_channels)
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.conv1(x)
+        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = self.conv2(y)
+        y = y.replace_feature(self.bn2(y.features))
+        shortcut = self.proj(x).features
+        return y.replace_feature(self.relu(y.features + shortcut))
+
+
+@MODELS.register_module("SpUNet-v1m1")
+class SpUNetBase(nn.Module):
+    def __init__(self, in_channels, num_classes, base_channels=32,
+                 channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2),
+                 cls_mode=False):
+        super().__init__()
+        assert len(layers) % 2 == 0 and len(layers) == len(channels)
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.base_channels, self.channels, self.layers = base_channels, channels, layers
+        self.num_stages = len(layers) // 2
+        self.cls_mode = cls_mode
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(in_channels, base_channels, kernel_size=5, padding=1, bias=False,
+                              indice_key="stem"),
+            norm_fn(base_channels), nn.ReLU())
+
+        self.down, self.up = nn.ModuleList(), nn.ModuleList()
+        self.enc = nn.ModuleList()
+        self.dec = nn.ModuleList() if not cls_mode else None
+        enc_c, dec_c = base_channels, channels[-1]
+        n = len(channels)
+        for s in range(self.num_stages):
+            self.down.append(spconv.SparseSequential(
+                spconv.SparseConv3d(enc_c, channels[s], kernel_size=2, stride=2, bias=False,
+                                    indice_key=f"spconv{s + 1}"),
+                norm_fn(channels[s]), nn.ReLU()))
+            self.enc.append(spconv.SparseSequential(OrderedDict(
+                (f"block{i}", BasicBlock(channels[s], channels[s], norm_fn=norm_fn,
+                                         indice_key=f"subm{s + 1}"))
+                for i in range(layers[s]))))
+            if not cls_mode:
+                self.up.append(spconv.SparseSequential(
+                    spconv.SparseInverseConv3d(channels[n - s - 2], dec_c, kernel_size=2,
+                                               bias=False, indice_key=f"spconv{s + 1}"),
+                    norm_fn(dec_c), nn.ReLU()))
+                self.dec.append(spconv.SparseSequential(OrderedDict(
+                    (f"block{i}", BasicBlock(dec_c + enc_c if i == 0 else dec_c, dec_c,
+                                             norm_fn=norm_fn, indice_key=f"subm{s}"))
+                    for i in range(layers[n - s - 1]))))
+            enc_c, dec_c = channels[s], channels[n - s - 2]
+
+        final_in = channels[-1] if not cls_mode else channels[self.num_stages - 1]
+        self.final = (spconv.SubMConv3d(final_in, num_classes, kernel_size=1, padding=1, bias=True)
+                      if num_classes > 0 else spconv.Identity())
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        # only Linear / SubMConv3d / BatchNorm1d are touched; strided and inverse convs keep the
+        # runtime's default init (reference :230-240)
+        if isinstance(m, (nn.Linear, spconv.SubMConv3d)):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm1d):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, input_dict):
+        grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
+        batch = offset2batch(offset)
+        sparse_shape = input_dict.get("sparse_shape")
+        if sparse_shape is None:  # one device->host read, as the reference's .tolist() (:248)
+            sparse_shape = torch.add(torch.max(grid_coord, dim=0).values, 96).tolist()
+        x = spconv.SparseConvTensor(
+            features=feat,
+            indices=torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous(),
+            spatial_shape=sparse_shape, batch_size=offset.numel())
+        x = self.conv_input(x)
+        skips = [x]
+        for s in range(self.num_stages):
+            x = self.enc[s](self.down[s](x))
+            skips.append(x)
+        x = skips.pop(-1)
+        if not self.cls_mode:
+            for s in reversed(range(self.num_stages)):
+                x = self.up[s](x)
+                skip = skips.pop(-1)
+                x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
+                x = self.dec[s](x)
+        x = self.final(x)
+        if self.cls_mode:
+            b = x.indices[:, 0].long()
+            summed = x.features.new_zeros((offset.numel(), x.features.shape[1])).index_add(
+                0, b, x.features)
+            x = x.replace_feature(summed / torch.bincount(b, minlength=offset.numel())
+                                  .clamp(min=1).unsqueeze(1))
+        return x.features

@@ -1,0 +1,14 @@
+"""offset <-> batch helpers (ponder/models/utils.py:11-30), computed on the device with no Python
+loop over scenes and no host round trip."""
+import torch
+
+
+def offset2batch(offset: torch.Tensor) -> torch.Tensor:
+    """(B,) cumulative point counts -> (N,) int64 scene index of every point."""
+    offset = offset.long()
+    counts = torch.diff(offset, prepend=offset.new_zeros(1))
+    return torch.repeat_interleave(torch.arange(offset.numel(), device=offset.device), counts)
+
+
+def batch2offset(batch: torch.Tensor) -> torch.Tensor:
+    return torch.cumsum(batch.bincount(), dim=0).long()

@@ -1,0 +1,156 @@
+"""Shared drivers for the golden-vector tests: build the PRODUCT model, give it the fixture's
+weights / random draws, run it on `device`, and compare with what the reference produced
+(fixtures written by oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle.detweights import fill_deterministic, formula_tensor
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SMALL_BACKBONE = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0, base_channels=16,
+                      channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 1, 1, 1, 1, 1, 1, 1))
+
+# model section of configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py (reference :16-152),
+# restated here because the reference tree is not available on the GPU box.
+RENDERER = dict(
+    type="NeuSModel",
+    field=dict(type="SDFField",
+               sdf_decoder=dict(in_dim=64, out_dim=65, hidden_size=128, n_blocks=1, pos_enc=False,
+                                points_factor=0.0),
+               rgb_decoder=dict(in_dim=134, out_dim=3, hidden_size=128, n_blocks=0, pos_enc=False,
+                                points_factor=0.0),
+               semantic_decoder=dict(in_dim=131, out_dim=512, hidden_size=128, n_blocks=0,
+                                     points_factor=0.0),
+               beta_init=0.3, use_gradient=True, volume_type="default", padding_mode="zeros",
+               share_volume=False, norm_pts=True, norm_padding=0.1),
+    collider=dict(type="AABBBoxCollider", near_plane=0.01,
+                  bbox=[-0.55, -0.55, -0.55, 0.55, 0.55, 0.55]),
+    sampler=dict(type="NeuSSampler", initial_sampler="UniformSampler", num_samples=96,
+                 num_samples_importance=36, num_upsample_steps=1, train_stratified=True,
+                 single_jitter=False),
+    loss=dict(sensor_depth_truncation=0.05, temperature=0.01,
+              weights=dict(eikonal_loss=0.01, free_space_loss=1.0, sdf_loss=10.0, depth_loss=1.0,
+                           rgb_loss=10.0, semantic_loss=0.1)))
+
+CLASS_NAMES = ("wall", "floor", "cabinet", "bed", "chair", "sofa", "table", "door", "window",
+               "bookshelf", "picture", "counter", "desk", "curtain", "refridgerator",
+               "shower curtain", "toilet", "sink", "bathtub", "otherfurniture")
+
+
+def indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=256):
+    return dict(type="PonderIndoor-v2", backbone=backbone,
+                projection=dict(type="UNet3D-v1m2", in_channels=96, out_channels=128),
+                renderer=RENDERER, mask=None, grid_shape=grid_shape, grid_size=0.02,
+                val_ray_split=10240, ray_nsample=ray_nsample, padding=0.1, pool_type="mean",
+                render_semantic=True, conditions=("ScanNet",), template="a photo of a [x]",
+                clip_model="ViT-B/16", class_name=CLASS_NAMES, valid_index=(tuple(range(20)),),
+                ppt_loss_weight=1.0,
+                ppt_criteria=[dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)])
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+class ReplayRand:
+    """Stands in for torch.rand inside the samplers: returns the reference's recorded draws."""
+
+    def __init__(self, draws, device):
+        self.draws, self.device, self.i = list(draws), device, 0
+
+    def __call__(self, shape, dtype=None, device=None):
+        t = torch.as_tensor(self.draws[self.i])
+        self.i += 1
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(self.device)
+
+
+def run_spunet(device, dtype):
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "spunet_small.npz"))
+    coords = g["coords"]
+    counts = np.bincount(coords[:, 0])
+    model = build_model(ConfigDict(SMALL_BACKBONE)).to(dtype)
+    fill_deterministic(model)
+    model = model.to(device).train()
+    n = len(coords)
+    feat = formula_tensor("spunet.feat", (n, 6), 1.0).to(dtype).to(device).requires_grad_(True)
+    out = model(dict(grid_coord=torch.from_numpy(coords[:, 1:].astype(np.int64)).to(device),
+                     feat=feat, offset=torch.from_numpy(np.cumsum(counts)).long().to(device)))
+    probe = formula_tensor("spunet.probe", tuple(out.shape), 1.0).to(dtype).to(device)
+    (out * probe).sum().backward()
+    params = dict(model.named_parameters())
+    errs = {"out": rel_err(out, g["out"]), "dfeat": rel_err(feat.grad, g["dfeat"])}
+    for i, name in enumerate(g["grad_names"]):
+        errs[str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs
+
+
+def run_neus(device):
+    from ponderv2_amd.ponder.models.ponder.render_utils import RayBundle, build_renderer
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "neus_head.npz"))
+    renderer = build_renderer(ConfigDict(RENDERER))
+    fill_deterministic(renderer)
+    renderer = renderer.to(device).train()
+    replay = ReplayRand([g["rand0"], g["rand1"]], device)
+    renderer.sampler.initial_sampler.rand = replay
+    renderer.sampler.pdf_sampler.rand = replay
+    volume = formula_tensor("neus.volume", (128, 8, 16, 16), 0.6).to(device)
+    if device.type == "cuda":
+        volume = volume.unsqueeze(0).contiguous(memory_format=torch.channels_last_3d).squeeze(0)
+    volume.requires_grad_(True)
+    o = torch.from_numpy(g["origins"]).to(device)
+    d = torch.from_numpy(g["directions"]).to(device)
+    targets = {k: torch.from_numpy(g[f"tgt_{k}"]).to(device) for k in ("depth", "rgb", "semantic")}
+    out = renderer(RayBundle(origins=o, directions=d), [volume])
+    losses = renderer.get_loss(out, targets)
+    sum(v for k, v in losses.items() if "loss" in k).backward()
+    errs = {}
+    for k in ("rgb", "semantic", "depth", "normal", "weights", "sdf", "gradients", "z_vals"):
+        errs["out_" + k] = rel_err(out[k], g["out_" + k])
+    for name, val in zip(g["loss_names"], g["loss_values"]):
+        errs["loss_" + str(name)] = abs(float(losses[str(name)]) - val) / (abs(val) + 1e-12)
+    errs["dvolume"] = rel_err(volume.grad, g["dvolume"])
+    params = dict(renderer.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs
+
+
+def run_ponder_indoor(device):
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "ponder_indoor_small.npz"))
+    cfg = indoor_model_cfg(dict(SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
+                           grid_shape=(32, 32, 8), ray_nsample=20)
+    cfg["template"] = ("a", "b")  # any template list: the stub embeddings do not depend on it
+    model = build_model(ConfigDict(cfg))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
+    kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64))
+    batch = collate_fn([make_scene(100, **kw), make_scene(101, **kw)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch["ray_pixels"] = torch.from_numpy(g["ray_pixels"])
+    out = model(batch)
+    out["loss"].backward()
+    errs = {}
+    for name, val in zip(g["out_names"], g["out_values"]):
+        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+    params = dict(model.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs

@@ -1,0 +1,29 @@
+"""CPU tests: the product's host-side model code (with oracle-backed kernel doubles) reproduces
+what the reference's own files produced (tests/golden/*.npz, oracle/make_golden.py)."""
+import pytest
+import torch
+
+import cpu_doubles
+import golden_cases as gc
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    cpu_doubles.install(monkeypatch)
+
+
+def test_spunet_topology_matches_reference(cpu_kernels):
+    errs = gc.run_spunet(torch.device("cpu"), torch.float64)
+    assert max(errs.values()) < 1e-9, errs
+
+
+def test_neus_head_matches_reference(cpu_kernels):
+    errs = gc.run_neus(torch.device("cpu"))
+    assert max(errs.values()) < 2e-4, errs
+
+
+def test_ponder_indoor_forward_matches_reference(cpu_kernels):
+    errs = gc.run_ponder_indoor(torch.device("cpu"))
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    assert max(errs.values()) < 5e-3, errs
