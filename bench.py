@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""PonderV2 pre-training throughput on MI355X: scenes/s (+ rays/s) of one training step
+(forward + backward + SGD step) of PonderIndoor-v2 / SpUNet-v1m1 on synthetic ScanNet-shaped
+scenes (BASELINE.json config 2: 2 scenes/GPU, 512 rays/scene; weak scaling over GPUs).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline     - the dominant hand-written kernel family, timed live with HIP events on the launch
+                 stream over the timed steps, against the gfx950 peak that bounds it;
+  kernels      - the same measurement for every instrumented kernel family;
+  cpu_baseline - the same model code on the host cores with the oracle's CPU kernels
+                 (rank 0, N=1 only; a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes-per-gpu", type=int, default=2)
+    ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--rays-per-view", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def model_cfg(rays_per_view):
+    import golden_cases as gc  # the ScanNet model section, restated (reference tree absent here)
+
+    backbone = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0,
+                    channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
+    cfg = gc.indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
+    return cfg
+
+
+class KernelTimer:
+    """Wraps the kernels.* launch functions with HIP events recorded on the launch stream and
+    accumulates algorithmic flops / bytes per kernel family."""
+
+    def __init__(self):
+        self.records = {}   # family -> list of (start, end, flops, bytes)
+        self._orig = {}
+
+    def _add(self, fam, s, e, flops, nbytes):
+        self.records.setdefault(fam, []).append((s, e, flops, nbytes))
+
+    def install(self):
+        import ponderv2_amd.kernels as K
+
+        timer = self
+
+        def wrap(name, fam, cost):
+            orig = getattr(K, name)
+            self._orig[name] = orig
+
+            def fn(*a, **k):
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = orig(*a, **k)
+                e.record()
+                flops, nbytes = cost(*a, **k)
+                timer._add(fam, s, e, flops, nbytes)
+                return out
+
+            setattr(K, name, fn)
+
+        def conv_cost(feats, w, rb, out=None):
+            c_out, kk, c_in = w.shape
+            p = rb.n_pairs
+            return (2.0 * p * c_in * c_out,
+                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + kk * c_in * c_out) + 8.0 * p)
+
+        def wgrad_cost(feats, gout, rb, c_out):
+            c_in = feats.shape[1]
+            p = rb.n_pairs
+            return (2.0 * p * c_in * c_out,
+                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + rb.K * c_in * c_out) + 8.0 * p)
+
+        def tri_cost_factory(mult):
+            def cost(*a, **k):
+                grid = a[1] if mult == 1 else (a[2] if mult == 2 else a[3])
+                inp = a[0] if mult == 1 else (a[1] if mult == 2 else a[2])
+                pts = grid.numel() // 3
+                c = inp.shape[1]
+                return (0.0, pts * 8.0 * c * inp.element_size() * mult)
+            return cost
+
+        wrap("spconv_forward", "spconv_fwd_kernel (fwd+dgrad)", conv_cost)
+        wrap("spconv_backward_weight", "spconv_wgrad_kernel", wgrad_cost)
+        wrap("trilinear_forward", "tri_fwd_kernel", tri_cost_factory(1))
+        wrap("trilinear_backward", "tri_bwd_kernel", tri_cost_factory(2))
+        wrap("trilinear_backward_backward", "tri_bwdbwd_kernel", tri_cost_factory(3))
+
+    def uninstall(self):
+        import ponderv2_amd.kernels as K
+
+        for name, orig in self._orig.items():
+            setattr(K, name, orig)
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = []
+        for fam, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            flops = sum(r[2] for r in recs)
+            nbytes = sum(r[3] for r in recs)
+            out.append(dict(kernel=fam, launches=len(recs), total_ms=ms,
+                            avg_us=1e3 * ms / max(len(recs), 1),
+                            tflops=flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                            alg_gbs=nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                            alg_flops_per_launch=flops / max(len(recs), 1),
+                            alg_bytes_per_launch=nbytes / max(len(recs), 1)))
+        return sorted(out, key=lambda r: -r["total_ms"])
+
+
+def make_batch(rank, scenes, views, device):
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    samples = [make_scene(1000 * rank + i, num_views=views, image_hw=(480, 640))
+               for i in range(scenes)]
+    batch = collate_fn(samples)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def clone_batch(batch):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def cpu_baseline(args):
+    """Same model code, oracle CPU kernels, host cores: one scene (20 000 voxels, 128 rays),
+    one full training step (forward + backward + SGD), fp32."""
+    from oracle import cpu_backend
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.manual_seed(0)
+    with cpu_backend.installed():
+        model = build_model(ConfigDict(model_cfg(64))).train()
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True,
+                              weight_decay=1e-4)
+        batch = collate_fn([make_scene(0, num_views=2, image_hw=(480, 640), n_voxels=20000)])
+        t0 = time.perf_counter()
+        out = model(clone_batch(batch))
+        t_fwd = time.perf_counter() - t0
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        t = time.perf_counter() - t0
+    return dict(value=1.0 / t, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 scene (20000 voxels, 2 views x 64 = 128 rays), ONE train step "
+                       "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels "
+                       f"(forward alone {t_fwd:.2f} s, step {t:.2f} s), no warm-up",
+                rays_per_s=128.0 / t, forward_s=t_fwd, step_s=t)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL
+
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.manual_seed(0)
+    model = build_model(ConfigDict(model_cfg(args.rays_per_view))).to(device).train()
+    step_model = model
+    if world > 1:
+        step_model = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)
+    lr = 0.0005 * (args.scenes_per_gpu * world) / 8
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
+    n_vox = int(batch["offset"][-1])
+
+    timer = None
+    if not args.no_kernel_timing:
+        timer = KernelTimer()
+        timer.install()
+
+    def step():
+        out = step_model(clone_batch(batch))
+        opt.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        opt.step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    if timer:
+        timer.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loss = float(out["loss"])
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    kernels = timer.summary() if timer else []
+    if timer:
+        timer.uninstall()
+    result = None
+    if rank == 0:
+        scenes = args.scenes_per_gpu * world * args.steps
+        rays_per_scene = args.views * args.rays_per_view
+        value = scenes / elapsed
+        result = {
+            "metric": "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 ScanNet-shaped",
+            "value": value, "unit": "scenes/s", "rays_per_s": value * rays_per_scene,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: PonderV2-indoor ScanNet pretrain, SpUNet-v1m1, "
+                                   f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
+                                   "train step fwd+bwd+SGD",
+                       "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
+                       "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
+            "final_loss": loss,
+        }
+        if kernels:
+            dom = kernels[0]
+            if dom["alg_flops_per_launch"] > 0:
+                result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma",
+                                      "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                                      "traffic": None, "avg_launch_us": dom["avg_us"],
+                                      "launches": dom["launches"]}
+            else:
+                result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm",
+                                      "achieved": dom["alg_gbs"], "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": dom["alg_gbs"] / HBM_PEAK_GBS,
+                                      "traffic": None, "avg_launch_us": dom["avg_us"],
+                                      "launches": dom["launches"]}
+            result["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v)
+                                  for k, v in r.items()} for r in kernels]
+            result["instrumented_ms_per_step"] = sum(r["total_ms"] for r in kernels) / args.steps
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,9 +1,12 @@
-"""CPU test doubles for the device kernels, built on oracle/ (tests only).
+"""CPU stand-ins for the device kernels, built on the oracle restatements (checker only).
 
 ``install(monkeypatch)`` swaps the entry points of ponderv2_amd.kernels for oracle-backed
 equivalents so that the host-side logic (spconv mirror, models, render head) can be exercised
-without a GPU.  The product never imports this file and has no CPU path of its own.
+without a GPU: by tests/ (pytest's monkeypatch) and by bench.py's cpu_baseline leg
+(``installed()`` context manager).  The product never imports this file and has no CPU path of
+its own.
 """
+import contextlib
 import numpy as np
 import torch
 
@@ -51,6 +54,31 @@ class _ScatterApply:
     @staticmethod
     def apply(src, index, out, mean):
         return oracle_scatter(src, index, dim=0, out=out, reduce="mean" if mean else "sum")
+
+
+class _Patcher:
+    """Minimal monkeypatch look-alike for use outside pytest."""
+
+    def __init__(self):
+        self.undo = []
+
+    def setattr(self, obj, name, value):
+        self.undo.append((obj, name, getattr(obj, name)))
+        setattr(obj, name, value)
+
+    def restore(self):
+        for obj, name, old in reversed(self.undo):
+            setattr(obj, name, old)
+
+
+@contextlib.contextmanager
+def installed():
+    p = _Patcher()
+    install(p)
+    try:
+        yield
+    finally:
+        p.restore()
 
 
 def install(monkeypatch):

@@ -3,13 +3,13 @@ what the reference's own files produced (tests/golden/*.npz, oracle/make_golden.
 import pytest
 import torch
 
-import cpu_doubles
+from oracle import cpu_backend
 import golden_cases as gc
 
 
 @pytest.fixture
 def cpu_kernels(monkeypatch):
-    cpu_doubles.install(monkeypatch)
+    cpu_backend.install(monkeypatch)
 
 
 def test_spunet_topology_matches_reference(cpu_kernels):
