@@ -41,15 +41,20 @@ def parse():
     ap.add_argument("--rays-per-view", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dense-dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"],
+                    help="autocast dtype of the dense UNet3D projection (MIOpen); the reference "
+                         "config trains with enable_amp=True.  float32 = the parity configuration")
+    ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     return ap.parse_args()
 
 
-def model_cfg(rays_per_view):
+def model_cfg(rays_per_view, dense_dtype="float32"):
     import golden_cases as gc  # the ScanNet model section, restated (reference tree absent here)
 
     backbone = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0,
                     channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
     cfg = gc.indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
+    cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
     return cfg
 
 
@@ -61,8 +66,8 @@ class KernelTimer:
         self.records = {}   # family -> list of (start, end, flops, bytes)
         self._orig = {}
 
-    def _add(self, fam, s, e, flops, nbytes):
-        self.records.setdefault(fam, []).append((s, e, flops, nbytes))
+    def _add(self, fam, s, e, flops, nbytes, shape=None):
+        self.records.setdefault(fam, []).append((s, e, flops, nbytes, shape))
 
     def install(self):
         import ponderv2_amd.kernels as K
@@ -79,8 +84,8 @@ class KernelTimer:
                 s.record()
                 out = orig(*a, **k)
                 e.record()
-                flops, nbytes = cost(*a, **k)
-                timer._add(fam, s, e, flops, nbytes)
+                c = cost(*a, **k)
+                timer._add(fam, s, e, c[0], c[1], c[2] if len(c) > 2 else None)
                 return out
 
             setattr(K, name, fn)
@@ -89,13 +94,15 @@ class KernelTimer:
             c_out, kk, c_in = w.shape
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
-                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + kk * c_in * c_out) + 8.0 * p)
+                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + kk * c_in * c_out) + 8.0 * p,
+                    (c_in, c_out, kk, p))
 
         def wgrad_cost(feats, gout, rb, c_out):
             c_in = feats.shape[1]
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
-                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + rb.K * c_in * c_out) + 8.0 * p)
+                    4.0 * (rb.n_in * c_in + rb.n_out * c_out + rb.K * c_in * c_out) + 8.0 * p,
+                    (c_in, c_out, rb.K, p))
 
         def tri_cost_factory(mult):
             def cost(*a, **k):
@@ -125,7 +132,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = []
         for fam, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             flops = sum(r[2] for r in recs)
             nbytes = sum(r[3] for r in recs)
             out.append(dict(kernel=fam, launches=len(recs), total_ms=ms,
@@ -135,6 +142,27 @@ class KernelTimer:
                             alg_flops_per_launch=flops / max(len(recs), 1),
                             alg_bytes_per_launch=nbytes / max(len(recs), 1)))
         return sorted(out, key=lambda r: -r["total_ms"])
+
+    def shape_table(self, steps):
+        """Per (kernel family, c_in, c_out, K, pairs): launches/step, us/launch, TFLOP/s."""
+        torch.cuda.synchronize()
+        rows = {}
+        for fam, recs in self.records.items():
+            for r in recs:
+                if r[4] is None:
+                    continue
+                key = (fam,) + tuple(r[4])
+                acc = rows.setdefault(key, [0, 0.0, 0.0])
+                acc[0] += 1
+                acc[1] += r[0].elapsed_time(r[1])
+                acc[2] += r[2]
+        lines = ["%-32s %5s %5s %4s %9s %7s %9s %8s %8s" % ("kernel", "c_in", "c_out", "K", "pairs",
+                 "n/step", "us/launch", "TFLOP/s", "ms/step")]
+        for key, (n, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            lines.append("%-32s %5d %5d %4d %9d %7.1f %9.1f %8.2f %8.3f" % (
+                key[0][:32], key[1], key[2], key[3], key[4], n / steps, 1e3 * ms / n,
+                fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, ms / steps))
+        return "\n".join(lines)
 
 
 def make_batch(rank, scenes, views, device):
@@ -196,7 +224,8 @@ def main():
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
     torch.manual_seed(0)
-    model = build_model(ConfigDict(model_cfg(args.rays_per_view))).to(device).train()
+    torch.backends.cudnn.benchmark = True  # let MIOpen search its solvers for the dense convs
+    model = build_model(ConfigDict(model_cfg(args.rays_per_view, args.dense_dtype))).to(device).train()
     step_model = model
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(
@@ -240,6 +269,10 @@ def main():
 
     kernels = timer.summary() if timer else []
     if timer:
+        if args.kernel_table and rank == 0:
+            os.makedirs(os.path.dirname(args.kernel_table) or ".", exist_ok=True)
+            with open(args.kernel_table, "w") as f:
+                f.write(timer.shape_table(args.steps) + "\n")
         timer.uninstall()
     result = None
     if rank == 0:
@@ -251,7 +284,11 @@ def main():
             "value": value, "unit": "scenes/s", "rays_per_s": value * rays_per_scene,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32" if args.dense_dtype == "float32" else
+                      f"f32 sparse conv + render head; {args.dense_dtype} autocast for the dense "
+                      "UNet3D convs (reference enable_amp=True)"),
+            "data": "synthetic",
             "config": {"workload": "configs[1]: PonderV2-indoor ScanNet pretrain, SpUNet-v1m1, "
                                    f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
                                    "train step fwd+bwd+SGD",

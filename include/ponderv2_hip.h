@@ -98,25 +98,29 @@ int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_row
  *
  * weight      fp32 [c_out, K, c_in]  (spconv 2.x layout [Cout, kD, kH, kW, Cin], flattened)
  * kstart      int32 [K+1] device prefix of pairs per offset (from pv2_table_count)
- * tile_start  int32 [K+1] device prefix of ceil(count_k / PV2_PAIR_TILE)
+ * tile_start  int32 [K+1] device prefix of ceil(count_k / tile_pairs), where
+ *             tile_pairs = pv2_spconv_forward_tile(c_in, c_out): 128 for the LDS-staged kernel
+ *             (c_in % 32 == 0), PV2_PAIR_TILE for the generic one
  * n_tiles     tile_start[K] (host value)
  * `out` must be pre-initialised (zeros, or a bias/residual to accumulate onto).
  * ------------------------------------------------------------------------------------------ */
 #define PV2_PAIR_TILE 32
+int pv2_spconv_forward_tile(int c_in, int c_out);
 int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
                        int c_out, const int32_t* pair_in, const int32_t* pair_out,
-                       const int32_t* kstart, const int32_t* tile_start, int64_t n_tiles,
-                       float* out_feat, int64_t n_out, pv2_stream_t stream);
+                       const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
+                       int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream);
 
 /* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
- * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count tiles of
- * PV2_WGRAD_TILE pairs (prefix of ceil(count_k / PV2_WGRAD_TILE)). */
+ * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count chunks of
+ * tile_pairs = pv2_spconv_wgrad_tile(c_in, c_out, n_pairs, K) pairs (PV2_WGRAD_TILE or 2048). */
 #define PV2_WGRAD_TILE 512
+int pv2_spconv_wgrad_tile(int c_in, int c_out, int64_t n_pairs, int K);
 int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,
                                int64_t n_out, int c_out, int K, const int32_t* pair_in,
                                const int32_t* pair_out, const int32_t* kstart,
-                               const int32_t* tile_start, int64_t n_tiles, float* dweight,
-                               pv2_stream_t stream);
+                               const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                               float* dweight, pv2_stream_t stream);
 /* (grad wrt input is pv2_spconv_forward with pair_in/pair_out swapped and weight transposed to
  *  [c_in, K, c_out].) */
 

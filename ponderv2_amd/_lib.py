@@ -38,10 +38,14 @@ SIGNATURES = {
         c_int, [_P, c_int64, c_int, POINTER(c_int32), _P, _P, _P, c_int64, _P]),
     "pv2_table_count": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P]),
     "pv2_table_compact": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, _P]),
+    "pv2_spconv_forward_tile": (c_int, [c_int, c_int]),
     "pv2_spconv_forward": (
-        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P]),
+        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, c_int64,
+                _P]),
+    "pv2_spconv_wgrad_tile": (c_int, [c_int, c_int, c_int64, c_int]),
     "pv2_spconv_backward_weight": (
-        c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int64, _P, _P]),
+        c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,
+                _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

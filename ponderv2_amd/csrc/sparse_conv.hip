@@ -45,6 +45,12 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ row, int kk, i
   return v;
 }
 
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p, bool ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *reinterpret_cast<const float4*>(p);
+  return v;
+}
+
 // out[pair_out[p], n] += sum_c in[pair_in[p], c] * W[n, k, c]
 template <int NB, bool VEC>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
@@ -173,6 +179,229 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v2 kernels: workgroup-cooperative, LDS-staged and software-pipelined.
+// ------------------------------------------------------------------------------------------
+
+// Forward / grad-input, c_in % 32 == 0.  A workgroup (4 waves) owns 128 pairs of ONE offset k and
+// NT = 32*NB output channels.  The weight slab W[n0:n0+NT, k, kk0:kk0+32] is shared by the four
+// waves through a double-buffered LDS tile (rows padded by 16 B: conflict-free ds_read_b128);
+// every wave streams its own 32 gathered feature rows straight into registers (they are private
+// to the wave's MFMA A operand, so an LDS round trip would buy nothing).  The loads of K-slab
+// t+1 (global -> registers) are issued before the 16*NB MFMAs of slab t; the LDS write of the
+// prefetched weights follows the MFMAs; one barrier per slab.
+constexpr int kFwdTile = 128;
+constexpr int kKC = 32;
+constexpr int kWPad = kKC + 4;
+
+template <int NB>
+__global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
+    const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
+    const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
+    const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int n_groups,
+    float* __restrict__ Y) {
+  constexpr int NT = 32 * NB;
+  __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+  const int k = find_offset(tile_start, K, tile);
+  const int p0 = kstart[k] + (tile - tile_start[k]) * kFwdTile;
+  const int pend = kstart[k + 1];
+  const int i = lane & 31, h = lane >> 5;
+  const int p = p0 + wave * 32 + i;
+  const bool pv = p < pend;
+  const int row_in = pv ? pair_in[p] : 0;
+  const int row_out = pv ? pair_out[p] : -1;
+  const int n0 = grp * NT;
+  const float* xrow = X + (int64_t)row_in * c_in + 4 * h;
+
+  // weight staging: NT rows x 8 float4 per slab; thread t owns float4 q = t + 256*u, i.e. row
+  // (t >> 3) + 32*u and 16-byte column t & 7
+  const int r0 = tid >> 3, c4 = tid & 7;
+  const float* wbase = W + ((int64_t)(n0 + r0) * K + k) * c_in + 4 * c4;
+  const int64_t wstride = (int64_t)32 * K * c_in;
+  const int wdst0 = r0 * kWPad + 4 * c4;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  float4 a_cur[4], a_nxt[4], w_nxt[NB];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow + 8 * s, pv);
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    *reinterpret_cast<float4*>(&sW[0][wdst0 + u * 32 * kWPad]) =
+        ld4(wbase + u * wstride, n0 + r0 + 32 * u < c_out);
+  }
+  __syncthreads();
+
+  const int nslab = c_in / kKC;
+  for (int t = 0; t < nslab; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < nslab;
+    if (more) {
+      const int kk = (t + 1) * kKC;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        a_nxt[s] = ld4(xrow + kk + 8 * s, pv);
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        w_nxt[u] = ld4(wbase + u * wstride + kk, n0 + r0 + 32 * u < c_out);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 b = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b.x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b.y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b.z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, b.w, acc[nb], 0, 0, 0);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        *reinterpret_cast<float4*>(&sW[buf ^ 1][wdst0 + u * 32 * kWPad]) = w_nxt[u];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
+    }
+    __syncthreads();
+  }
+
+  int orow[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) orow[r] = __shfl(row_out, (r & 3) + 8 * (r >> 2) + 4 * h);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (orow[r] >= 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 32 + i;
+        if (n < c_out) unsafeAtomicAdd(Y + (int64_t)orow[r] * c_out + n, acc[nb][r]);
+      }
+    }
+  }
+}
+
+// Weight gradient, c_in % 4 == 0 and c_out % 4 == 0.  A workgroup owns one chunk of `tile_pairs`
+// pairs of ONE offset k and a (64*WN) x (64*WC) block of dW[:, k, :].  Per step 32 pairs are
+// staged: their dY rows and X rows (only the block's column ranges) go global -> registers ->
+// LDS (double buffered, next step's global loads in flight during the MFMAs).  Waves form a
+// WN x WC x WK grid; each owns a 64x64 sub-block (2x2 MFMA accumulators) and, when WK > 1, every
+// WK-th pair couple of the step (split-K over waves, merged by the final atomics).
+constexpr int kStep = 32;
+constexpr int kMaxWgradTile = 2048;
+
+template <int WN, int WC, int WK>
+__global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
+    const float* __restrict__ X, int c_in, const float* __restrict__ dY, int c_out, int K,
+    const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
+    const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int tile_pairs,
+    int n_ntile, int n_ctile, float* __restrict__ dW) {
+  static_assert(WN * WC * WK == 4, "4 waves");
+  constexpr int TN = 64 * WN, TC = 64 * WC;
+  constexpr int UA = TN / 32, UB = TC / 32;  // float4 staged per thread per step
+  __shared__ __attribute__((aligned(16))) float sA[2][kStep * TN];
+  __shared__ __attribute__((aligned(16))) float sB[2][kStep * TC];
+  __shared__ int s_in[kMaxWgradTile];
+  __shared__ int s_out[kMaxWgradTile];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int per_tile = n_ntile * n_ctile;
+  const int tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
+  const int n0 = (sub / n_ctile) * TN, c0 = (sub % n_ctile) * TC;
+  const int k = find_offset(tile_start, K, tile);
+  const int p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
+  const int cnt = min(kstart[k + 1] - p0, tile_pairs);
+  for (int t = tid; t < tile_pairs; t += 256) {
+    s_in[t] = t < cnt ? pair_in[p0 + t] : -1;
+    s_out[t] = t < cnt ? pair_out[p0 + t] : -1;
+  }
+  __syncthreads();
+
+  const int wk = wave % WK, wc = (wave / WK) % WC, wn = wave / (WK * WC);
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[UA], rb[UB];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q / (TN / 4), col = (q % (TN / 4)) * 4;
+      const int o = s_out[s * kStep + row];
+      ra[u] = ld4(dY + (int64_t)max(o, 0) * c_out + n0 + col, o >= 0 && n0 + col < c_out);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q / (TC / 4), col = (q % (TC / 4)) * 4;
+      const int r_in = s_in[s * kStep + row];
+      rb[u] = ld4(X + (int64_t)max(r_in, 0) * c_in + c0 + col, r_in >= 0 && c0 + col < c_in);
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<float4*>(&sA[buf][(q / (TN / 4)) * TN + (q % (TN / 4)) * 4]) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<float4*>(&sB[buf][(q / (TC / 4)) * TC + (q % (TC / 4)) * 4]) = rb[u];
+    }
+  };
+
+  const int nsteps = (cnt + kStep - 1) / kStep;
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = (s + 1) < nsteps;
+    if (more) load_step(s + 1);
+    const float* A = &sA[buf][wn * 64 + i];
+    const float* B = &sB[buf][wc * 64 + i];
+#pragma unroll
+    for (int kk = wk; kk < kStep / 2; kk += WK) {
+      const int pr = 2 * kk + h;
+      const float a0 = A[pr * TN], a1 = A[pr * TN + 32];
+      const float b0 = B[pr * TC], b1 = B[pr * TC + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < c_out) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int c = c0 + wc * 64 + b * 32 + i;
+          if (c < c_in) unsafeAtomicAdd(dW + ((int64_t)n * K + k) * c_in + c, acc[a][b][r]);
+        }
+      }
+    }
+}
+
 template <int NB>
 int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -194,45 +423,96 @@ int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const
   return pv2::check_launch("spconv_fwd");
 }
 
+template <int NB>
+int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
+                   const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
+                   float* Y, hipStream_t s) {
+  const int n_groups = (c_out + NB * 32 - 1) / (NB * 32);
+  const int64_t blocks = n_tiles * n_groups;
+  if (blocks > 0x7fffffffLL) {
+    pv2::set_error("pv2_spconv_forward: grid too large");
+    return PV2_E_BADARG;
+  }
+  hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, X, c_in,
+                     W, K, c_out, pi, po, ks, ts, n_groups, Y);
+  return pv2::check_launch("spconv_fwd_lds");
+}
+
 }  // namespace
 
 extern "C" {
 
+int pv2_spconv_forward_tile(int c_in, int c_out) {
+  (void)c_out;
+  return (c_in % kKC) == 0 ? kFwdTile : PV2_PAIR_TILE;
+}
+
 int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
                        int c_out, const int32_t* pair_in, const int32_t* pair_out,
-                       const int32_t* kstart, const int32_t* tile_start, int64_t n_tiles,
-                       float* out_feat, int64_t n_out, pv2_stream_t stream) {
+                       const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
+                       int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream) {
   PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_forward: bad channel/offset count");
+  PV2_REQUIRE(tile_pairs == pv2_spconv_forward_tile(c_in, c_out),
+              "pv2_spconv_forward: tile_pairs must be pv2_spconv_forward_tile(c_in, c_out)");
   (void)n_in;
   (void)n_out;
   if (n_tiles == 0) return PV2_OK;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = (c_out + 31) / 32;
-  // Few tiles: split the output channels over more waves so the 1024 SIMDs have work.
+#define PV2_FWD_ARGS in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart, tile_start, n_tiles, out_feat, s
+  if (tile_pairs == kFwdTile) {
+    switch (nblk >= 4 ? 4 : nblk) {
+      case 1: return launch_fwd_lds<1>(PV2_FWD_ARGS);
+      case 2: return launch_fwd_lds<2>(PV2_FWD_ARGS);
+      case 3: return launch_fwd_lds<3>(PV2_FWD_ARGS);
+      default: return launch_fwd_lds<4>(PV2_FWD_ARGS);
+    }
+  }
+  // generic path (any c_in): one wave per 32-pair tile, operands straight from global memory
   int nb = nblk >= 4 ? 4 : nblk;
   if (nb == 4 && n_tiles * ((nblk + 3) / 4) < 2048) nb = 2;
   switch (nb) {
-    case 1: return launch_fwd<1>(in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart,
-                                 tile_start, n_tiles, out_feat, s);
-    case 2: return launch_fwd<2>(in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart,
-                                 tile_start, n_tiles, out_feat, s);
-    case 3: return launch_fwd<3>(in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart,
-                                 tile_start, n_tiles, out_feat, s);
-    default: return launch_fwd<4>(in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart,
-                                  tile_start, n_tiles, out_feat, s);
+    case 1: return launch_fwd<1>(PV2_FWD_ARGS);
+    case 2: return launch_fwd<2>(PV2_FWD_ARGS);
+    case 3: return launch_fwd<3>(PV2_FWD_ARGS);
+    default: return launch_fwd<4>(PV2_FWD_ARGS);
   }
+#undef PV2_FWD_ARGS
 }
 
 int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,
                                int64_t n_out, int c_out, int K, const int32_t* pair_in,
                                const int32_t* pair_out, const int32_t* kstart,
-                               const int32_t* tile_start, int64_t n_tiles, float* dweight,
-                               pv2_stream_t stream) {
+                               const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                               float* dweight, pv2_stream_t stream) {
   PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_backward_weight: bad sizes");
+  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE || tile_pairs == kMaxWgradTile,
+              "pv2_spconv_backward_weight: tile_pairs must be 512 or 2048");
   (void)n_in;
   (void)n_out;
   if (n_tiles == 0) return PV2_OK;
   hipStream_t s = (hipStream_t)stream;
+  if ((c_in % 4) == 0 && (c_out % 4) == 0) {
+    const bool big_n = c_out > 64, big_c = c_in > 64;
+    const int n_ntile = (c_out + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
+    const int n_ctile = (c_in + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
+    const int64_t blocks = n_tiles * n_ntile * n_ctile;
+    if (blocks > 0x7fffffffLL) {
+      pv2::set_error("pv2_spconv_backward_weight: grid too large");
+      return PV2_E_BADARG;
+    }
+#define PV2_LAUNCH_WGRAD_LDS(WN, WC, WK)                                                          \
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK>), dim3((unsigned)blocks), dim3(256), 0, \
+                     s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart, tile_start,     \
+                     tile_pairs, n_ntile, n_ctile, dweight)
+    if (big_n && big_c) PV2_LAUNCH_WGRAD_LDS(2, 2, 1);
+    else if (big_n) PV2_LAUNCH_WGRAD_LDS(2, 1, 2);
+    else if (big_c) PV2_LAUNCH_WGRAD_LDS(1, 2, 2);
+    else PV2_LAUNCH_WGRAD_LDS(1, 1, 4);
+#undef PV2_LAUNCH_WGRAD_LDS
+    return pv2::check_launch("spconv_wgrad_lds");
+  }
+  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE, "pv2_spconv_backward_weight: generic path needs 512");
   const int n_nblk = (c_out + 31) / 32;
   const int cblk = (c_in + 31) / 32;
   const int cb = cblk >= 4 ? 4 : (cblk >= 2 ? 2 : 1);
@@ -252,6 +532,15 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
   else PV2_LAUNCH_WGRAD(1);
 #undef PV2_LAUNCH_WGRAD
   return pv2::check_launch("spconv_wgrad");
+}
+
+int pv2_spconv_wgrad_tile(int c_in, int c_out, int64_t n_pairs, int K) {
+  if ((c_in % 4) != 0 || (c_out % 4) != 0) return PV2_WGRAD_TILE;
+  const int nt = (c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64);
+  const int ct = (c_in + (c_in > 64 ? 127 : 63)) / (c_in > 64 ? 128 : 64);
+  // long chunks amortise the final atomics; keep >= ~768 workgroups in flight
+  const int64_t big = (n_pairs / kMaxWgradTile + K) * nt * ct;
+  return big >= 768 ? kMaxWgradTile : PV2_WGRAD_TILE;
 }
 
 }  // extern "C"

@@ -154,16 +154,18 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
     if out is None:
         out = torch.zeros((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
-    tile_start, n_tiles = rb.tiles(PAIR_TILE)
-    _lib.check(_lib.lib().pv2_spconv_forward(
+    L = _lib.lib()
+    tile = L.pv2_spconv_forward_tile(c_in, c_out)
+    tile_start, n_tiles = rb.tiles(tile)
+    _lib.check(L.pv2_spconv_forward(
         _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
-        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), n_tiles, _ptr(out), rb.n_out,
+        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(out), rb.n_out,
         _stream(feats)), "pv2_spconv_forward")
     return out
 
 
 def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rulebook,
-                           c_out: int) -> torch.Tensor:
+                           c_out: int, tile: Optional[int] = None) -> torch.Tensor:
     """dW [c_out, K, c_in] for out = conv(feats, W)."""
     _require_device(feats, grad_out)
     feats = feats.contiguous()
@@ -171,10 +173,13 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     c_in = feats.shape[1]
     assert grad_out.shape == (rb.n_out, c_out) and feats.shape[0] == rb.n_in
     dw = torch.zeros((c_out, rb.K, c_in), dtype=torch.float32, device=feats.device)
-    tile_start, n_tiles = rb.tiles(WGRAD_TILE)
-    _lib.check(_lib.lib().pv2_spconv_backward_weight(
+    L = _lib.lib()
+    if tile is None:
+        tile = L.pv2_spconv_wgrad_tile(c_in, c_out, rb.n_pairs, rb.K)
+    tile_start, n_tiles = rb.tiles(tile)
+    _lib.check(L.pv2_spconv_backward_weight(
         _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, rb.K, _ptr(rb.pair_in),
-        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), n_tiles, _ptr(dw),
+        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(dw),
         _stream(feats)), "pv2_spconv_backward_weight")
     return dw
 

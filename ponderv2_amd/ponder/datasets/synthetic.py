@@ -159,6 +159,7 @@ def collate_fn(samples):
     return dict(coord=cat("coord", np.float32), grid_coord=cat("grid_coord", np.int64),
                 feat=torch.from_numpy(feat.astype(np.float32)), segment=cat("segment", np.int64),
                 offset=torch.tensor(np.cumsum(counts), dtype=torch.int64),
+                offset_host=[int(v) for v in np.cumsum(counts)],
                 condition=[s["condition"] for s in samples], rgb=stack("rgb"), depth=stack("depth"),
                 semantic=stack("semantic"), extrinsic=stack("extrinsic"), intrinsic=stack("intrinsic"),
                 depth_scale=torch.tensor([s["depth_scale"] for s in samples], dtype=torch.float32))

@@ -1,0 +1,163 @@
+"""Hook-driven trainer for the pre-training path (ponder/engines/train.py: TrainerBase :39-115,
+Trainer/"DefaultTrainer" :118-291; run_step :178-203).  One process per GPU; gradients are
+all-reduced by DDP over RCCL.  Tensor inputs are moved with non_blocking copies; AMP uses bf16/fp16
+autocast + GradScaler as the reference does when ``enable_amp`` is set."""
+import logging
+import os
+import sys
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ..datasets import SyntheticRGBDDataset, collate_fn
+from ..models import build_model
+from ..utils import comm
+from ..utils.optimizer import build_optimizer, build_scheduler
+from ..utils.registry import Registry
+from .defaults import create_ddp_model
+from .hooks import HOOKS, HookBase
+
+TRAINERS = Registry("trainers")
+DATASETS = Registry("datasets")
+DATASETS.register_module(module=SyntheticRGBDDataset, name="SyntheticRGBDDataset")
+
+
+def build_dataset(cfg):
+    if cfg["type"] not in DATASETS:
+        raise KeyError(
+            f"dataset {cfg['type']!r}: on-disk dataset readers are not part of this round's hot "
+            "path; run with --options data.train.type=SyntheticRGBDDataset")
+    return DATASETS.build(cfg)
+
+
+def get_logger(save_path, name="ponderv2_amd"):
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.INFO if comm.is_main_process() else logging.WARNING)
+    logger.propagate = False
+    if not logger.handlers:
+        fmt = logging.Formatter("[%(asctime)s %(levelname)s] %(message)s", "%Y-%m-%d %H:%M:%S")
+        h = logging.StreamHandler(stream=sys.stdout)
+        h.setFormatter(fmt)
+        logger.addHandler(h)
+        if comm.is_main_process() and save_path:
+            fh = logging.FileHandler(os.path.join(save_path, "train.log"))
+            fh.setFormatter(fmt)
+            logger.addHandler(fh)
+    return logger
+
+
+class TrainerBase:
+    def __init__(self):
+        self.hooks = []
+        self.epoch = self.start_epoch = 0
+        self.max_epoch = 0
+        self.max_iter = 0
+        self.comm_info = dict()
+        self.writer = None
+
+    def register_hooks(self, hooks):
+        for h in (HOOKS.build(cfg) if isinstance(cfg, dict) else cfg for cfg in hooks):
+            assert isinstance(h, HookBase)
+            h.trainer = self
+            self.hooks.append(h)
+
+    def _call(self, name):
+        for h in self.hooks:
+            getattr(h, name)()
+
+    def train(self):
+        self._call("before_train")
+        for self.epoch in range(self.start_epoch, self.max_epoch):
+            self.before_epoch()
+            self._call("before_epoch")
+            for it, batch in enumerate(self.train_loader):
+                self.comm_info.update(iter=it, input_dict=batch,
+                                      global_iter=self.epoch * len(self.train_loader) + it)
+                self._call("before_step")
+                self.run_step()
+                self._call("after_step")
+            self._call("after_epoch")
+        self._call("after_train")
+        comm.synchronize()
+        if self.writer is not None:
+            self.writer.close()
+
+    def before_epoch(self):
+        pass
+
+    def run_step(self):
+        raise NotImplementedError
+
+
+@TRAINERS.register_module("DefaultTrainer")
+class Trainer(TrainerBase):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.max_epoch = cfg.eval_epoch
+        self.best_metric_value = -float("inf")
+        self.device = (torch.device("cuda", torch.cuda.current_device())
+                       if torch.cuda.is_available() else torch.device("cpu"))
+        self.logger = get_logger(cfg.save_path)
+        self.logger.info(f"Save path: {cfg.save_path}")
+        self.model = self.build_model()
+        self.writer = (open(os.path.join(cfg.save_path, "scalars.jsonl"), "a")
+                       if comm.is_main_process() else None)
+        self.train_loader = self.build_train_loader()
+        self.max_iter = len(self.train_loader) * self.max_epoch
+        self.optimizer = build_optimizer(cfg.optimizer, self.model, cfg.get("param_dicts"))
+        sched = dict(cfg.scheduler)
+        sched["total_steps"] = max(self.max_iter, 1)
+        self.scheduler = build_scheduler(sched, self.optimizer)
+        self.amp_dtype = dict(float16=torch.float16, bfloat16=torch.bfloat16)[
+            cfg.get("amp_dtype", "bfloat16")]
+        self.scaler = (torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
+                       if cfg.enable_amp else None)
+        self.register_hooks(cfg.hooks)
+
+    def build_model(self):
+        model = build_model(self.cfg.model)
+        if self.cfg.sync_bn:
+            model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        self.logger.info(f"Num params: {n}")
+        return create_ddp_model(model.to(self.device), broadcast_buffers=False,
+                                find_unused_parameters=self.cfg.find_unused_parameters)
+
+    def build_train_loader(self):
+        data = build_dataset(self.cfg.data.train)
+        sampler = (torch.utils.data.distributed.DistributedSampler(data)
+                   if comm.get_world_size() > 1 else None)
+        workers = self.cfg.num_worker_per_gpu
+        return torch.utils.data.DataLoader(
+            data, batch_size=self.cfg.batch_size_per_gpu, shuffle=sampler is None,
+            num_workers=workers, sampler=sampler, collate_fn=collate_fn,
+            pin_memory=torch.cuda.is_available(), drop_last=True,
+            persistent_workers=workers > 0)
+
+    def before_epoch(self):
+        if comm.get_world_size() > 1:
+            self.train_loader.sampler.set_epoch(self.epoch)
+        self.model.train()
+
+    def run_step(self):
+        batch = self.comm_info["input_dict"]
+        batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
+                 for k, v in batch.items()}
+        with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=bool(self.cfg.enable_amp)):
+            out = self.model(batch)
+            loss = out["loss"]
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.scaler is not None and self.scaler.is_enabled():
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.optimizer)
+            before = self.scaler.get_scale()
+            self.scaler.update()
+            if before <= self.scaler.get_scale():  # the step was not skipped
+                self.scheduler.step()
+        else:
+            loss.backward()
+            self.optimizer.step()
+            self.scheduler.step()
+        self.comm_info["model_output_dict"] = out

@@ -20,13 +20,23 @@ class _ConditionedMLP(nn.Module):
         self.out_activation = out_activation
         self.points_factor = points_factor
 
-    def forward(self, points, point_feats):
+    def hidden(self, points, point_feats):
+        """Input of the LAST linear layer.  When the head has no output activation the last layer
+        commutes with alpha compositing: sum_k w_k lin(h_k) = lin.weight (sum_k w_k h_k) +
+        lin.bias sum_k w_k, so callers may composite ``hidden`` and apply ``last_linear`` per ray
+        instead of per sample (removes the (R*S, 512) semantic activations)."""
         x = self.fc_p(points) * self.points_factor
         last = self.num_layers - 2
-        for l in range(self.num_layers - 1):
-            x = getattr(self, f"lin{l}")(x + self.fc_c[l](point_feats))
-            if l < last:
-                x = self.activation(x)
+        for l in range(last):
+            x = self.activation(getattr(self, f"lin{l}")(x + self.fc_c[l](point_feats)))
+        return x + self.fc_c[last](point_feats)
+
+    @property
+    def last_linear(self):
+        return getattr(self, f"lin{self.num_layers - 2}")
+
+    def forward(self, points, point_feats):
+        x = self.last_linear(self.hidden(points, point_feats))
         return x if self.out_activation is None else self.out_activation(x)
 
 

@@ -58,7 +58,7 @@ def normalize_3d_coordinate(p, padding=0.1):
 class SDFField(nn.Module):
     def __init__(self, sdf_decoder, beta_init, use_gradient=True, volume_type="default",
                  padding_mode="zeros", share_volume=True, rgb_decoder=None, semantic_decoder=None,
-                 norm_pts=False, norm_padding=0.1):
+                 norm_pts=False, norm_padding=0.1, hoist_semantic=True):
         super().__init__()
         if volume_type != "default":
             raise NotImplementedError(f"volume_type={volume_type!r}")
@@ -73,6 +73,9 @@ class SDFField(nn.Module):
         self.deviation_network = SingleVarianceNetwork(init_val=beta_init)
         self._cos_anneal_ratio = 1.0
         self.norm_pts, self.norm_padding = norm_pts, norm_padding
+        # composite the semantic head before its last (linear) layer - exact up to fp
+        # re-association; False reproduces the reference's per-sample evaluation order
+        self.hoist_semantic = hoist_semantic
 
     def set_cos_anneal_ratio(self, anneal):
         self._cos_anneal_ratio = anneal
@@ -133,7 +136,10 @@ class SDFField(nn.Module):
         if self.rgb_decoder is not None:
             outputs["rgb"] = self.rgb_decoder(points, torch.cat(cond + [directions], dim=-1))
         if self.semantic_decoder is not None:
-            outputs["semantic"] = self.semantic_decoder(points, torch.cat(cond, dim=-1))
+            if self.hoist_semantic and self.semantic_decoder.out_activation is None:
+                outputs["semantic_hidden"] = self.semantic_decoder.hidden(points, torch.cat(cond, dim=-1))
+            else:
+                outputs["semantic"] = self.semantic_decoder(points, torch.cat(cond, dim=-1))
         outputs.update(density=self.laplace_density(sdf), sdf=sdf, gradients=gradients,
                        normal=F.normalize(gradients, dim=-1))
         if return_alphas:

@@ -37,6 +37,10 @@ class SurfaceModel(nn.Module):
         if "semantic" in field_outputs:
             outputs["semantic"] = self.semantic_renderer(semantic=field_outputs["semantic"],
                                                          weights=weights)
+        elif "semantic_hidden" in field_outputs:  # composite first, last linear layer per ray
+            lin = self.field.semantic_decoder.last_linear
+            comp = self.semantic_renderer(semantic=field_outputs["semantic_hidden"], weights=weights)
+            outputs["semantic"] = F.linear(comp, lin.weight) + lin.bias * torch.sum(weights, dim=-2)
         outputs.update(
             depth=self.depth_renderer(ray_samples=ray_samples, weights=weights),
             normal=self.normal_renderer(normals=field_outputs["normal"], weights=weights),

@@ -12,3 +12,14 @@ def offset2batch(offset: torch.Tensor) -> torch.Tensor:
 
 def batch2offset(batch: torch.Tensor) -> torch.Tensor:
     return torch.cumsum(batch.bincount(), dim=0).long()
+
+
+def offsets_host(data_dict):
+    """Python list of the cumulative point counts.  Collate functions that still hold the counts
+    on the host can pass ``offset_host``; otherwise this is ONE device->host read per batch, shared
+    by every consumer (the reference does one per use, e.g. models/utils.py:11-26)."""
+    oh = data_dict.get("offset_host")
+    if oh is None:
+        oh = [int(v) for v in data_dict["offset"].tolist()]
+        data_dict["offset_host"] = oh
+    return oh

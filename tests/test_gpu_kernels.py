@@ -133,6 +133,27 @@ def test_spconv_down_and_inverse_vs_oracle(device):
     assert (up.double().cpu() - ref_up).abs().max() < 1e-4 * ref_up.abs().max()
 
 
+@pytest.mark.parametrize("tile", [512, 2048])
+@pytest.mark.parametrize("c_in,c_out", [(64, 32), (128, 256), (192, 128), (32, 96)])
+def test_spconv_wgrad_chunk_sizes(device, tile, c_in, c_out):
+    """Both chunk lengths of the LDS-staged weight-gradient kernel, on enough pairs that chunks
+    are full, partly filled and (for some offsets) empty."""
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(1)
+    coords = random_voxels(8, batch=2, n_per_batch=9000, extent=(64, 60, 24))
+    n = len(coords)
+    feats, gout = torch.randn(n, c_in), torch.randn(n, c_out)
+    pin, pout, ks = orb.subm_rulebook(coords, 3)
+    w = torch.zeros(c_out, 27, c_in, dtype=torch.double, requires_grad=True)
+    _oracle_conv(feats.double(), w, pin, pout, ks, n).backward(gout.double())
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), 3)
+    dw = K.spconv_backward_weight(feats.to(device), gout.to(device), rb, c_out, tile=tile)
+    err = (dw.double().cpu() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    assert err < 1e-5, err
+
+
 # ------------------------------------------------------------------ scatter mean
 def test_scatter_mean_vs_oracle(device):
     from oracle.scatter import scatter as oscatter
