@@ -13,6 +13,8 @@
 //     along the reduction axis, so neither operand needs a transpose or an LDS round trip;
 //   * the 32x32 result block has its 32 columns (output channels) on lanes 0..31, so the
 //     scatter-add is 128-byte contiguous per output row.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -440,11 +442,20 @@ int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, c
 
 }  // namespace
 
+// Debug switch: PV2_SPCONV_GENERIC=1 routes everything to the generic (v1) kernels.
+static bool force_generic() {
+  static const bool v = [] {
+    const char* e = getenv("PV2_SPCONV_GENERIC");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
+
 extern "C" {
 
 int pv2_spconv_forward_tile(int c_in, int c_out) {
   (void)c_out;
-  return (c_in % kKC) == 0 ? kFwdTile : PV2_PAIR_TILE;
+  return ((c_in % kKC) == 0 && !force_generic()) ? kFwdTile : PV2_PAIR_TILE;
 }
 
 int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
@@ -492,7 +503,7 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
   (void)n_out;
   if (n_tiles == 0) return PV2_OK;
   hipStream_t s = (hipStream_t)stream;
-  if ((c_in % 4) == 0 && (c_out % 4) == 0) {
+  if ((c_in % 4) == 0 && (c_out % 4) == 0 && !force_generic()) {
     const bool big_n = c_out > 64, big_c = c_in > 64;
     const int n_ntile = (c_out + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
     const int n_ctile = (c_in + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
@@ -535,7 +546,7 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
 }
 
 int pv2_spconv_wgrad_tile(int c_in, int c_out, int64_t n_pairs, int K) {
-  if ((c_in % 4) != 0 || (c_out % 4) != 0) return PV2_WGRAD_TILE;
+  if ((c_in % 4) != 0 || (c_out % 4) != 0 || force_generic()) return PV2_WGRAD_TILE;
   const int nt = (c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64);
   const int ct = (c_in + (c_in > 64 ? 127 : 63)) / (c_in > 64 ? 128 : 64);
   // long chunks amortise the final atomics; keep >= ~768 workgroups in flight

@@ -49,13 +49,16 @@ class Rulebook:
         return int(self.kstart_host[-1])
 
     def tiles(self, tile: int):
-        """(device prefix int32[K+1], total) of ceil(count_k / tile)."""
+        """(device prefix int32[K+1], total) of ceil(count_k / tile).  The prefix is computed ON
+        THE DEVICE from ``kstart`` (no host->device copy whose source could be freed early); the
+        total comes from the host copy of ``kstart``."""
         if tile not in self._tiles:
-            counts = np.diff(self.kstart_host)
-            pre = np.zeros(self.K + 1, dtype=np.int64)
-            np.cumsum((counts + tile - 1) // tile, out=pre[1:])
-            dev = torch.from_numpy(pre.astype(np.int32)).to(self.kstart.device, non_blocking=True)
-            self._tiles[tile] = (dev, int(pre[-1]))
+            counts = self.kstart[1:] - self.kstart[:-1]
+            per_k = torch.div(counts + (tile - 1), tile, rounding_mode="floor")
+            dev = torch.zeros(self.K + 1, dtype=torch.int32, device=self.kstart.device)
+            dev[1:] = torch.cumsum(per_k, 0).to(torch.int32)
+            total = int(((np.diff(self.kstart_host) + tile - 1) // tile).sum())
+            self._tiles[tile] = (dev, total)
         return self._tiles[tile]
 
     def transposed(self) -> "Rulebook":
