@@ -24,6 +24,10 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# MIOpen's find results for the dense UNet3D convs ship in-tree (miopen_cache/): without them the
+# first step spends ~95 s benchmarking solvers on every fresh box.
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_cache", "db"))
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(ROOT, "miopen_cache", "cache"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

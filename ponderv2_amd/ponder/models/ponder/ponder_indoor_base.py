@@ -45,7 +45,7 @@ class PonderIndoor(nn.Module):
                  context_channels=256, pool_type="mean", render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True,
-                 proj_autocast=None):
+                 proj_autocast=None, batched_render=True):
         super().__init__()
         self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
         self.grid_size, self.pool_type = grid_size, pool_type
@@ -55,6 +55,7 @@ class PonderIndoor(nn.Module):
         # dtype name ("bfloat16"/"float16") to run ONLY the dense projection U-Net under autocast,
         # as the reference does for the whole model with enable_amp=True; None = fp32 (parity mode)
         self.proj_autocast = proj_autocast
+        self.batched_render = batched_render
         h = 0.5 + padding / 2
         self.bounds = [[-h, -h, -h], [h, h, h]]
         if mask is not None:
@@ -343,8 +344,15 @@ class PonderIndoor(nn.Module):
 
     # ------------------------------------------------------------------ rendering + losses
     def render_func(self, ray_dict, volume_feature):
+        B, R = ray_dict["ray_o"].shape[:2]
+        if self.training and self.batched_render:
+            # all scenes in one pass: rays are scene-major with equal counts, the field samples the
+            # batched volume with a single launch per call (the reference loops over scenes)
+            bundle = RayBundle(origins=ray_dict["ray_o"].reshape(B * R, 3),
+                               directions=ray_dict["ray_d"].reshape(B * R, 3), num_scenes=B)
+            return self.renderer(bundle, volume_feature)
         outs = []
-        for i in range(ray_dict["ray_o"].shape[0]):
+        for i in range(B):
             vols = [v[i] for v in volume_feature]
             o, d = ray_dict["ray_o"][i], ray_dict["ray_d"][i]
             if self.training:

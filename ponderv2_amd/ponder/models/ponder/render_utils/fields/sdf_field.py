@@ -93,12 +93,19 @@ class SDFField(nn.Module):
     def feature_sampling(self, pts_norm, volume_feature):
         """pts_norm (R,S,3) in [0,1]; volume_feature list of (C,Z,Y,X) -> (R,S,L*C) with the first
         halves of every level's channels first."""
-        grid = (pts_norm * 2 - 1)[None, None]  # (1,1,R,S,3)
         feats = []
         for vol in volume_feature:
-            out = SmoothSampler.apply(vol.unsqueeze(0).to(pts_norm.dtype), grid, self.padding_mode,
-                                      True, False)  # (1,C,1,R,S)
-            feats.append(out.squeeze(0).squeeze(1).permute(1, 2, 0))
+            if vol.dim() == 5:  # (B,C,Z,Y,X): rays are scene-major, R/B rays per scene
+                B = vol.shape[0]
+                grid = (pts_norm * 2 - 1).reshape(B, 1, pts_norm.shape[0] // B, *pts_norm.shape[1:])
+                out = SmoothSampler.apply(vol.to(pts_norm.dtype), grid, self.padding_mode, True,
+                                          False)  # (B,C,1,R/B,S)
+                feats.append(out.squeeze(2).permute(0, 2, 3, 1).reshape(*pts_norm.shape[:2], -1))
+            else:
+                grid = (pts_norm * 2 - 1)[None, None]  # (1,1,R,S,3)
+                out = SmoothSampler.apply(vol.unsqueeze(0).to(pts_norm.dtype), grid,
+                                          self.padding_mode, True, False)  # (1,C,1,R,S)
+                feats.append(out.squeeze(0).squeeze(1).permute(1, 2, 0))
         if len(feats) == 1:
             return feats[0]  # cat([f[:h], f[h:]]) of a single level is the identity
         ret = torch.stack(feats, dim=-2)

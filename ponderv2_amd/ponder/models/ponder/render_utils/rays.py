@@ -28,7 +28,8 @@ def alphas_to_weights(alphas):
 
 class RaySamples:
     def __init__(self, frustums, deltas, spacing_starts=None, spacing_ends=None,
-                 spacing_to_euclidean_fn=None):
+                 spacing_to_euclidean_fn=None, num_scenes=1):
+        self.num_scenes = num_scenes  # rays are scene-major with equal counts per scene
         self.frustums = frustums
         self.deltas = deltas
         self.spacing_starts, self.spacing_ends = spacing_starts, spacing_ends
@@ -46,9 +47,12 @@ class RaySamples:
 
 
 class RayBundle:
-    def __init__(self, origins, directions, nears=None, fars=None):
+    def __init__(self, origins, directions, nears=None, fars=None, num_scenes=1):
         self.origins, self.directions = origins, directions  # (R,3)
         self.nears, self.fars = nears, fars                  # (R,1)
+        # >1: the bundle holds the rays of several scenes (scene-major, equal counts); the field
+        # then samples a batched (B,C,Z,Y,X) volume in ONE launch instead of looping over scenes
+        self.num_scenes = num_scenes
 
     def get_ray_samples(self, bin_starts, bin_ends, spacing_starts, spacing_ends,
                         spacing_to_euclidean_fn):
@@ -56,7 +60,8 @@ class RayBundle:
         shape = [*deltas.shape[:-1], -1]
         frustums = Frustums(self.origins[..., None, :].expand(shape),
                             self.directions[..., None, :].expand(shape), bin_starts, bin_ends)
-        return RaySamples(frustums, deltas, spacing_starts, spacing_ends, spacing_to_euclidean_fn)
+        return RaySamples(frustums, deltas, spacing_starts, spacing_ends, spacing_to_euclidean_fn,
+                          num_scenes=self.num_scenes)
 
     def merge_ray_samples(self, samples_a, samples_b):
         """Union of two sample sets sorted by spacing start; returns (samples, sorted_index) where

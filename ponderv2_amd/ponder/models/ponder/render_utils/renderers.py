@@ -23,7 +23,13 @@ class DepthRenderer(nn.Module):
     def forward(self, ray_samples, weights):
         steps = ray_samples.frustums.starts
         depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
-        return torch.clip(depth, steps.min(), steps.max())
+        B = getattr(ray_samples, "num_scenes", 1)
+        if B == 1:
+            return torch.clip(depth, steps.min(), steps.max())
+        per_scene = steps.reshape(B, -1)  # the clip range is per rendered scene (reference :50)
+        lo = per_scene.amin(1).repeat_interleave(depth.shape[0] // B).reshape(-1, 1)
+        hi = per_scene.amax(1).repeat_interleave(depth.shape[0] // B).reshape(-1, 1)
+        return torch.maximum(torch.minimum(depth, hi), lo)
 
 
 class NormalRenderer(nn.Module):

@@ -1,0 +1,84 @@
+"""Worker functions for the world_size-2 gloo tests (run in spawned processes, CPU only)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def tiny_model_cfg():
+    import golden_cases as gc
+
+    return gc.indoor_model_cfg(dict(gc.SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
+                               grid_shape=(32, 32, 8), ray_nsample=6)
+
+
+def tiny_scene(seed):
+    from ponderv2_amd.ponder.datasets import make_scene
+
+    return make_scene(seed, n_raw=5000, num_views=2, image_hw=(24, 32))
+
+
+def grad_sync_worker(rank, world, port, out_dir):
+    """DDP gradient == mean over ranks of the local gradients; scenes are sharded by rank."""
+    from oracle import cpu_backend
+    from oracle.detweights import fill_deterministic
+    from ponderv2_amd.ponder.datasets import collate_fn
+    from ponderv2_amd.ponder.engines.defaults import create_ddp_model
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils import comm
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    with cpu_backend.installed():
+        model = build_model(ConfigDict(tiny_model_cfg()))
+        fill_deterministic(model)
+        model.train()
+        ddp = create_ddp_model(model, broadcast_buffers=False, find_unused_parameters=True)
+        assert comm.get_world_size() == world and comm.get_rank() == rank
+        batch = collate_fn([tiny_scene(50 + rank)])  # each rank renders its own scene
+
+        def run(sync):
+            torch.manual_seed(7)
+            ddp.zero_grad(set_to_none=True)
+            ctx = torch.enable_grad() if sync else ddp.no_sync()
+            with ctx:
+                out = ddp({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+                out["loss"].backward()
+            return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, out
+
+        g_ddp, out = run(sync=True)
+        # BatchNorm running stats advanced by the first pass do not enter train-mode gradients
+        g_loc, _ = run(sync=False)
+        worst = 0.0
+        for n in g_ddp:
+            avg = g_loc[n].clone()
+            dist.all_reduce(avg)
+            avg /= world
+            worst = max(worst, (avg - g_ddp[n]).abs().max().item() / (avg.abs().max().item() + 1e-12))
+        torch.save(dict(rank=rank, worst=worst, loss=float(out["loss"]), n_grads=len(g_ddp)),
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def trainer_main(cfg):
+    """main_func for engines.launch(): two optimisation steps of the hook-driven Trainer."""
+    from oracle import cpu_backend
+    from ponderv2_amd.ponder.engines import default_setup
+    from ponderv2_amd.ponder.engines.train import TRAINERS
+
+    torch.set_num_threads(2)
+    with cpu_backend.installed():
+        cfg = default_setup(cfg)
+        trainer = TRAINERS.build(dict(type=cfg.train.type, cfg=cfg))
+        trainer.train()
+        if trainer.writer is None:
+            return
+    return

@@ -58,16 +58,25 @@ def rel_err(a, b):
 
 
 class ReplayRand:
-    """Stands in for torch.rand inside the samplers: returns the reference's recorded draws."""
+    """Stands in for torch.rand inside the samplers: returns the reference's recorded draws.  The
+    reference renders scene by scene (draw shapes (R,97),(R,37) per scene); a batched renderer asks
+    once for (B*R,97) then (B*R,37): recorded draws with the same trailing size are concatenated
+    in recording order, so both call patterns see exactly the reference's numbers."""
 
     def __init__(self, draws, device):
-        self.draws, self.device, self.i = list(draws), device, 0
+        self.queues, self.device = {}, device
+        for d in draws:
+            d = torch.as_tensor(d)
+            self.queues.setdefault(d.shape[-1], []).append(d)
 
     def __call__(self, shape, dtype=None, device=None):
-        t = torch.as_tensor(self.draws[self.i])
-        self.i += 1
-        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
-        return t.to(self.device)
+        rows, width = shape
+        q, got = self.queues[width], []
+        while sum(t.shape[0] for t in got) < rows:
+            got.append(q.pop(0))
+        out = torch.cat(got, 0)
+        assert tuple(out.shape) == tuple(shape), (out.shape, shape)
+        return out.to(self.device)
 
 
 def run_spunet(device, dtype):

@@ -22,7 +22,8 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     t0 = time.time()
-    model = build_model(ConfigDict(bench.model_cfg(256))).to(dev).train()
+    torch.backends.cudnn.benchmark = True
+    model = build_model(ConfigDict(bench.model_cfg(256, os.environ.get("DENSE_DTYPE", "bfloat16")))).to(dev).train()
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True)
     batch = bench.make_batch(0, 2, 2, dev)
     print("setup %.1fs" % (time.time() - t0), flush=True)
@@ -39,10 +40,8 @@ def main():
         mark("backbone_fwd")
         ray_dict, d = model.prepare_ray(d)
         mark("prepare_ray")
-        d = model.grid_sample(d)
-        dense = model.to_dense(d)
-        mark("to_dense")
-        vol = model.proj_net(dense).contiguous(memory_format=torch.channels_last_3d)
+        mark("to_dense(skipped)")
+        vol = model.prepare_volume(d)[0]
         mark("proj_net_fwd")
         ro = model.render_func(ray_dict, [vol])
         loss, _ = model.render_loss(ro, ray_dict)
