@@ -125,6 +125,18 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
  *  [c_in, K, c_out].) */
 
 /* ------------------------------------------------------------------------------------------
+ * Dense fp32 MFMA GEMMs for the MLP heads of the render field (SDF / RGB / semantic decoders).
+ * Replaces the rocBLAS/hipBLASLt calls behind nn.Linear and its autograd at
+ * ponder/models/ponder/render_utils/decoders.py:21-35,57-76,91-109 (M = rays x samples rows).
+ *   pv2_gemm_nt:  y[m, n] = sum_k x[m, k] * w[n, k] (+ bias[n]);  k % 8 == 0; bias may be NULL.
+ *   pv2_gemm_tn:  c[i, j] += sum_m a[m, i] * b[m, j];  k1 % 4 == 0, k2 % 4 == 0; c ZERO-initialised.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_gemm_nt(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                float* y, pv2_stream_t stream);
+int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float* c,
+                pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,
  * reduce="mean"|"sum", out=...) at ponder/models/ponder/ponder_indoor_base.py:214 and
  * ponder_outdoor_base.py:204.

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pv2_spconv_backward_weight": (
         c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,
                 _P]),
+    "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
+    "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

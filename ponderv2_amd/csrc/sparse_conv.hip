@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 constexpr int kStep = 32;
 constexpr int kMaxWgradTile = 2048;
 
-template <int WN, int WC, int WK>
+// IDENT: no rulebook - pair p is (row p, row p) of a single offset; this is C = A^T B over `K`
+// (= total rows) for dense [M, c_out] / [M, c_in] operands (the MLP heads' weight gradients).
+template <int WN, int WC, int WK, bool IDENT>
 __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ dY, int c_out, int K,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
@@ -316,13 +318,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
   const int per_tile = n_ntile * n_ctile;
   const int tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
   const int n0 = (sub / n_ctile) * TN, c0 = (sub % n_ctile) * TC;
-  const int k = find_offset(tile_start, K, tile);
-  const int p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
-  const int cnt = min(kstart[k + 1] - p0, tile_pairs);
-  for (int t = tid; t < tile_pairs; t += 256) {
-    s_in[t] = t < cnt ? pair_in[p0 + t] : -1;
-    s_out[t] = t < cnt ? pair_out[p0 + t] : -1;
+  int k, p0, cnt;
+  if (IDENT) {  // here `K` carries the row count M and there is one "offset"
+    k = 0;
+    p0 = tile * tile_pairs;
+    cnt = min(K - p0, tile_pairs);
+    for (int t = tid; t < tile_pairs; t += 256) s_in[t] = s_out[t] = t < cnt ? p0 + t : -1;
+  } else {
+    k = find_offset(tile_start, K, tile);
+    p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
+    cnt = min(kstart[k + 1] - p0, tile_pairs);
+    for (int t = tid; t < tile_pairs; t += 256) {
+      s_in[t] = t < cnt ? pair_in[p0 + t] : -1;
+      s_out[t] = t < cnt ? pair_out[p0 + t] : -1;
+    }
   }
+  const int Kw = IDENT ? 1 : K;  // offsets in the weight tensor
   __syncthreads();
 
   const int wk = wave % WK, wc = (wave / WK) % WC, wn = wave / (WK * WC);
@@ -398,10 +409,97 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int c = c0 + wc * 64 + b * 32 + i;
-          if (c < c_in) unsafeAtomicAdd(dW + ((int64_t)n * K + k) * c_in + c, acc[a][b][r]);
+          if (c < c_in) unsafeAtomicAdd(dW + ((int64_t)n * Kw + k) * c_in + c, acc[a][b][r]);
         }
       }
     }
+}
+
+// Dense "tall" GEMM  Y[M, N] = X[M, K] . W[N, K]^T (+ bias): the MLP heads of the render field
+// (M = rays x samples ~ 1e5, K and N <= 512).  Same structure as spconv_fwd_lds_kernel without the
+// rulebook: 128 rows per workgroup, the weight slab shared through LDS, A fragments streamed from
+// global memory one slab ahead, plain (non-atomic) 128-byte row segments out.  K % 8 == 0.
+template <int NB>
+__global__ __launch_bounds__(256) void tall_gemm_nt_kernel(const float* __restrict__ X, int64_t M,
+                                                           int K, const float* __restrict__ W,
+                                                           int N, const float* __restrict__ bias,
+                                                           int n_groups, float* __restrict__ Y) {
+  constexpr int NT = 32 * NB;
+  __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t tile = blockIdx.x / n_groups;
+  const int grp = blockIdx.x % n_groups;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t row = tile * kFwdTile + wave * 32 + i;
+  const bool pv = row < M;
+  const int n0 = grp * NT;
+  const float* xrow = X + (pv ? row : 0) * K + 4 * h;
+  const int r0 = tid >> 3, c4 = tid & 7;
+  const float* wbase = W + (int64_t)(n0 + r0) * K + 4 * c4;
+  const int64_t wstride = (int64_t)32 * K;
+  const int wdst0 = r0 * kWPad + 4 * c4;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  float4 a_cur[4], a_nxt[4], w_nxt[NB];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow + 8 * s, pv && (8 * s + 4 * h) < K);
+#pragma unroll
+  for (int u = 0; u < NB; ++u)
+    *reinterpret_cast<float4*>(&sW[0][wdst0 + u * 32 * kWPad]) =
+        ld4(wbase + u * wstride, (n0 + r0 + 32 * u < N) && 4 * c4 < K);
+  __syncthreads();
+
+  const int nslab = (K + kKC - 1) / kKC;
+  for (int t = 0; t < nslab; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < nslab;
+    if (more) {
+      const int kk = (t + 1) * kKC;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a_nxt[s] = ld4(xrow + kk + 8 * s, pv && (kk + 8 * s + 4 * h) < K);
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        w_nxt[u] = ld4(wbase + u * wstride + kk, (n0 + r0 + 32 * u < N) && (kk + 4 * c4) < K);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 b = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b.x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b.y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b.z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, b.w, acc[nb], 0, 0, 0);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        *reinterpret_cast<float4*>(&sW[buf ^ 1][wdst0 + u * 32 * kWPad]) = w_nxt[u];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
+    }
+    __syncthreads();
+  }
+
+  const int64_t rbase = tile * kFwdTile + wave * 32 + 4 * h;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + nb * 32 + i;
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = rbase + (r & 3) + 8 * (r >> 2);
+        if (m < M) Y[m * N + n] = acc[nb][r] + bv;
+      }
+    }
+  }
 }
 
 template <int NB>
@@ -513,9 +611,9 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
       return PV2_E_BADARG;
     }
 #define PV2_LAUNCH_WGRAD_LDS(WN, WC, WK)                                                          \
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK>), dim3((unsigned)blocks), dim3(256), 0, \
-                     s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart, tile_start,     \
-                     tile_pairs, n_ntile, n_ctile, dweight)
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, false>), dim3((unsigned)blocks),        \
+                     dim3(256), 0, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart,   \
+                     tile_start, tile_pairs, n_ntile, n_ctile, dweight)
     if (big_n && big_c) PV2_LAUNCH_WGRAD_LDS(2, 2, 1);
     else if (big_n) PV2_LAUNCH_WGRAD_LDS(2, 1, 2);
     else if (big_c) PV2_LAUNCH_WGRAD_LDS(1, 2, 2);
@@ -543,6 +641,56 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
   else PV2_LAUNCH_WGRAD(1);
 #undef PV2_LAUNCH_WGRAD
   return pv2::check_launch("spconv_wgrad");
+}
+
+int pv2_gemm_nt(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                float* y, pv2_stream_t stream) {
+  PV2_REQUIRE(k >= 8 && (k % 8) == 0, "pv2_gemm_nt: k must be a positive multiple of 8");
+  PV2_REQUIRE(n >= 1 && m >= 0, "pv2_gemm_nt: bad sizes");
+  if (m == 0) return PV2_OK;
+  const int nblk = (n + 31) / 32;
+  const int nb = nblk >= 4 ? 4 : nblk;
+  const int n_groups = (nblk + nb - 1) / nb;
+  const int64_t blocks = ((m + kFwdTile - 1) / kFwdTile) * n_groups;
+  if (blocks > 0x7fffffffLL) {
+    pv2::set_error("pv2_gemm_nt: grid too large");
+    return PV2_E_BADARG;
+  }
+#define PV2_LAUNCH_TALL(NB)                                                                      \
+  hipLaunchKernelGGL((tall_gemm_nt_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0,            \
+                     (hipStream_t)stream, x, m, k, w, n, bias, n_groups, y)
+  switch (nb) {
+    case 1: PV2_LAUNCH_TALL(1); break;
+    case 2: PV2_LAUNCH_TALL(2); break;
+    case 3: PV2_LAUNCH_TALL(3); break;
+    default: PV2_LAUNCH_TALL(4); break;
+  }
+#undef PV2_LAUNCH_TALL
+  return pv2::check_launch("gemm_nt");
+}
+
+int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float* c,
+                pv2_stream_t stream) {
+  PV2_REQUIRE(k1 >= 4 && k2 >= 4 && (k1 % 4) == 0 && (k2 % 4) == 0,
+              "pv2_gemm_tn: k1 and k2 must be positive multiples of 4");
+  PV2_REQUIRE(m >= 0 && m < 0x7fffffffLL, "pv2_gemm_tn: bad row count");
+  if (m == 0) return PV2_OK;
+  const bool big_n = k1 > 64, big_c = k2 > 64;
+  const int n_ntile = (k1 + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
+  const int n_ctile = (k2 + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
+  const int tile_pairs = PV2_WGRAD_TILE;
+  const int64_t blocks = ((m + tile_pairs - 1) / tile_pairs) * n_ntile * n_ctile;
+  hipStream_t s = (hipStream_t)stream;
+#define PV2_LAUNCH_TN(WN, WC, WK)                                                                \
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, true>), dim3((unsigned)blocks),         \
+                     dim3(256), 0, s, b, k2, a, k1, (int)m, nullptr, nullptr, nullptr, nullptr,  \
+                     tile_pairs, n_ntile, n_ctile, c)
+  if (big_n && big_c) PV2_LAUNCH_TN(2, 2, 1);
+  else if (big_n) PV2_LAUNCH_TN(2, 1, 2);
+  else if (big_c) PV2_LAUNCH_TN(1, 2, 2);
+  else PV2_LAUNCH_TN(1, 1, 4);
+#undef PV2_LAUNCH_TN
+  return pv2::check_launch("gemm_tn");
 }
 
 int pv2_spconv_wgrad_tile(int c_in, int c_out, int64_t n_pairs, int K) {

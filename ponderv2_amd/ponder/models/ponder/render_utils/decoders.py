@@ -5,6 +5,13 @@ x = lin_l(x + fc_c[l](feat)), activation on all but the last layer."""
 import torch
 import torch.nn as nn
 
+from ponderv2_amd.linear import linear
+
+
+def _lin(layer, x):
+    """nn.Linear parameters, MFMA GEMM kernels (ponderv2_amd.linear) for big device batches."""
+    return linear(x, layer.weight, layer.bias)
+
 
 class _ConditionedMLP(nn.Module):
     def __init__(self, in_dim, out_dim, hidden_size, n_blocks, points_factor, activation,
@@ -25,18 +32,24 @@ class _ConditionedMLP(nn.Module):
         commutes with alpha compositing: sum_k w_k lin(h_k) = lin.weight (sum_k w_k h_k) +
         lin.bias sum_k w_k, so callers may composite ``hidden`` and apply ``last_linear`` per ray
         instead of per sample (removes the (R*S, 512) semantic activations)."""
-        x = self.fc_p(points) * self.points_factor
+        if self.points_factor == 0.0:
+            # the positional branch contributes exactly zero; keep fc_p in the graph with an exact
+            # zero gradient (the reference's fc_p(points) * 0.0 does the same, so weight decay
+            # still acts on it) without materialising an (M, hidden) tensor
+            x = (self.fc_p.weight.sum() + self.fc_p.bias.sum()) * 0.0
+        else:
+            x = _lin(self.fc_p, points) * self.points_factor
         last = self.num_layers - 2
         for l in range(last):
-            x = self.activation(getattr(self, f"lin{l}")(x + self.fc_c[l](point_feats)))
-        return x + self.fc_c[last](point_feats)
+            x = self.activation(_lin(getattr(self, f"lin{l}"), x + _lin(self.fc_c[l], point_feats)))
+        return x + _lin(self.fc_c[last], point_feats)
 
     @property
     def last_linear(self):
         return getattr(self, f"lin{self.num_layers - 2}")
 
     def forward(self, points, point_feats):
-        x = self.last_linear(self.hidden(points, point_feats))
+        x = _lin(self.last_linear, self.hidden(points, point_feats))
         return x if self.out_activation is None else self.out_activation(x)
 
 

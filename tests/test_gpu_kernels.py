@@ -154,6 +154,35 @@ def test_spconv_wgrad_chunk_sizes(device, tile, c_in, c_out):
     assert err < 1e-5, err
 
 
+# ------------------------------------------------------------------ MLP-head GEMMs
+@pytest.mark.parametrize("k,n", [(64, 128), (128, 128), (128, 65), (134, 128), (131, 128), (128, 3),
+                                 (3, 128), (128, 512)])
+def test_mfma_linear_matches_torch_to_second_order(device, k, n):
+    """ponderv2_amd.linear.linear == F.linear (fp64 reference) for value, first-order gradients and
+    a second-order term (gradient of a function of d(out)/d(x)), incl. the zero-padded odd sizes."""
+    import torch.nn.functional as F
+
+    from ponderv2_amd.linear import linear
+
+    torch.manual_seed(k * 1000 + n)
+    m = 4500
+    x, w, b = torch.randn(m, k), torch.randn(n, k) * 0.2, torch.randn(n)
+    probe = torch.randn(m, n)
+
+    def run(fn, x_, w_, b_, probe_):
+        x_, w_, b_ = (t.requires_grad_(True) for t in (x_, w_, b_))
+        y = torch.tanh(fn(x_, w_, b_))
+        (gx,) = torch.autograd.grad((y * probe_).sum(), x_, create_graph=True)
+        loss = (gx ** 2).mean() + (y ** 2).mean()
+        return (y.detach(), gx.detach()) + torch.autograd.grad(loss, [x_, w_, b_])
+
+    ref = run(F.linear, x.double(), w.double(), b.double(), probe.double())
+    got = run(linear, x.to(device), w.to(device), b.to(device), probe.to(device))
+    for name, a, r in zip(("y", "dx", "g_x", "g_w", "g_b"), got, ref):
+        err = (a.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
+        assert err < 2e-5, (name, err)
+
+
 # ------------------------------------------------------------------ scatter mean
 def test_scatter_mean_vs_oracle(device):
     from oracle.scatter import scatter as oscatter
