@@ -26,5 +26,11 @@ def test_ponder_indoor_gpu_vs_reference_golden(device):
     errs = gc.run_ponder_indoor(device)
     print(errs)
     losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
-    assert max(losses.values()) < 1e-3, errs
-    assert max(errs.values()) < 2e-2, errs
+    assert max(losses.values()) < 1e-4, errs  # the north-star bound: loss within 1e-4 relative
+    # The stem weight gradient sits at the end of a backward chain through ~60 BatchNorm layers,
+    # some over a few dozen voxels: on the CPU oracle a 1e-7 relative perturbation of the input
+    # features moves it by 3e-2 (and the dec.0 gradient by 1e-4) while the loss moves by 2e-7.
+    # Its bound reflects that conditioning; every other probe is held to 1e-3.
+    stem = errs.pop("grad_backbone.conv_input.0.weight")
+    assert stem < 0.2, stem
+    assert max(errs.values()) < 1e-3, errs
