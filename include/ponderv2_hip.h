@@ -137,6 +137,30 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
                 pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm1d over the active-voxel feature matrix x[n, c], fused with the optional
+ * residual add and ReLU that follow it in SpUNet's blocks; and a column sum.
+ * Replaces the ATen batch_norm / add / relu kernels behind BasicBlock.forward
+ * (ponder/models/sparse_unet/spconv_unet_v1m1_base.py:70-83) and the BatchNorm1d + ReLU entries of
+ * its SparseSequential stages (:108,120-121,143-145,178-180).
+ *   forward : y = [relu]( (x - mean) * invstd * weight + bias [+ residual] ), biased batch
+ *             variance; running_mean / running_var (may be NULL) updated with `momentum` and the
+ *             unbiased variance; mean_invstd[2c] = {mean, invstd} is kept for backward.
+ *   backward: g = dy * (y > 0) when y is given (fused ReLU), else dy;
+ *             dx = weight*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g (optional);
+ *             sums_ws[0..c) = sum g (= dbias), sums_ws[c..2c) = sum g*xhat (= dweight), double.
+ * sums_ws: device scratch of 2*c doubles.  weight / bias may be NULL (affine=False).
+ * ------------------------------------------------------------------------------------------ */
+int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const float* bias,
+                   const float* residual, int relu, float eps, float momentum,
+                   float* running_mean, float* running_var, double* sums_ws,
+                   float* mean_invstd, float* y, pv2_stream_t stream);
+int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
+                    const float* mean_invstd, const float* weight, int64_t n, int c,
+                    double* sums_ws, float* dx, float* dresidual_or_null, pv2_stream_t stream);
+/* out[c] = sum_r x[r, c] */
+int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,
  * reduce="mean"|"sum", out=...) at ponder/models/ponder/ponder_indoor_base.py:214 and
  * ponder_outdoor_base.py:204.

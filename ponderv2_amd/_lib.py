@@ -5,7 +5,8 @@ with instructions to build it (``python -c "import __graft_entry__ as g; g.build
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libponderv2_hip.so")
@@ -48,6 +49,10 @@ SIGNATURES = {
                 _P]),
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
+    "pv2_bn_forward": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P,
+                               _P, _P, _P]),
+    "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "pv2_col_sum": (c_int, [_P, c_int64, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

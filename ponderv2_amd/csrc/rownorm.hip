@@ -1,0 +1,220 @@
+// Row-matrix reductions for the sparse backbone on gfx950: training-mode BatchNorm1d over the
+// active-voxel feature matrix [N, C], fused with the ReLU and the residual add that follow it in
+// SpUNet's blocks, and a column sum (bias gradients of the MLP heads).
+//
+// Stands in for the ATen batch_norm / relu / add kernels behind
+// ponder/models/sparse_unet/spconv_unet_v1m1_base.py:70-83 (BasicBlock.forward) and :108,120-121
+// (norm_fn = BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU inside SparseSequential).  59 BN layers
+// per forward make this launch-latency territory: the stock path costs ~5 launches and >50 us per
+// layer per direction; here a layer is 3 short launches (statistics, finalise, apply).
+//
+// Layout trick: a 256-thread block views consecutive rows as one flat run of floats; thread t
+// always sees column t % C (C <= 256) so every load is fully coalesced and the per-column partial
+// sums stay in registers until one LDS pass and one double-precision atomic per column per block.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// sums[0..C) += sum_r f0(r,c);  sums[C..2C) += sum_r f1(r,c)
+// MODE 0: f0 = x, f1 = x*x                          (forward statistics)
+// MODE 1: g = dy * (y > 0 if y else 1);  f0 = g, f1 = g * xhat       (backward reductions)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void col_reduce2_kernel(
+    const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ mean_invstd, int64_t n, int c, int64_t rows_per_block,
+    double* __restrict__ sums) {
+  __shared__ float s0[kThreads];
+  __shared__ float s1[kThreads];
+  const int tid = threadIdx.x;
+  for (int cb = 0; cb < c; cb += kThreads) {  // column panels of <= 256
+    const int cw = min(c - cb, kThreads);
+    const int rpi = kThreads / cw;             // rows covered per iteration
+    const int rr = tid / cw, cc = tid % cw;
+    const bool active = rr < rpi;
+    float acc0 = 0.f, acc1 = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(n, r0 + rows_per_block);
+    float mu = 0.f, is = 1.f;
+    if (MODE == 1 && active) {
+      mu = mean_invstd[cb + cc];
+      is = mean_invstd[c + cb + cc];
+    }
+    if (active) {
+      for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        const int64_t idx = r * c + cb + cc;
+        if (MODE == 0) {
+          const float v = a[idx];
+          acc0 += v;
+          acc1 += v * v;
+        } else {
+          float g = a[idx];
+          if (y != nullptr && !(y[idx] > 0.f)) g = 0.f;
+          acc0 += g;
+          acc1 += g * (x[idx] - mu) * is;
+        }
+      }
+    }
+    s0[tid] = acc0;
+    s1[tid] = acc1;
+    __syncthreads();
+    if (tid < cw) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int q = 0; q < rpi; ++q) {
+        t0 += s0[q * cw + tid];
+        t1 += s1[q * cw + tid];
+      }
+      atomicAdd(&sums[cb + tid], (double)t0);
+      atomicAdd(&sums[c + cb + tid], (double)t1);
+    }
+    __syncthreads();
+  }
+}
+
+// one thread per channel: batch mean / inverse std (biased variance) and the running statistics
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t n, int c, float eps,
+                                   float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var,
+                                   float* __restrict__ mean_invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const double inv_n = 1.0 / (double)n;
+  const double mean = sums[ch] * inv_n;
+  double var = sums[c + ch] * inv_n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_invstd[ch] = (float)mean;
+  mean_invstd[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+  }
+}
+
+// y = [relu]( (x - mean) * invstd * w + b [+ residual] )
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(
+    const float* __restrict__ x, int64_t total, int c, const float* __restrict__ mean_invstd,
+    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ residual,
+    int relu, float* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ch = (int)(i % c);
+    float v = (x[i] - mean_invstd[ch]) * mean_invstd[c + ch];
+    v = v * (w ? w[ch] : 1.f) + (b ? b[ch] : 0.f);
+    if (residual) v += residual[i];
+    if (relu && !(v > 0.f)) v = 0.f;
+    y[i] = v;
+  }
+}
+
+// g = dy * mask;  dx = w * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g
+__global__ __launch_bounds__(kThreads) void bn_backward_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ mean_invstd, const float* __restrict__ w,
+    const double* __restrict__ sums, int64_t n, int c, float* __restrict__ dx,
+    float* __restrict__ dres) {
+  const int64_t total = n * c;
+  const double inv_n = 1.0 / (double)n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ch = (int)(i % c);
+    float g = dy[i];
+    if (y != nullptr && !(y[i] > 0.f)) g = 0.f;
+    const float is = mean_invstd[c + ch];
+    const float xh = (x[i] - mean_invstd[ch]) * is;
+    const float mg = (float)(sums[ch] * inv_n), mgx = (float)(sums[c + ch] * inv_n);
+    dx[i] = (w ? w[ch] : 1.f) * is * (g - mg - xh * mgx);
+    if (dres) dres[i] = g;
+  }
+}
+
+// out[c] += sum_r x[r, c]
+__global__ __launch_bounds__(kThreads) void col_sum_kernel(const float* __restrict__ x, int64_t n,
+                                                           int c, int64_t rows_per_block,
+                                                           float* __restrict__ out) {
+  __shared__ float s0[kThreads];
+  const int tid = threadIdx.x;
+  for (int cb = 0; cb < c; cb += kThreads) {
+    const int cw = min(c - cb, kThreads);
+    const int rpi = kThreads / cw;
+    const int rr = tid / cw, cc = tid % cw;
+    float acc = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(n, r0 + rows_per_block);
+    if (rr < rpi)
+      for (int64_t r = r0 + rr; r < r1; r += rpi) acc += x[r * c + cb + cc];
+    s0[tid] = acc;
+    __syncthreads();
+    if (tid < cw) {
+      float t = 0.f;
+      for (int q = 0; q < rpi; ++q) t += s0[q * cw + tid];
+      unsafeAtomicAdd(&out[cb + tid], t);
+    }
+    __syncthreads();
+  }
+}
+
+inline void reduce_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block) {
+  // aim for ~2 blocks per CU with at least ~64 row-iterations each
+  const int rpi = c >= kThreads ? 1 : kThreads / c;
+  int64_t want = (n + (int64_t)rpi * 32 - 1) / ((int64_t)rpi * 32);
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  *blocks = (int)want;
+  *rows_per_block = (n + want - 1) / want;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const float* bias,
+                   const float* residual, int relu, float eps, float momentum,
+                   float* running_mean, float* running_var, double* sums_ws,
+                   float* mean_invstd, float* y, pv2_stream_t stream) {
+  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_forward: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = pv2::hip_status(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * c, s))) return e;
+  int blocks;
+  int64_t rpb;
+  reduce_geometry(n, c, &blocks, &rpb);
+  hipLaunchKernelGGL((col_reduce2_kernel<0>), dim3(blocks), dim3(kThreads), 0, s, x, nullptr,
+                     nullptr, nullptr, n, c, rpb, sums_ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums_ws, n, c, eps,
+                     momentum, running_mean, running_var, mean_invstd);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(pv2::grid_for(n * c, kThreads)), dim3(kThreads), 0, s,
+                     x, n * c, c, mean_invstd, weight, bias, residual, relu, y);
+  return pv2::check_launch("bn_forward");
+}
+
+int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
+                    const float* mean_invstd, const float* weight, int64_t n, int c,
+                    double* sums_ws, float* dx, float* dresidual_or_null, pv2_stream_t stream) {
+  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_backward: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = pv2::hip_status(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * c, s))) return e;
+  int blocks;
+  int64_t rpb;
+  reduce_geometry(n, c, &blocks, &rpb);
+  hipLaunchKernelGGL((col_reduce2_kernel<1>), dim3(blocks), dim3(kThreads), 0, s, dy, x, y_or_null,
+                     mean_invstd, n, c, rpb, sums_ws);
+  hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(pv2::grid_for(n * c, kThreads)),
+                     dim3(kThreads), 0, s, dy, x, y_or_null, mean_invstd, weight, sums_ws, n, c, dx,
+                     dresidual_or_null);
+  return pv2::check_launch("bn_backward");
+}
+
+int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream) {
+  PV2_REQUIRE(c >= 1 && n >= 0, "pv2_col_sum: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = pv2::hip_status(hipMemsetAsync(out, 0, sizeof(float) * c, s))) return e;
+  if (n == 0) return PV2_OK;
+  int blocks;
+  int64_t rpb;
+  reduce_geometry(n, c, &blocks, &rpb);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(blocks), dim3(kThreads), 0, s, x, n, c, rpb, out);
+  return pv2::check_launch("col_sum");
+}
+
+}  // extern "C"

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .kernels import _ptr, _require_device, _stream
+from .rownorm import col_sum
 
 MIN_ROWS = 2048  # below this the GEMM is launch-bound either way: leave it to the BLAS
 
@@ -50,7 +51,7 @@ class TallGemmNT(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = reduce_gemm_tn(gy, x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0)
+            gb = col_sum(gy)
         return gx, gw, gb
 
 

@@ -11,6 +11,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from ponderv2_amd.rownorm import fused_bn
 from ponderv2_amd.spconv import pytorch as spconv
 from ..builder import MODELS
 from ..utils import offset2batch
@@ -47,11 +48,11 @@ class BasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         y = self.conv1(x)
-        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = y.replace_feature(fused_bn(self.bn1, y.features, relu=True))
         y = self.conv2(y)
-        y = y.replace_feature(self.bn2(y.features))
         shortcut = self.proj(x).features
-        return y.replace_feature(self.relu(y.features + shortcut))
+        # relu(bn2(conv2) + shortcut) in one pass over the feature matrix
+        return y.replace_feature(fused_bn(self.bn2, y.features, residual=shortcut, relu=True))
 
 
 @MODELS.register_module("SpUNet-v1m1")

@@ -1,0 +1,89 @@
+"""Fused training-mode BatchNorm1d (+ residual add + ReLU) on the active-voxel feature matrix and
+a column-sum, on the gfx950 kernels of csrc/rownorm.hip.
+
+``fused_bn(bn_module, x, residual=None, relu=False)`` uses the parameters and running buffers of a
+stock ``nn.BatchNorm1d`` (so state_dicts stay reference-compatible) and computes
+``[relu](bn(x) [+ residual])`` in three short launches; the backward is two.  Anything the kernels
+do not cover (eval mode, other dtypes, host tensors under the test doubles) takes the module path.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .kernels import _ptr, _require_device, _stream
+
+
+class _FusedBNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, relu, eps, momentum):
+        _require_device(x)
+        x = x.contiguous()
+        n, c = x.shape
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        mean_invstd = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().pv2_bn_forward(
+            _ptr(x), n, c, _ptr(weight), _ptr(bias), _ptr(residual), int(relu), float(eps),
+            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(sums), _ptr(mean_invstd),
+            _ptr(y), _stream(x)), "pv2_bn_forward")
+        ctx.save_for_backward(x, y if relu else None, mean_invstd, weight)
+        ctx.has_residual = residual is not None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean_invstd, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_residual else None
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().pv2_bn_backward(
+            _ptr(dy), _ptr(x), _ptr(y), _ptr(mean_invstd), _ptr(weight), n, c, _ptr(sums),
+            _ptr(dx), _ptr(dres), _stream(x)), "pv2_bn_backward")
+        s32 = sums.float()
+        dweight = s32[c:] if weight is not None else None
+        dbias = s32[:c] if ctx.has_bias else None
+        return dx, dweight, dbias, dres, None, None, None, None, None
+
+
+def fused_bn(bn, x, residual=None, relu=False):
+    """[relu](bn(x) [+ residual]) with ``bn`` an nn.BatchNorm1d."""
+    use_kernel = (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() == 2
+                  and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled())
+    if not use_kernel:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _FusedBNFunction.apply(x, bn.weight, bn.bias, residual, rm, rv, relu, bn.eps, bn.momentum)
+
+
+class _ColSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_device(x)
+        x = x.contiguous()
+        ctx.rows = x.shape[0]
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().pv2_col_sum(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream(x)),
+                   "pv2_col_sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.unsqueeze(0).expand(ctx.rows, -1)
+
+
+def col_sum(x):
+    """x[M, N].sum(0) for large fp32 device matrices."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096:
+        return _ColSum.apply(x)
+    return x.sum(0)

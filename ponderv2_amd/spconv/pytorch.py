@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
+from ..rownorm import fused_bn
 
 
 class SparseConvTensor:
@@ -160,12 +161,22 @@ class SparseSequential(SparseModule):
         return list(self._modules.values())[idx]
 
     def forward(self, x):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if isinstance(module, SparseModule):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.indices.shape[0] != 0:
-                    x = x.replace_feature(module(x.features))
+                    if isinstance(module, nn.BatchNorm1d):
+                        # BatchNorm1d (+ ReLU) on the feature matrix: one fused op (rownorm.hip)
+                        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                        x = x.replace_feature(fused_bn(module, x.features, relu=relu))
+                        i += int(relu)
+                    else:
+                        x = x.replace_feature(module(x.features))
             else:
                 x = module(x)
+            i += 1
         return x

@@ -183,6 +183,59 @@ def test_mfma_linear_matches_torch_to_second_order(device, k, n):
         assert err < 2e-5, (name, err)
 
 
+# ------------------------------------------------------------------ fused BatchNorm (+add+ReLU)
+@pytest.mark.parametrize("n,c", [(2, 16), (37, 48), (5000, 32), (46842, 96), (989, 256), (3001, 300)])
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True)])
+def test_fused_bn_matches_torch(device, n, c, relu, with_res):
+    import torch.nn as nn
+
+    from ponderv2_amd.rownorm import fused_bn
+
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 2 + 0.5
+    res = torch.randn(n, c) if with_res else None
+    gout = torch.randn(n, c)
+
+    def run(dev, dtype):
+        bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).to(dtype).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, c))
+        xi = x.to(dev).to(dtype).requires_grad_(True)
+        ri = res.to(dev).to(dtype).requires_grad_(True) if with_res else None
+        if dtype == torch.float32:
+            y = fused_bn(bn, xi, residual=ri, relu=relu)
+        else:  # reference composition
+            y = bn(xi)
+            if ri is not None:
+                y = y + ri
+            if relu:
+                y = torch.relu(y)
+        y.backward(gout.to(dev).to(dtype))
+        outs = [y.detach(), xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var]
+        if with_res:
+            outs.append(ri.grad)
+        return [o.double().cpu() for o in outs], int(bn.num_batches_tracked)
+
+    ref, _ = run(torch.device("cpu"), torch.float64)
+    got, nbt = run(device, torch.float32)
+    assert nbt == 1
+    for name, a, b in zip(("y", "dx", "dw", "db", "rmean", "rvar", "dres"), got, ref):
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        assert err < 2e-5, (name, err)
+
+
+def test_col_sum(device):
+    from ponderv2_amd.rownorm import col_sum
+
+    torch.manual_seed(0)
+    for m, n in ((135168, 128), (5000, 65), (70000, 3), (4096, 512)):
+        x = torch.randn(m, n)
+        got = col_sum(x.to(device)).double().cpu()
+        ref = x.double().sum(0)
+        assert (got - ref).abs().max() < 1e-4 * (ref.abs().max() + 1), (m, n)
+
+
 # ------------------------------------------------------------------ scatter mean
 def test_scatter_mean_vs_oracle(device):
     from oracle.scatter import scatter as oscatter
