@@ -221,7 +221,9 @@ def test_fused_bn_matches_torch(device, n, c, relu, with_res):
     got, nbt = run(device, torch.float32)
     assert nbt == 1
     for name, a, b in zip(("y", "dx", "dw", "db", "rmean", "rvar", "dres"), got, ref):
-        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        # relative to the tensor's scale, floored: with n = 2 the exact dx is ~eps-sized (BN of two
+        # rows cancels almost completely) and a purely relative test would measure rounding noise
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 0.05)
         assert err < 2e-5, (name, err)
 
 
