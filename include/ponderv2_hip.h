@@ -33,6 +33,8 @@ typedef void* pv2_stream_t; /* hipStream_t */
 #define PV2_E_WORKSPACE (-3)
 
 int pv2_abi_version(void);
+/* Debug only: kernel ablation flags used by tools/bench_spconv_kernels.py (0 = production). */
+int pv2_debug_set_ablate(int flags);
 const char* pv2_last_error(void);
 
 /* ------------------------------------------------------------------------------------------

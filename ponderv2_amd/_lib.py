@@ -30,6 +30,7 @@ _P = c_void_p  # every device pointer travels as void*
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
     "pv2_last_error": (c_char_p, []),
+    "pv2_debug_set_ablate": (c_int, [c_int]),
     "pv2_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
     "pv2_subm_neighbor_table": (c_int, [_P, c_int64, c_int, _P, _P, c_int64, _P, _P]),
     "pv2_downsample_workspace_bytes": (c_size_t, [c_int64]),

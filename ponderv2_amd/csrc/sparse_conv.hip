@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int n_groups,
-    float* __restrict__ Y) {
+    float* __restrict__ Y, int ablate) {
   constexpr int NT = 32 * NB;
   __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
   const int i = lane & 31, h = lane >> 5;
   const int p = p0 + wave * 32 + i;
   const bool pv = p < pend;
-  const int row_in = pv ? pair_in[p] : 0;
+  int row_in = pv ? pair_in[p] : 0;
   const int row_out = pv ? pair_out[p] : -1;
+  if (ablate & 2) row_in = pv ? (p & 0x1ff) : 0;  // [ablation] contiguous rows instead of a gather
   const int n0 = grp * NT;
   const float* xrow = X + (int64_t)row_in * c_in + 4 * h;
 
@@ -275,6 +276,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     __syncthreads();
   }
 
+  if (ablate & 1) {  // [ablation] no scatter: keep the accumulators alive, write nothing
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[nb][r]));
+    return;
+  }
   int orow[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) orow[r] = __shfl(row_out, (r & 3) + 8 * (r >> 2) + 4 * h);
@@ -523,6 +531,8 @@ int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const
   return pv2::check_launch("spconv_fwd");
 }
 
+int ablate_flags();
+
 template <int NB>
 int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                    const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -534,11 +544,17 @@ int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, c
     return PV2_E_BADARG;
   }
   hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, X, c_in,
-                     W, K, c_out, pi, po, ks, ts, n_groups, Y);
+                     W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags());
   return pv2::check_launch("spconv_fwd_lds");
 }
 
 }  // namespace
+
+// Debug: ablation flags for tools/bench_spconv_kernels.py (0 in production).
+static int g_ablate = 0;
+namespace {
+int ablate_flags() { return g_ablate; }
+}
 
 // Debug switch: PV2_SPCONV_GENERIC=1 routes everything to the generic (v1) kernels.
 static bool force_generic() {
@@ -550,6 +566,11 @@ static bool force_generic() {
 }
 
 extern "C" {
+
+int pv2_debug_set_ablate(int flags) {
+  g_ablate = flags;
+  return PV2_OK;
+}
 
 int pv2_spconv_forward_tile(int c_in, int c_out) {
   (void)c_out;
