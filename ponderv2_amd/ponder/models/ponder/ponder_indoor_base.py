@@ -45,7 +45,7 @@ class PonderIndoor(nn.Module):
                  context_channels=256, pool_type="mean", render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True,
-                 proj_autocast=None, batched_render=True):
+                 proj_autocast=None, batched_render=True, graph_render_head=True):
         super().__init__()
         self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
         self.grid_size, self.pool_type = grid_size, pool_type
@@ -56,6 +56,9 @@ class PonderIndoor(nn.Module):
         # as the reference does for the whole model with enable_amp=True; None = fp32 (parity mode)
         self.proj_autocast = proj_autocast
         self.batched_render = batched_render
+        # replay the (static-shape) render head + its backward as one hipGraph during training
+        self.graph_render_head = graph_render_head
+        self._graphed = None
         h = 0.5 + padding / 2
         self.bounds = [[-h, -h, -h], [h, h, h]]
         if mask is not None:
@@ -378,8 +381,19 @@ class PonderIndoor(nn.Module):
         data_dict = self.extract_feature(data_dict)
         ray_dict, data_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
-        render_out = self.render_func(ray_dict, volume_feature)
-        loss, loss_dict = self.render_loss(render_out, ray_dict)
+        res = None
+        if (self.training and self.graph_render_head and self.batched_render
+                and volume_feature[0].is_cuda and torch.is_grad_enabled()):
+            if self._graphed is None:
+                from .graphed_render import GraphedRenderHead
+
+                self._graphed = GraphedRenderHead(self)
+            if not self._graphed.failed:
+                res = self._graphed(volume_feature[0], ray_dict)
+        if res is None:
+            render_out = self.render_func(ray_dict, volume_feature)
+            res = self.render_loss(render_out, ray_dict)
+        loss, loss_dict = res
         out = dict(loss=loss, **loss_dict)
         if self.ppt_loss_weight > 0:
             out["ppt_loss"] = self.ppt_loss(data_dict)  # reported only (reference :699-704)

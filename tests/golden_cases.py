@@ -144,6 +144,7 @@ def run_ponder_indoor(device):
     cfg = indoor_model_cfg(dict(SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
                            grid_shape=(32, 32, 8), ray_nsample=20)
     cfg["template"] = ("a", "b")  # any template list: the stub embeddings do not depend on it
+    cfg["graph_render_head"] = False  # the recorded random draws are injected from the host
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()

@@ -34,3 +34,46 @@ def test_ponder_indoor_gpu_vs_reference_golden(device):
     stem = errs.pop("grad_backbone.conv_input.0.weight")
     assert stem < 0.2, stem
     assert max(errs.values()) < 1e-3, errs
+
+
+def test_graphed_render_head_equals_eager(device):
+    """hipGraph replay of the render head (forward + backward) == the eager path, with the samplers'
+    jitter switched off so both are deterministic; three steps to cover capture, replay, replay with
+    updated inputs."""
+    import copy
+
+    from oracle.detweights import fill_deterministic
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    cfg = gc.indoor_model_cfg(dict(gc.SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
+                              grid_shape=(32, 32, 8), ray_nsample=24)
+    cfg["renderer"] = copy.deepcopy(cfg["renderer"])
+    cfg["renderer"]["sampler"]["train_stratified"] = False
+    kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64))
+    batches = [collate_fn([make_scene(200 + 2 * i, **kw), make_scene(201 + 2 * i, **kw)])
+               for i in range(3)]
+    results = {}
+    for graphed in (False, True):
+        cfg["graph_render_head"] = graphed
+        model = build_model(ConfigDict(cfg))
+        fill_deterministic(model)
+        model = model.to(device).train()
+        rows = []
+        for i, b in enumerate(batches):
+            torch.manual_seed(100 + i)  # same pixel choice in both runs
+            b = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
+            model.zero_grad(set_to_none=True)
+            out = model(b)
+            out["loss"].backward()
+            rows.append((float(out["loss"]), float(out["eikonal_loss"]),
+                         model.renderer.field.sdf_decoder.lin0.weight.grad.clone(),
+                         model.proj_net.final_conv.weight.grad.clone()))
+        if graphed:
+            assert model._graphed is not None and not model._graphed.failed, "capture was refused"
+        results[graphed] = rows
+    for e, g in zip(results[False], results[True]):
+        assert abs(e[0] - g[0]) < 1e-5 * abs(e[0]) and abs(e[1] - g[1]) < 1e-4 * abs(e[1]) + 1e-9
+        for a, b in zip(e[2:], g[2:]):
+            assert (a - b).abs().max() < 2e-4 * a.abs().max()
