@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .builder import SAMPLERS
-from .rays import alphas_to_weights
+from .rays import alphas_to_weights, device_linspace
 
 
 class Sampler(nn.Module):
@@ -38,7 +38,7 @@ class SpacedSampler(Sampler):
         n = num_samples or self.num_samples
         rays = ray_bundle.origins.shape[0]
         dev = ray_bundle.origins.device
-        bins = torch.linspace(0.0, 1.0, n + 1).to(dev).expand(rays, -1)
+        bins = device_linspace(0.0, 1.0, n + 1, dev).expand(rays, -1)
         if self.train_stratified and self.training:
             t_rand = self.rand((rays, 1 if self.single_jitter else n + 1), dtype=bins.dtype,
                                device=dev)

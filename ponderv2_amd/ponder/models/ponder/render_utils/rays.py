@@ -8,6 +8,32 @@ Plain Python objects here (the reference makes them nn.Modules without parameter
 import torch
 
 
+_CONST_CACHE = {}
+
+
+def device_constant(values, device, dtype=torch.float32):
+    """A small constant tensor on `device`, uploaded once and then reused: host->device copies
+    inside the render head would both cost a launch every step and make the region impossible to
+    capture into a hipGraph."""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(list(values), dtype=dtype).to(device)
+        _CONST_CACHE[key] = t
+    return t
+
+
+def device_linspace(start, end, steps, device):
+    """torch.linspace evaluated on the host (bit-identical to the reference's CPU linspace,
+    ray_samplers.py:70-74) and cached on the device."""
+    key = ("linspace", float(start), float(end), int(steps), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(start, end, steps).to(device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 class Frustums:
     def __init__(self, origins, directions, starts, ends):
         self.origins, self.directions, self.starts, self.ends = origins, directions, starts, ends

@@ -4,6 +4,8 @@ semantic :66-75)."""
 import torch
 from torch import nn
 
+from .rays import device_constant
+
 
 class RGBRenderer(nn.Module):
     def __init__(self, background_color=(0.0, 0.0, 0.0)):
@@ -13,7 +15,7 @@ class RGBRenderer(nn.Module):
     def forward(self, rgb, weights):
         comp = torch.sum(weights * rgb, dim=-2)
         acc = torch.sum(weights, dim=-2)
-        comp = comp + comp.new_tensor(self.background_color) * (1.0 - acc)
+        comp = comp + device_constant(self.background_color, comp.device, comp.dtype) * (1.0 - acc)
         if not self.training:
             comp = comp.clamp(0.0, 1.0)
         return comp

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .builder import COLLIDERS
+from .rays import device_constant
 
 
 class SceneCollider(nn.Module):
@@ -30,8 +31,8 @@ class AABBBoxCollider(SceneCollider):
 
     def _intersect_with_aabb(self, rays_o, rays_d, aabb):
         inv = 1.0 / (rays_d + 1e-6)
-        lo = rays_o.new_tensor(list(aabb[:3]))
-        hi = rays_o.new_tensor(list(aabb[3:]))
+        lo = device_constant(aabb[:3], rays_o.device, rays_o.dtype)
+        hi = device_constant(aabb[3:], rays_o.device, rays_o.dtype)
         ta, tb = (lo - rays_o) * inv, (hi - rays_o) * inv
         nears = torch.minimum(ta, tb).max(dim=1).values
         fars = torch.maximum(ta, tb).min(dim=1).values
