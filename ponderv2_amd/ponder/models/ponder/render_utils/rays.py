@@ -45,10 +45,30 @@ class Frustums:
         return self.origins + self.directions * self.starts
 
 
+class _CumprodNoZero(torch.autograd.Function):
+    """torch.cumprod along dim 1 for inputs that are never zero (here 1 - alpha + 1e-7 >= 1e-7).
+    ATen's cumprod backward first asks the device whether the input contains zeros (a host sync,
+    which also makes the region impossible to capture into a hipGraph); for non-zero inputs it then
+    uses exactly this formula: dx_i = (sum_{j>=i} g_j y_j) / x_i."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.cumprod(x, dim=1)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        w = g * y
+        rev = torch.flip(torch.cumsum(torch.flip(w, dims=[1]), dim=1), dims=[1])
+        return rev / x
+
+
 def alphas_to_weights(alphas):
     """w_k = alpha_k * prod_{j<k} (1 - alpha_j + 1e-7); also returns the (S+1) transmittance."""
     ones = torch.ones((alphas.shape[0], 1, 1), device=alphas.device, dtype=alphas.dtype)
-    transmittance = torch.cumprod(torch.cat([ones, 1.0 - alphas + 1e-7], dim=1), dim=1)
+    transmittance = _CumprodNoZero.apply(torch.cat([ones, 1.0 - alphas + 1e-7], dim=1))
     return alphas * transmittance[:, :-1, :], transmittance
 
 
