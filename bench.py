@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--dense-dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"],
                     help="autocast dtype of the dense UNet3D projection (MIOpen); the reference "
                          "config trains with enable_amp=True.  float32 = the parity configuration")
+    ap.add_argument("--no-graph", action="store_true", help="eager render head (no hipGraph replay)")
+    ap.add_argument("--print-losses", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     return ap.parse_args()
 
@@ -230,7 +232,9 @@ def main():
 
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = True  # let MIOpen search its solvers for the dense convs
-    model = build_model(ConfigDict(model_cfg(args.rays_per_view, args.dense_dtype))).to(device).train()
+    cfg = model_cfg(args.rays_per_view, args.dense_dtype)
+    cfg["graph_render_head"] = not args.no_graph
+    model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(
@@ -245,6 +249,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         out["loss"].backward()
         opt.step()
+        if args.print_losses and rank == 0:
+            print("loss", {k: round(float(v.detach()), 5) for k, v in out.items()}, flush=True)
         return out
 
     def timed_pass(n_steps):

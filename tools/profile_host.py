@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""cProfile of the host side of training steps (where does the enqueue time go?)."""
+import cProfile, io, os, pstats, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from ponderv2_amd.ponder.models import build_model
+from ponderv2_amd.ponder.utils.config import ConfigDict
+
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True
+model = build_model(ConfigDict(bench.model_cfg(256, "bfloat16"))).to(dev).train()
+opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4)
+batch = bench.make_batch(0, 2, 2, dev)
+def step():
+    out = model(bench.clone_batch(batch)); opt.zero_grad(set_to_none=True); out["loss"].backward(); opt.step(); return out
+for _ in range(4): step()
+torch.cuda.synchronize()
+# section timing on the host (enqueue only)
+import contextlib
+def sect():
+    d = bench.clone_batch(batch); t = [time.perf_counter()]
+    d = model.extract_feature(d); t.append(time.perf_counter())
+    ray, d = model.prepare_ray(d); t.append(time.perf_counter())
+    vol = model.prepare_volume(d); t.append(time.perf_counter())
+    res = model._graphed(vol[0], ray); t.append(time.perf_counter())
+    opt.zero_grad(set_to_none=True); res[0].backward(); t.append(time.perf_counter())
+    opt.step(); t.append(time.perf_counter())
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    names = ["backbone_fwd", "prepare_ray", "prepare_volume", "render(graph)", "backward", "opt", "drain"]
+    print(" | ".join("%s %.2f" % (n, 1e3 * (b - a)) for n, a, b in zip(names, t[:-1], t[1:])), flush=True)
+for _ in range(3): sect()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5): step()
+pr.disable(); torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
