@@ -29,6 +29,12 @@ inline int hip_status(hipError_t e) {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Zero `n32` 32-bit words with a kernel launch.  Used instead of hipMemsetAsync for the small
+// scratch buffers: a kernel node is what a hipGraph capture of the caller's stream records
+// reliably (the render head of a training step is replayed as a graph).
+__global__ void zero_words_kernel(uint32_t* p, int64_t n32);
+int zero_words(void* p, int64_t n32, hipStream_t s);
+
 // Grid size for a grid-stride elementwise launch: enough blocks to fill 256 CUs x 8, no more.
 inline int grid_for(int64_t work_items, int block) {
   int64_t b = (work_items + block - 1) / block;

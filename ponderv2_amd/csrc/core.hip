@@ -11,6 +11,18 @@ void set_error(const char* msg) {
 }
 }  // namespace pv2
 
+namespace pv2 {
+__global__ void zero_words_kernel(uint32_t* p, int64_t n32) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += stride) p[i] = 0u;
+}
+int zero_words(void* p, int64_t n32, hipStream_t s) {
+  if (n32 <= 0) return PV2_OK;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(n32, 256)), dim3(256), 0, s, (uint32_t*)p, n32);
+  return check_launch("zero_words");
+}
+}  // namespace pv2
+
 extern "C" {
 int pv2_abi_version(void) { return 1; }
 const char* pv2_last_error(void) { return pv2::g_error; }

@@ -175,7 +175,7 @@ int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const 
                    float* mean_invstd, float* y, pv2_stream_t stream) {
   PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_forward: empty input");
   hipStream_t s = (hipStream_t)stream;
-  if (int e = pv2::hip_status(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * c, s))) return e;
+  if (int e = pv2::zero_words(sums_ws, 4 * (int64_t)c, s)) return e;
   int blocks;
   int64_t rpb;
   reduce_geometry(n, c, &blocks, &rpb);
@@ -193,7 +193,7 @@ int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     double* sums_ws, float* dx, float* dresidual_or_null, pv2_stream_t stream) {
   PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_backward: empty input");
   hipStream_t s = (hipStream_t)stream;
-  if (int e = pv2::hip_status(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * c, s))) return e;
+  if (int e = pv2::zero_words(sums_ws, 4 * (int64_t)c, s)) return e;
   int blocks;
   int64_t rpb;
   reduce_geometry(n, c, &blocks, &rpb);
@@ -208,7 +208,7 @@ int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream) {
   PV2_REQUIRE(c >= 1 && n >= 0, "pv2_col_sum: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  if (int e = pv2::hip_status(hipMemsetAsync(out, 0, sizeof(float) * c, s))) return e;
+  if (int e = pv2::zero_words(out, c, s)) return e;
   if (n == 0) return PV2_OK;
   int blocks;
   int64_t rpb;

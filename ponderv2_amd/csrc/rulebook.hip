@@ -296,7 +296,7 @@ int pv2_downsample_unique(const int32_t* coords, int64_t n, int stride, const in
                           pv2_stream_t stream) {
   PV2_REQUIRE(stride >= 1, "pv2_downsample_unique: stride must be >= 1");
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) return pv2::hip_status(hipMemsetAsync(n_out, 0, sizeof(int32_t), s));
+  if (n == 0) return pv2::zero_words(n_out, 1, s);
   // raw keys -> keys_sorted (as scratch), sorted -> keys_tmp, unique -> keys_sorted.
   hipLaunchKernelGGL(down_keys_kernel, dim3(pv2::grid_for(n, 256)), dim3(256), 0, s,
                      (const int4*)coords, n, stride, out_shape[0], out_shape[1], out_shape[2],
@@ -346,7 +346,7 @@ int pv2_table_count(const int32_t* tbl, int K, int64_t n, const int32_t* n_rows_
                     int32_t* block_sums, int32_t* kstart, pv2_stream_t stream) {
   PV2_REQUIRE(K >= 1, "pv2_table_count: K must be >= 1");
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) return pv2::hip_status(hipMemsetAsync(kstart, 0, sizeof(int32_t) * (K + 1), s));
+  if (n == 0) return pv2::zero_words(kstart, K + 1, s);
   const int nchunks = (int)((n + PV2_SCAN_CHUNK - 1) / PV2_SCAN_CHUNK);
   hipLaunchKernelGGL(table_count_kernel, dim3(nchunks, K), dim3(256), 0, s, tbl, n, n_rows_dev,
                      block_sums);

@@ -64,6 +64,8 @@ class GraphedRenderHead:
     def _capture(self, volume, ray_dict):
         self.s_volume = volume.detach().clone(memory_format=torch.preserve_format)
         self.s_ray = {k: v.detach().clone() for k, v in ray_dict.items()}
+        for p in self.params:
+            p.view_as(p)  # bind the parameters' AccumulateGrad nodes to the caller's stream
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires

@@ -67,13 +67,14 @@ def test_graphed_render_head_equals_eager(device):
             model.zero_grad(set_to_none=True)
             out = model(b)
             out["loss"].backward()
+            grads = [p.grad.clone() for p in model.renderer.parameters() if p.grad is not None]
             rows.append((float(out["loss"]), float(out["eikonal_loss"]),
-                         model.renderer.field.sdf_decoder.lin0.weight.grad.clone(),
-                         model.proj_net.final_conv.weight.grad.clone()))
+                         model.proj_net.final_conv.weight.grad.clone(), *grads))
         if graphed:
             assert model._graphed is not None and not model._graphed.failed, "capture was refused"
         results[graphed] = rows
     for e, g in zip(results[False], results[True]):
         assert abs(e[0] - g[0]) < 1e-5 * abs(e[0]) and abs(e[1] - g[1]) < 1e-4 * abs(e[1]) + 1e-9
+        assert len(e) == len(g) > 20  # every renderer parameter (weights AND biases) is compared
         for a, b in zip(e[2:], g[2:]):
-            assert (a - b).abs().max() < 2e-4 * a.abs().max()
+            assert (a - b).abs().max() <= 2e-4 * a.abs().max() + 1e-12
