@@ -21,14 +21,16 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # MIOpen's find results for the dense UNet3D convs ship in-tree (miopen_cache/): without them the
-# first step spends ~95 s benchmarking solvers on every fresh box.
+# first step spends ~95 s benchmarking solvers on every fresh box.  Must be set before MIOpen loads.
 os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_cache", "db"))
 os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(ROOT, "miopen_cache", "cache"))
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # use the find-db record when there is one
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -111,6 +111,16 @@ class PonderIndoor(nn.Module):
             emb = emb / emb.norm(dim=-1, keepdim=True)
         return emb.float(), float(model.logit_scale)
 
+    def _valid_embedding(self, cond_idx, device):
+        """class_embedding rows of one condition's valid classes, sliced once per device (indexing
+        with a Python list every step is a host->device copy and a sync)."""
+        cache = self.__dict__.setdefault("_valid_emb_cache", {})
+        key = (cond_idx, str(device))
+        if key not in cache:
+            vi = list(self.valid_index[cond_idx])
+            cache[key] = self.class_embedding.to(device)[vi, :].contiguous()
+        return cache[key]
+
     def _condition_index(self, data_dict):
         condition = data_dict["condition"][0]
         assert condition in self.conditions
@@ -234,8 +244,7 @@ class PonderIndoor(nn.Module):
         if self.render_semantic:
             index2semantic = data_dict.get("index2semantic")
             if "condition" in data_dict:
-                vi = list(self.valid_index[self._condition_index(data_dict)])
-                index2semantic = self.class_embedding[vi, :]
+                index2semantic = self._valid_embedding(self._condition_index(data_dict), dev)
                 data_dict["index2semantic"] = index2semantic
             if index2semantic is None:
                 index2semantic = self.class_embedding
@@ -373,8 +382,7 @@ class PonderIndoor(nn.Module):
     def ppt_loss(self, data_dict):
         feat = self.proj_head(data_dict["sparse_backbone_feat"])
         feat = feat / feat.norm(dim=-1, keepdim=True)
-        vi = list(self.valid_index[self._condition_index(data_dict)])
-        sim = feat @ self.class_embedding[vi, :].t()
+        sim = feat @ self._valid_embedding(self._condition_index(data_dict), feat.device).t()
         return self.ppt_criteria(self.logit_scale.exp() * sim, data_dict["segment"])
 
     def forward(self, data_dict):
