@@ -233,7 +233,9 @@ def main():
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
     torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = True  # let MIOpen search its solvers for the dense convs
+    # MIOpen: "benchmark" = run the solver search now; otherwise immediate mode, which reads the
+    # find-db shipped in miopen_cache/ (written by an earlier search on this GPU / MIOpen version)
+    torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
     cfg = model_cfg(args.rays_per_view, args.dense_dtype)
     cfg["graph_render_head"] = not args.no_graph
     model = build_model(ConfigDict(cfg)).to(device).train()
