@@ -104,6 +104,11 @@ int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_row
  *             tile_pairs = pv2_spconv_forward_tile(c_in, c_out): 128 for the LDS-staged kernel
  *             (c_in % 32 == 0), PV2_PAIR_TILE for the generic one
  * n_tiles     tile_start[K] (host value)
+ * center_tile_lo/hi  tile range [tile_start[kc], tile_start[kc+1]) of an offset kc whose pairs hit
+ *             EVERY output row exactly once (the centre tap of a submanifold conv, or the single
+ *             offset of a 1x1 conv).  When non-empty (LDS-staged kernel only) that offset runs first
+ *             with plain stores, so `out` need NOT be initialised and only the other offsets pay
+ *             for atomics.  Pass lo == hi (e.g. 0,0) otherwise; then
  * `out` must be pre-initialised (zeros, or a bias/residual to accumulate onto).
  * ------------------------------------------------------------------------------------------ */
 #define PV2_PAIR_TILE 32
@@ -111,7 +116,8 @@ int pv2_spconv_forward_tile(int c_in, int c_out);
 int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
                        int c_out, const int32_t* pair_in, const int32_t* pair_out,
                        const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
-                       int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream);
+                       int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
+                       float* out_feat, int64_t n_out, pv2_stream_t stream);
 
 /* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
  * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count chunks of

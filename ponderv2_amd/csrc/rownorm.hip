@@ -156,11 +156,12 @@ __global__ __launch_bounds__(kThreads) void col_sum_kernel(const float* __restri
 }
 
 inline void reduce_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block) {
-  // aim for ~2 blocks per CU with at least ~64 row-iterations each
+  // enough blocks to cover the 256 CUs several times over (these matrices are only a few MB, the
+  // reduction is latency-bound), at least 8 row-iterations per block
   const int rpi = c >= kThreads ? 1 : kThreads / c;
-  int64_t want = (n + (int64_t)rpi * 32 - 1) / ((int64_t)rpi * 32);
+  int64_t want = (n + (int64_t)rpi * 8 - 1) / ((int64_t)rpi * 8);
   if (want < 1) want = 1;
-  if (want > 512) want = 512;
+  if (want > 2048) want = 2048;
   *blocks = (int)want;
   *rows_per_block = (n + want - 1) / want;
 }

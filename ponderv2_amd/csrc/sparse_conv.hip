@@ -202,11 +202,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int n_groups,
-    float* __restrict__ Y, int ablate) {
+    float* __restrict__ Y, int ablate, int tile_base, int skip_lo, int skip_len, int store) {
   constexpr int NT = 32 * NB;
   __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+  int tile = blockIdx.x / n_groups + tile_base;
+  if (tile >= skip_lo) tile += skip_len;  // the tiles of the centre offset ran in the store pass
+  const int grp = blockIdx.x % n_groups;
   const int k = find_offset(tile_start, K, tile);
   const int p0 = kstart[k] + (tile - tile_start[k]) * kFwdTile;
   const int pend = kstart[k + 1];
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + nb * 32 + i;
-        if (n < c_out) unsafeAtomicAdd(Y + (int64_t)orow[r] * c_out + n, acc[nb][r]);
+        if (n < c_out) {
+          if (store) Y[(int64_t)orow[r] * c_out + n] = acc[nb][r];  // first writer of this row
+          else unsafeAtomicAdd(Y + (int64_t)orow[r] * c_out + n, acc[nb][r]);
+        }
       }
     }
   }
@@ -536,15 +541,29 @@ int ablate_flags();
 template <int NB>
 int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                    const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
-                   float* Y, hipStream_t s) {
+                   float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi) {
   const int n_groups = (c_out + NB * 32 - 1) / (NB * 32);
-  const int64_t blocks = n_tiles * n_groups;
-  if (blocks > 0x7fffffffLL) {
+  if (n_tiles * n_groups > 0x7fffffffLL) {
     pv2::set_error("pv2_spconv_forward: grid too large");
     return PV2_E_BADARG;
   }
-  hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, X, c_in,
-                     W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags());
+  if (center_hi > center_lo) {
+    // pass A: the centre offset touches every output row exactly once -> plain stores initialise
+    // the output (no zero-fill, no atomics); pass B: every other offset accumulates on top.
+    const int64_t nc = center_hi - center_lo;
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
+                       s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(),
+                       (int)center_lo, 0x7fffffff, 0, 1);
+    const int64_t rest = n_tiles - nc;
+    if (rest > 0)
+      hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(rest * n_groups)), dim3(256),
+                         0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
+                         (int)center_lo, (int)nc, 0);
+  } else {
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
+                       0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
+                       0x7fffffff, 0, 0);
+  }
   return pv2::check_launch("spconv_fwd_lds");
 }
 
@@ -580,7 +599,8 @@ int pv2_spconv_forward_tile(int c_in, int c_out) {
 int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
                        int c_out, const int32_t* pair_in, const int32_t* pair_out,
                        const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
-                       int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream) {
+                       int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
+                       float* out_feat, int64_t n_out, pv2_stream_t stream) {
   PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_forward: bad channel/offset count");
   PV2_REQUIRE(tile_pairs == pv2_spconv_forward_tile(c_in, c_out),
               "pv2_spconv_forward: tile_pairs must be pv2_spconv_forward_tile(c_in, c_out)");
@@ -591,13 +611,17 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
   const int nblk = (c_out + 31) / 32;
 #define PV2_FWD_ARGS in_feat, c_in, weight, K, c_out, pair_in, pair_out, kstart, tile_start, n_tiles, out_feat, s
   if (tile_pairs == kFwdTile) {
+    PV2_REQUIRE(center_tile_hi <= n_tiles && center_tile_lo <= center_tile_hi,
+                "pv2_spconv_forward: bad centre tile range");
     switch (nblk >= 4 ? 4 : nblk) {
-      case 1: return launch_fwd_lds<1>(PV2_FWD_ARGS);
-      case 2: return launch_fwd_lds<2>(PV2_FWD_ARGS);
-      case 3: return launch_fwd_lds<3>(PV2_FWD_ARGS);
-      default: return launch_fwd_lds<4>(PV2_FWD_ARGS);
+      case 1: return launch_fwd_lds<1>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      case 2: return launch_fwd_lds<2>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      case 3: return launch_fwd_lds<3>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      default: return launch_fwd_lds<4>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
     }
   }
+  PV2_REQUIRE(center_tile_hi <= center_tile_lo,
+              "pv2_spconv_forward: the generic kernel has no store pass (pass an empty centre range)");
   // generic path (any c_in): one wave per 32-pair tile, operands straight from global memory
   int nb = nblk >= 4 ? 4 : nblk;
   if (nb == 4 && n_tiles * ((nblk + 3) / 4) < 2048) nb = 2;

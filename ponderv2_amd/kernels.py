@@ -12,6 +12,8 @@ import torch
 from . import _lib
 from ._lib import PAIR_TILE, SCAN_CHUNK, WGRAD_TILE, PointsDesc, VolumeDesc
 
+FWD_LDS_TILE = 128  # tile of the LDS-staged forward kernel (pv2_spconv_forward_tile)
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -42,6 +44,9 @@ class Rulebook:
     pair_out: torch.Tensor   # int32 [P]
     kstart: torch.Tensor     # int32 [K+1] device
     kstart_host: np.ndarray  # int64 [K+1]
+    # offset whose pairs hit every output row exactly once (centre tap of a submanifold conv, the
+    # single offset of a 1x1 conv); -1 when there is none (strided / inverse convs)
+    center_k: int = -1
     _tiles: dict = field(default_factory=dict)
 
     @property
@@ -57,14 +62,15 @@ class Rulebook:
             per_k = torch.div(counts + (tile - 1), tile, rounding_mode="floor")
             dev = torch.zeros(self.K + 1, dtype=torch.int32, device=self.kstart.device)
             dev[1:] = torch.cumsum(per_k, 0).to(torch.int32)
-            total = int(((np.diff(self.kstart_host) + tile - 1) // tile).sum())
-            self._tiles[tile] = (dev, total)
+            host = np.zeros(self.K + 1, dtype=np.int64)
+            np.cumsum((np.diff(self.kstart_host) + tile - 1) // tile, out=host[1:])
+            self._tiles[tile] = (dev, int(host[-1]), host)
         return self._tiles[tile]
 
     def transposed(self) -> "Rulebook":
         """Same pairs with the roles of input and output swapped (inverse conv / grad-input)."""
         rb = Rulebook(self.K, self.n_out, self.n_in, self.pair_out, self.pair_in, self.kstart,
-                      self.kstart_host)
+                      self.kstart_host, self.center_k if self.n_in == self.n_out else -1)
         rb._tiles = self._tiles
         return rb
 
@@ -99,7 +105,8 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if ksize == 1:
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         kh = np.array([0, n], dtype=np.int64)
-        return Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh)
+        return Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh,
+                        center_k=0)
     L = _lib.lib()
     tsize = 1 << max(4, int(2 * max(n, 1) - 1).bit_length())
     keys = torch.empty(tsize, dtype=torch.int64, device=dev)
@@ -110,7 +117,7 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     _lib.check(L.pv2_subm_neighbor_table(_ptr(coords), n, ksize, _ptr(keys), _ptr(vals), tsize,
                                          _ptr(nbr), _stream(coords)), "pv2_subm_neighbor_table")
     pair_in, pair_out, kstart, kstart_host = _compact(nbr, K, n, None)
-    return Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host)
+    return Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host, center_k=K // 2)
 
 
 def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List[int]):
@@ -155,15 +162,21 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     weight_okc = weight_okc.contiguous()
     c_out, K, c_in = weight_okc.shape
     assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
-    if out is None:
-        out = torch.zeros((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
     L = _lib.lib()
     tile = L.pv2_spconv_forward_tile(c_in, c_out)
-    tile_start, n_tiles = rb.tiles(tile)
+    tile_start, n_tiles, tile_host = rb.tiles(tile)
+    c_lo = c_hi = 0
+    if out is None:
+        if tile == FWD_LDS_TILE and rb.center_k >= 0 and rb.n_out > 0:
+            # the centre offset initialises every output row with plain stores (no zero-fill)
+            c_lo, c_hi = int(tile_host[rb.center_k]), int(tile_host[rb.center_k + 1])
+            out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
+        else:
+            out = torch.zeros((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
     _lib.check(L.pv2_spconv_forward(
         _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
-        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(out), rb.n_out,
-        _stream(feats)), "pv2_spconv_forward")
+        _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, c_lo, c_hi, _ptr(out),
+        rb.n_out, _stream(feats)), "pv2_spconv_forward")
     return out
 
 
@@ -179,7 +192,7 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     L = _lib.lib()
     if tile is None:
         tile = L.pv2_spconv_wgrad_tile(c_in, c_out, rb.n_pairs, rb.K)
-    tile_start, n_tiles = rb.tiles(tile)
+    tile_start, n_tiles, _ = rb.tiles(tile)
     _lib.check(L.pv2_spconv_backward_weight(
         _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, rb.K, _ptr(rb.pair_in),
         _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(dw),
