@@ -33,6 +33,11 @@ typedef void* pv2_stream_t; /* hipStream_t */
 #define PV2_E_WORKSPACE (-3)
 
 int pv2_abi_version(void);
+/* Zero `nbytes` (multiple of 4) with a KERNEL on `stream`.  The accumulate-into buffers of this
+ * library (conv outputs, weight gradients, sampler volume gradients) are cleared with this rather
+ * than hipMemsetAsync / torch.zeros: on ROCm 7.2 a memset was observed to be reordered against the
+ * atomics of the following kernel on the same stream (and not to replay inside a captured graph). */
+int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream);
 /* Debug only: kernel ablation flags used by tools/bench_spconv_kernels.py (0 = production). */
 int pv2_debug_set_ablate(int flags);
 const char* pv2_last_error(void);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "pv2_abi_version": (c_int, []),
     "pv2_last_error": (c_char_p, []),
     "pv2_debug_set_ablate": (c_int, [c_int]),
+    "pv2_zero_fill": (c_int, [_P, c_int64, _P]),
     "pv2_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
     "pv2_subm_neighbor_table": (c_int, [_P, c_int64, c_int, _P, _P, c_int64, _P, _P]),
     "pv2_downsample_workspace_bytes": (c_size_t, [c_int64]),

@@ -24,6 +24,13 @@ int zero_words(void* p, int64_t n32, hipStream_t s) {
 }  // namespace pv2
 
 extern "C" {
+int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream) {
+  if (nbytes % 4 != 0) {
+    pv2::set_error("pv2_zero_fill: nbytes must be a multiple of 4");
+    return PV2_E_BADARG;
+  }
+  return pv2::zero_words(ptr, nbytes / 4, (hipStream_t)stream);
+}
 int pv2_abi_version(void) { return 1; }
 const char* pv2_last_error(void) { return pv2::g_error; }
 }

@@ -23,6 +23,15 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def zeros_by_kernel(shape, dtype, device):
+    """torch.zeros, but cleared by a kernel launch on the current stream (see pv2_zero_fill)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if t.numel():
+        _lib.check(_lib.lib().pv2_zero_fill(_ptr(t), t.numel() * t.element_size(), _stream(t)),
+                   "pv2_zero_fill")
+    return t
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -172,7 +181,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
             c_lo, c_hi = int(tile_host[rb.center_k]), int(tile_host[rb.center_k + 1])
             out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
         else:
-            out = torch.zeros((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
+            out = zeros_by_kernel((rb.n_out, c_out), torch.float32, feats.device)
     _lib.check(L.pv2_spconv_forward(
         _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
         _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, c_lo, c_hi, _ptr(out),
@@ -188,7 +197,7 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     grad_out = grad_out.contiguous()
     c_in = feats.shape[1]
     assert grad_out.shape == (rb.n_out, c_out) and feats.shape[0] == rb.n_in
-    dw = torch.zeros((c_out, rb.K, c_in), dtype=torch.float32, device=feats.device)
+    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
     L = _lib.lib()
     if tile is None:
         tile = L.pv2_spconv_wgrad_tile(c_in, c_out, rb.n_pairs, rb.K)

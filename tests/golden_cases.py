@@ -51,6 +51,13 @@ def indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=256):
                 ppt_criteria=[dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)])
 
 
+def cos_err(a, b):
+    """1 - cosine similarity (direction error of a gradient tensor)."""
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double().flatten()
+    b = torch.as_tensor(np.asarray(b)).double().flatten()
+    return 1.0 - float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
 def rel_err(a, b):
     a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
     b = torch.as_tensor(np.asarray(b)).double()
@@ -97,9 +104,13 @@ def run_spunet(device, dtype):
     (out * probe).sum().backward()
     params = dict(model.named_parameters())
     errs = {"out": rel_err(out, g["out"]), "dfeat": rel_err(feat.grad, g["dfeat"])}
+    cos = {"dfeat": cos_err(feat.grad, g["dfeat"])}
     for i, name in enumerate(g["grad_names"]):
         errs[str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
-    return errs
+        cos[str(name)] = cos_err(params[str(name)].grad, g[f"grad_{i}"])
+    if dtype == torch.float64:
+        return errs
+    return errs, cos
 
 
 def run_neus(device):

@@ -28,5 +28,5 @@ if os.path.exists("/tmp/grads_1.pt") and os.path.exists("/tmp/grads_0.pt"):
         e = (g1[k] - g0[k]).abs().max().item() / (g1[k].abs().max().item() + 1e-30)
         if e > 1e-4 and "weight" in k and g1[k].dim() > 1:
             print("%-40s %s rel diff %.2e" % (k, tuple(g1[k].shape), e))
-errs = gc.run_spunet(torch.device("cuda:0"), torch.float32)
+errs, _ = gc.run_spunet(torch.device("cuda:0"), torch.float32)
 print("GENERIC=%s vs golden:" % os.environ.get("PV2_SPCONV_GENERIC", "0"), {k: float("%.2e" % v) for k, v in errs.items()})
