@@ -33,10 +33,10 @@ typedef void* pv2_stream_t; /* hipStream_t */
 #define PV2_E_WORKSPACE (-3)
 
 int pv2_abi_version(void);
-/* Zero `nbytes` (multiple of 4) with a KERNEL on `stream`.  The accumulate-into buffers of this
- * library (conv outputs, weight gradients, sampler volume gradients) are cleared with this rather
- * than hipMemsetAsync / torch.zeros: on ROCm 7.2 a memset was observed to be reordered against the
- * atomics of the following kernel on the same stream (and not to replay inside a captured graph). */
+/* Zero `nbytes` (multiple of 4) with a KERNEL on `stream`.  Scratch and accumulate-into buffers of
+ * this library are cleared with a kernel rather than hipMemsetAsync: on ROCm 7.2 a hipMemsetAsync
+ * issued from this library while the stream was being captured into a hipGraph was not replayed
+ * with the graph (stale bias gradients in the render head until it was replaced). */
 int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream);
 /* Debug only: kernel ablation flags used by tools/bench_spconv_kernels.py (0 = production). */
 int pv2_debug_set_ablate(int flags);
