@@ -13,6 +13,10 @@ from . import _lib
 from ._lib import PAIR_TILE, SCAN_CHUNK, WGRAD_TILE, PointsDesc, VolumeDesc
 
 FWD_LDS_TILE = 128  # tile of the LDS-staged forward kernel (pv2_spconv_forward_tile)
+# Run the centre offset of submanifold convs as a separate plain-store pass (no zero-fill, fewer
+# atomics).  Measured neutral on MI355X at the ScanNet batch (the second launch and its smaller
+# grids cost what the saved fill and atomics gain), so the single-launch path is the default.
+USE_CENTER_STORE = False
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -176,7 +180,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     tile_start, n_tiles, tile_host = rb.tiles(tile)
     c_lo = c_hi = 0
     if out is None:
-        if tile == FWD_LDS_TILE and rb.center_k >= 0 and rb.n_out > 0:
+        if USE_CENTER_STORE and tile == FWD_LDS_TILE and rb.center_k >= 0 and rb.n_out > 0:
             # the centre offset initialises every output row with plain stores (no zero-fill)
             c_lo, c_hi = int(tile_host[rb.center_k]), int(tile_host[rb.center_k + 1])
             out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
