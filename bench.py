@@ -56,7 +56,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenes-per-gpu", type=int, default=2)
+    ap.add_argument("--workload", default="indoor", choices=["indoor", "outdoor"],
+                    help="indoor = BASELINE configs[1] (the headline metric); outdoor = the "
+                         "PonderOutdoor-v2 / nuScenes-shaped step of configs[4] on this GPU's shard")
+    ap.add_argument("--scenes-per-gpu", type=int, default=None,
+                    help="default 2 (indoor, configs[1]) / 4 (outdoor, the reference's per-GPU batch)")
+    ap.add_argument("--rays-per-camera", type=int, default=512, help="outdoor: RaySample.point_nsample")
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--rays-per-view", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,7 +74,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager render head (no hipGraph replay)")
     ap.add_argument("--print-losses", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scenes_per_gpu is None:
+        args.scenes_per_gpu = 2 if args.workload == "indoor" else 4
+    return args
 
 
 def model_cfg(rays_per_view, dense_dtype="float32"):
@@ -80,6 +88,24 @@ def model_cfg(rays_per_view, dense_dtype="float32"):
     cfg = gc.indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
     cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
     return cfg
+
+
+def outdoor_model_cfg(dense_dtype="float32"):
+    import golden_cases as gc  # the nuScenes model section, restated
+
+    backbone = dict(type="SpUNet-v1m1", in_channels=4, num_classes=0,
+                    channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
+    cfg = gc.outdoor_model_cfg(backbone)
+    cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
+    return cfg
+
+
+def make_outdoor_batch(rank, scenes, rays_per_camera, device):
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+
+    batch = lidar_collate_fn([make_lidar_scene(1000 * rank + i, point_nsample=rays_per_camera)
+                              for i in range(scenes)])
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 class KernelTimer:
@@ -251,16 +277,23 @@ def main():
     # MIOpen: "benchmark" = run the solver search now; otherwise immediate mode, which reads the
     # find-db shipped in miopen_cache/ (written by an earlier search on this GPU / MIOpen version)
     torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
-    cfg = model_cfg(args.rays_per_view, args.dense_dtype)
+    outdoor = args.workload == "outdoor"
+    cfg = outdoor_model_cfg(args.dense_dtype) if outdoor else model_cfg(args.rays_per_view,
+                                                                          args.dense_dtype)
     cfg["graph_render_head"] = not args.no_graph
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)
-    lr = 0.0005 * (args.scenes_per_gpu * world) / 8
-    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
-    batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
+    if outdoor:  # configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py:95
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01)
+        batch = make_outdoor_batch(rank, args.scenes_per_gpu, args.rays_per_camera, device)
+    else:
+        lr = 0.0005 * (args.scenes_per_gpu * world) / 8
+        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4,
+                              nesterov=True)
+        batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
     n_vox = int(batch["offset"][-1])
 
     def step():
@@ -314,9 +347,13 @@ def main():
     if rank == 0:
         scenes = args.scenes_per_gpu * world * args.steps
         rays_per_scene = args.views * args.rays_per_view
+        if outdoor:
+            rays_per_scene = int(batch["ray_offset"][-1]) / args.scenes_per_gpu
         value = scenes / elapsed
         result = {
-            "metric": "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 ScanNet-shaped",
+            "metric": ("pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 nuScenes-shaped"
+                       if outdoor else
+                       "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 ScanNet-shaped"),
             "value": value, "unit": "scenes/s", "rays_per_s": value * rays_per_scene,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -327,9 +364,13 @@ def main():
                       f"f32 sparse conv + render head; {args.dense_dtype} autocast for the dense "
                       "UNet3D convs (reference enable_amp=True)"),
             "data": "synthetic",
-            "config": {"workload": "configs[1]: PonderV2-indoor ScanNet pretrain, SpUNet-v1m1, "
-                                   f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
-                                   "train step fwd+bwd+SGD",
+            "config": {"workload": (("configs[4]: PonderV2-outdoor nuScenes pretrain, SpUNet-v1m1, "
+                                     f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene:.0f} rays/scene"
+                                     " (6 cameras), mask 0.8, train step fwd+bwd+AdamW") if outdoor
+                                    else
+                                    ("configs[1]: PonderV2-indoor ScanNet pretrain, SpUNet-v1m1, "
+                                     f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
+                                     "train step fwd+bwd+SGD")),
                        "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
             "final_loss": loss,
@@ -359,7 +400,7 @@ def main():
                                   for k, v in r.items()} for r in kernels]
             result["handwritten_kernel_ms_per_step"] = sum(r["total_ms"] for r in kernels) / args.steps
             result["ms_per_step_with_event_instrumentation"] = 1e3 * elapsed_instr / args.steps
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not outdoor:
             result["cpu_baseline"] = cpu_baseline(args)
     if world > 1:
         dist.barrier()

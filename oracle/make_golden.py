@@ -181,14 +181,90 @@ def ponder_indoor_case(ConfigDict):
           "rand draws", [tuple(r.shape) for r in rec.rand])
 
 
+# reduced nuScenes geometry shared with tests/golden_cases.py: a 54 m box, 1.2 m dense cells
+OUTDOOR_SMALL = dict(scene_bbox=((-27.0, -27.0, -5.0, 27.0, 27.0, 3.0),), grid_shape=((45, 45, 5),),
+                     grid_size=((1.2, 1.2, 1.6),))
+OUTDOOR_SCENE_KW = dict(grid_size=0.1, point_nsample=24, n_azimuth=200,
+                        point_cloud_range=(-27.0, -27.0, -5.0, 27.0, 27.0, 3.0))
+
+
+def lidar_transform_case():
+    """Reference PointRangeFilter / GridSample(ravel) / ProjectOnImage / RaySample
+    (datasets/transform.py:232-378,1078-1213) on one synthetic sweep, numpy seed fixed."""
+    from ponderv2_amd.ponder.datasets import make_sweep
+
+    T = ref_shims.load_reference_file("ponder/datasets/transform.py")
+    data = make_sweep(7, n_azimuth=200)
+    np.random.seed(7)
+    data = T.PointRangeFilter(point_cloud_range=OUTDOOR_SCENE_KW["point_cloud_range"], padding=0.1)(data)
+    data = T.GridSample(grid_size=0.1, hash_type="ravel", mode="train",
+                        keys=("coord", "strength", "segment"), return_grid_coord=True)(data)
+    data = T.ProjectOnImage(filter_overlap=True, close_radius=3.0)(data)
+    n_proj = np.array([int(m.sum()) for m in data["img_proj_mask"]])
+    data = T.RaySample(point_nsample=24, fetch_color=False, fetch_segment=True)(data)
+    np.savez_compressed(os.path.join(GOLDEN, "lidar_transforms.npz"),
+                        grid_coord=data["grid_coord"].astype(np.int32), n_proj=n_proj,
+                        ray_start=data["ray_start"], ray_end=data["ray_end"],
+                        ray_segment=data["ray_segment"])
+    print("lidar_transforms: voxels", len(data["grid_coord"]), "projected", n_proj.tolist(),
+          "rays", len(data["ray_end"]))
+
+
+def ponder_outdoor_case(ConfigDict):
+    """Reference PonderOutdoor.forward (ponder_outdoor_base.py:258-265) end to end on a synthetic
+    two-sweep batch: block masking with mtoken, reduced backbone / grid, fp32, training mode."""
+    from ponder.models.builder import MODELS
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+    from ponderv2_amd.ponder.utils.config import Config
+
+    cfg = Config.fromfile(os.path.join(ref_shims.REFERENCE_ROOT,
+                                       "configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py"))
+    mcfg = cfg.model.to_dict()
+    mcfg["backbone"] = dict(SMALL_BACKBONE, in_channels=4, channels=(16, 32, 48, 64, 64, 48, 32, 96))
+    mcfg.update(OUTDOOR_SMALL)
+    torch.manual_seed(0)
+    model = MODELS.build(ConfigDict(mcfg))
+    fill_deterministic(model)
+    model.train()
+    batch = lidar_collate_fn([make_lidar_scene(200, **OUTDOOR_SCENE_KW),
+                              make_lidar_scene(201, **OUTDOOR_SCENE_KW)])
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()
+           if not k.endswith("_host")}
+    torch.manual_seed(99)
+    with Recorder() as rec:
+        out = model(inp)
+    out["loss"].backward()
+    B = len(batch["offset"])
+    mask_rand = np.concatenate([r.numpy().reshape(-1) for r in rec.rand[:B]])
+    draws = rec.rand[B:]
+    params = dict(model.named_parameters())
+    gnames = ["mtoken", "backbone.conv_input.0.weight", "backbone.dec.0.block0.conv2.weight",
+              "proj_net.conv.0.weight", "proj_net.conv.1.bias",
+              "renderer.field.sdf_decoder.lin1.weight", "renderer.field.deviation_network.variance"]
+    np.savez_compressed(
+        os.path.join(GOLDEN, "ponder_outdoor_small.npz"), mask_rand=mask_rand,
+        rands=np.array(len(draws)), **{f"rand_{i}": r.numpy() for i, r in enumerate(draws)},
+        out_names=np.array(list(out.keys())), out_values=np.array([float(v) for v in out.values()]),
+        grad_names=np.array(gnames),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    print("ponder_outdoor_small:", {k: round(float(v), 6) for k, v in out.items()},
+          "mask draws", [tuple(r.shape) for r in rec.rand[:B]],
+          "sampler draws", [tuple(r.shape) for r in draws],
+          "rays", batch["ray_offset"].tolist(), "voxels", batch["offset"].tolist())
+
+
 def main():
     ref_shims.install()
     os.makedirs(GOLDEN, exist_ok=True)
     from ponderv2_amd.ponder.utils.config import ConfigDict  # attribute dict, like addict's
 
-    spunet_case()
-    neus_case_impl(ConfigDict)
-    ponder_indoor_case(ConfigDict)
+    only = sys.argv[1:]
+    cases = dict(spunet=spunet_case, neus=lambda: neus_case_impl(ConfigDict),
+                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case,
+                 outdoor=lambda: ponder_outdoor_case(ConfigDict))
+    for name, fn in cases.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

@@ -168,6 +168,8 @@ def collate_fn(samples):
 class SyntheticRGBDDataset(torch.utils.data.Dataset):
     """Endless-ish stream of seeded scenes; ``len`` scenes, scene i uses seed ``base_seed + i``."""
 
+    collate_fn = staticmethod(collate_fn)
+
     def __init__(self, length=64, base_seed=0, num_views=2, image_hw=(480, 640), n_raw=120000,
                  keep=0.2, grid_size=0.02, n_voxels=None, loop=1, **kwargs):
         self.length, self.base_seed, self.loop = length, base_seed, loop

@@ -10,7 +10,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ..datasets import SyntheticRGBDDataset, collate_fn
+from ..datasets import (ConcatDataset, MultiDatasetDataloader, SyntheticLidarDataset,
+                        SyntheticRGBDDataset, collate_fn)
 from ..models import build_model
 from ..utils import comm
 from ..utils.optimizer import build_optimizer, build_scheduler
@@ -21,9 +22,12 @@ from .hooks import HOOKS, HookBase
 TRAINERS = Registry("trainers")
 DATASETS = Registry("datasets")
 DATASETS.register_module(module=SyntheticRGBDDataset, name="SyntheticRGBDDataset")
+DATASETS.register_module(module=SyntheticLidarDataset, name="SyntheticLidarDataset")
 
 
 def build_dataset(cfg):
+    if cfg["type"] == "ConcatDataset":  # ponder/datasets/defaults.py:143-148
+        return ConcatDataset([build_dataset(d) for d in cfg["datasets"]], loop=cfg.get("loop", 1))
     if cfg["type"] not in DATASETS:
         raise KeyError(
             f"dataset {cfg['type']!r}: on-disk dataset readers are not part of this round's hot "
@@ -132,7 +136,8 @@ class Trainer(TrainerBase):
         workers = self.cfg.num_worker_per_gpu
         return torch.utils.data.DataLoader(
             data, batch_size=self.cfg.batch_size_per_gpu, shuffle=sampler is None,
-            num_workers=workers, sampler=sampler, collate_fn=collate_fn,
+            num_workers=workers, sampler=sampler,
+            collate_fn=getattr(data, "collate_fn", None) or collate_fn,
             pin_memory=torch.cuda.is_available(), drop_last=True,
             persistent_workers=workers > 0)
 
@@ -161,3 +166,21 @@ class Trainer(TrainerBase):
             self.optimizer.step()
             self.scheduler.step()
         self.comm_info["model_output_dict"] = out
+
+
+@TRAINERS.register_module("MultiDatasetTrainer")
+class MultiDatasetTrainer(Trainer):
+    """Batches alternate between the sub-datasets of a ConcatDataset (engines/train.py:294-309)."""
+
+    def build_train_loader(self):
+        data = build_dataset(self.cfg.data.train)
+        loader = MultiDatasetDataloader(data, self.cfg.batch_size_per_gpu,
+                                        self.cfg.num_worker_per_gpu, self.cfg.get("mix_prob", 0),
+                                        self.cfg.get("seed"), max_point=self.cfg.get("max_point", -1),
+                                        default_collate=collate_fn)
+        self.comm_info["iter_per_epoch"] = len(loader)
+        return loader
+
+    def before_epoch(self):
+        self.train_loader.sampler.set_epoch(self.epoch)
+        self.model.train()

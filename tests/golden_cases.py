@@ -175,3 +175,69 @@ def run_ponder_indoor(device):
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
     return errs
+
+
+# model section of configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py (reference :20-92)
+OUTDOOR_RENDERER = dict(
+    type="NeuSModel",
+    field=dict(type="SDFField", sdf_decoder=dict(in_dim=32, out_dim=17, hidden_size=16, n_blocks=5),
+               beta_init=0.3, use_gradient=True, volume_type="default", padding_mode="zeros",
+               share_volume=True),
+    collider=dict(type="AABBBoxCollider", near_plane=0.01, bbox=[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]),
+    sampler=dict(type="NeuSSampler", initial_sampler="UniformSampler", num_samples=72,
+                 num_samples_importance=24, num_upsample_steps=1, train_stratified=True,
+                 single_jitter=False),
+    loss=dict(sensor_depth_truncation=0.01, weights=dict(depth_loss=10.0)))
+
+NUSCENES_CLASSES = ("barrier", "bicycle", "bus", "car", "construction vehicle", "motorcycle",
+                    "pedestrian", "traffic cone", "trailer", "truck",
+                    "path suitable or safe for driving", "other flat", "sidewalk", "terrain",
+                    "man made", "vegetation")
+
+OUTDOOR_SMALL = dict(scene_bbox=((-27.0, -27.0, -5.0, 27.0, 27.0, 3.0),), grid_shape=((45, 45, 5),),
+                     grid_size=((1.2, 1.2, 1.6),))
+OUTDOOR_SCENE_KW = dict(grid_size=0.1, point_nsample=24, n_azimuth=200,
+                        point_cloud_range=(-27.0, -27.0, -5.0, 27.0, 27.0, 3.0))
+
+
+def outdoor_model_cfg(backbone, **geometry):
+    cfg = dict(type="PonderOutdoor-v2", mask=dict(ratio=0.8, size=8, channel=4), backbone=backbone,
+               projection=dict(type="SimpleConv3D-v1m1", in_channels=96, out_channels=32),
+               renderer=OUTDOOR_RENDERER,
+               scene_bbox=((-54.0, -54.0, -5.0, 54.0, 54.0, 3.0),), grid_shape=((180, 180, 5),),
+               grid_size=((0.6, 0.6, 1.6),), val_ray_split=8192, pool_type="mean",
+               share_volume=True, render_semantic=False, conditions=("nuScenes",),
+               template="[x]", clip_model="ViT-B/16", class_name=NUSCENES_CLASSES,
+               valid_index=(tuple(range(16)),))
+    cfg.update(geometry)
+    return cfg
+
+
+def run_ponder_outdoor(device):
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "ponder_outdoor_small.npz"))
+    cfg = outdoor_model_cfg(dict(SMALL_BACKBONE, in_channels=4,
+                                 channels=(16, 32, 48, 64, 64, 48, 32, 96)), **OUTDOOR_SMALL)
+    cfg["graph_render_head"] = False  # the recorded random draws are injected from the host
+    model = build_model(ConfigDict(cfg))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
+    batch = lidar_collate_fn([make_lidar_scene(200, **OUTDOOR_SCENE_KW),
+                              make_lidar_scene(201, **OUTDOOR_SCENE_KW)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch["mask_rand"] = torch.from_numpy(g["mask_rand"]).to(device)
+    out = model(batch)
+    out["loss"].backward()
+    errs = {}
+    for name, val in zip(g["out_names"], g["out_values"]):
+        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+    params = dict(model.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs

@@ -52,3 +52,33 @@ def test_trainer_two_ranks_via_launch(tmp_path):
     assert len(rows) == 2 and all("loss" in r and r["loss"] == r["loss"] for r in rows)
     ckpt = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
     assert ckpt["epoch"] == 1 and "backbone.conv_input.0.weight" in ckpt["state_dict"]
+
+
+@pytest.mark.timeout(900)
+def test_multi_dataset_trainer_outdoor_two_ranks(tmp_path):
+    """MultiDatasetTrainer + PonderOutdoor-v2 (block masking, lidar rays) over 2 gloo ranks."""
+    import golden_cases as gc
+    from ponderv2_amd.ponder.engines import launch
+    from ponderv2_amd.ponder.utils.config import Config
+
+    model = gc.outdoor_model_cfg(dict(gc.SMALL_BACKBONE, in_channels=4,
+                                      channels=(16, 32, 48, 64, 64, 48, 32, 96)), **gc.OUTDOOR_SMALL)
+    cfg = Config(dict(
+        weight=None, resume=False, evaluate=False, seed=5, save_path=str(tmp_path), num_worker=0,
+        batch_size=2, epoch=1, eval_epoch=1, sync_bn=False, enable_amp=False, empty_cache=False,
+        find_unused_parameters=True, mix_prob=0, param_dicts=None,
+        hooks=[dict(type="CheckpointLoader"), dict(type="IterationTimer", warmup_iter=0),
+               dict(type="InformationWriter"), dict(type="CheckpointSaver", save_freq=None)],
+        train=dict(type="MultiDatasetTrainer"), model=model,
+        optimizer=dict(type="AdamW", lr=2e-4, weight_decay=0.01),
+        scheduler=dict(type="OneCycleLR", max_lr=2e-4, pct_start=0.4, anneal_strategy="cos",
+                       div_factor=10.0, final_div_factor=100.0),
+        data=dict(train=dict(type="ConcatDataset", datasets=[
+            dict(type="SyntheticLidarDataset", length=4, base_seed=300, loop=1,
+                 **gc.OUTDOOR_SCENE_KW)]))))
+    os.makedirs(tmp_path / "model", exist_ok=True)
+    launch(ddp_worker.trainer_main, num_gpus_per_machine=2, cfg=(cfg,))
+    rows = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+    assert len(rows) == 2 and all("depth_loss" in r and r["loss"] == r["loss"] for r in rows)
+    ckpt = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
+    assert "mtoken" in ckpt["state_dict"]

@@ -27,3 +27,11 @@ def test_ponder_indoor_forward_matches_reference(cpu_kernels):
     losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
     assert max(losses.values()) < 1e-4, errs
     assert max(errs.values()) < 5e-3, errs
+
+
+def test_ponder_outdoor_forward_matches_reference(cpu_kernels):
+    """PonderOutdoor-v2 (block masking with the reference's draws, fixed scene box, depth loss)."""
+    errs = gc.run_ponder_outdoor(torch.device("cpu"))
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    assert max(errs.values()) < 5e-3, errs

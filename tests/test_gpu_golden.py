@@ -86,3 +86,77 @@ def test_graphed_render_head_equals_eager(device):
         assert len(e) == len(g) > 20  # every renderer parameter (weights AND biases) is compared
         for a, b in zip(e[2:], g[2:]):
             assert (a - b).abs().max() <= 2e-4 * a.abs().max() + 1e-12
+
+
+def test_ponder_outdoor_gpu_vs_reference_golden(device):
+    """PonderOutdoor-v2 (reference ponder_outdoor_base.py run on the host with the same weights,
+    mask draws and sampler jitter): depth loss to 1e-4, gradients from the mask token to the
+    variance network."""
+    errs = gc.run_ponder_outdoor(device)
+    print(errs)
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    # probes inside / upstream of the backbone's BatchNorm chain get the conditioning bound used
+    # for the indoor model (measured here: 2-3e-3); everything downstream of the backbone
+    # (projection conv, SDF MLP, variance) is held to 1e-3 (measured: <= 2e-4)
+    deep = [errs.pop(k) for k in list(errs) if k.startswith("grad_backbone.") or k == "grad_mtoken"]
+    assert len(deep) == 3 and max(deep) < 0.2, deep
+    assert max(errs.values()) < 1e-3, errs
+
+
+def test_outdoor_graphed_render_head_equals_eager(device):
+    """Same check as the indoor one for the outdoor head (flat ray arrays with ray_offset, depth
+    loss only, 5-block 16-wide SDF MLP): graph replay == eager over three different batches; a
+    ragged batch must fall back to the per-scene path and still train."""
+    import copy
+
+    from oracle.detweights import fill_deterministic
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    cfg = gc.outdoor_model_cfg(dict(gc.SMALL_BACKBONE, in_channels=4,
+                                    channels=(16, 32, 48, 64, 64, 48, 32, 96)), **gc.OUTDOOR_SMALL)
+    cfg["renderer"] = copy.deepcopy(cfg["renderer"])
+    cfg["renderer"]["sampler"]["train_stratified"] = False
+    batches = [lidar_collate_fn([make_lidar_scene(400 + 2 * i, **gc.OUTDOOR_SCENE_KW),
+                                 make_lidar_scene(401 + 2 * i, **gc.OUTDOOR_SCENE_KW)])
+               for i in range(3)]
+    results = {}
+    for graphed in (False, True):
+        cfg["graph_render_head"] = graphed
+        model = build_model(ConfigDict(cfg))
+        fill_deterministic(model)
+        model = model.to(device).train()
+        rows = []
+        for i, b in enumerate(batches):
+            torch.manual_seed(100 + i)  # same block mask in both runs
+            b = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
+            model.zero_grad(set_to_none=True)
+            out = model(b)
+            out["loss"].backward()
+            grads = [p.grad.clone() for p in model.renderer.parameters() if p.grad is not None]
+            rows.append((float(out["loss"]), model.proj_net.conv[0].weight.grad.clone(),
+                         model.mtoken.grad.clone(), *grads))
+        if graphed:
+            assert model._graphed is not None and not model._graphed.failed, "capture was refused"
+        results[graphed] = rows
+    for e, g in zip(results[False], results[True]):
+        assert abs(e[0] - g[0]) < 1e-5 * abs(e[0])
+        assert len(e) == len(g) > 10
+        for a, b in zip([e[1]] + list(e[3:]), [g[1]] + list(g[3:])):
+            assert (a - b).abs().max() <= 2e-4 * a.abs().max() + 1e-12
+        # the mask token's gradient has crossed the whole backbone (see the conditioning note in
+        # test_spunet_gpu_vs_reference_golden); measured 8e-4
+        assert (e[2] - g[2]).abs().max() <= 2e-2 * e[2].abs().max()
+    # ragged batch: drop 5 rays of the second sweep -> per-scene rendering, no graph
+    b = dict(batches[0])
+    n = int(b["ray_offset"][-1]) - 5
+    b["ray_start"], b["ray_end"] = b["ray_start"][:n], b["ray_end"][:n]
+    b["ray_offset"] = torch.tensor([int(b["ray_offset"][0]), n])
+    b["ray_offset_host"] = [int(v) for v in b["ray_offset"]]
+    b = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
+    model.zero_grad(set_to_none=True)
+    out = model(b)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]) and torch.isfinite(model.mtoken.grad).all()

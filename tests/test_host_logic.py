@@ -108,3 +108,120 @@ def test_offset2batch():
     b = offset2batch(off)
     assert b.tolist() == [0, 0, 0, 2, 2, 2, 2]
     assert batch2offset(torch.tensor([0, 0, 1, 1, 1])).tolist() == [2, 5]
+
+
+# ------------------------------------------------------------------ outdoor (nuScenes-shaped) side
+def test_lidar_batch_contract():
+    """Keys / dtypes of the nuScenes Collect (configs/nuscenes/...-0-base.py:186-199)."""
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+
+    kw = dict(n_azimuth=200, point_nsample=24)
+    b = lidar_collate_fn([make_lidar_scene(3, **kw), make_lidar_scene(4, **kw)])
+    n, r = int(b["offset"][-1]), int(b["ray_offset"][-1])
+    assert b["coord"].shape == (n, 3) and b["coord"].dtype == torch.float32
+    assert b["grid_coord"].shape == (n, 3) and b["grid_coord"].dtype == torch.int64
+    assert b["feat"].shape == (n, 4)  # [coord, strength]
+    assert b["ray_start"].shape == (r, 3) and b["ray_end"].shape == (r, 3)
+    assert b["ray_start"].dtype == torch.float32  # ToTensor casts every float array to f32
+    assert b["offset_host"] == b["offset"].tolist() and b["ray_offset_host"] == b["ray_offset"].tolist()
+    assert r == 2 * 6 * 24 and b["condition"] == ["nuScenes", "nuScenes"]
+    # every ray ends on a voxelised lidar return and starts at one of the 6 camera centres
+    ends = {tuple(np.round(p, 4)) for p in b["ray_end"].numpy().tolist()}
+    pts = {tuple(np.round(p, 4)) for p in b["coord"].numpy().tolist()}
+    assert ends <= pts
+    assert len({tuple(np.round(p, 4)) for p in b["ray_start"].numpy().tolist()}) == 6
+    assert (b["grid_coord"].min(0).values >= 0).all()
+
+
+def test_lidar_transforms_match_reference_golden():
+    """PointRangeFilter -> GridSample(ravel) -> ProjectOnImage -> RaySample restated in
+    datasets/lidar.py reproduce what the reference's classes (transform.py:232-378) produced from
+    the same sweep and numpy seed (fixture written by oracle/make_golden.py lidar_transform_case)."""
+    from ponderv2_amd.ponder.datasets import (GridSample, PointRangeFilter, ProjectOnImage,
+                                              RaySample, make_sweep)
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lidar_transforms.npz"))
+    data = make_sweep(7, n_azimuth=200)
+    np.random.seed(7)
+    data = PointRangeFilter(point_cloud_range=(-27.0, -27.0, -5.0, 27.0, 27.0, 3.0), padding=0.1)(data)
+    data = GridSample(grid_size=0.1, hash_type="ravel", mode="train",
+                      keys=("coord", "strength", "segment"), return_grid_coord=True)(data)
+    data = ProjectOnImage(filter_overlap=True, close_radius=3.0)(data)
+    assert [int(m.sum()) for m in data["img_proj_mask"]] == g["n_proj"].tolist()
+    data = RaySample(point_nsample=24, fetch_color=False, fetch_segment=True)(data)
+    assert np.array_equal(data["grid_coord"], g["grid_coord"])
+    for k in ("ray_start", "ray_end", "ray_segment"):
+        assert np.array_equal(data[k], g[k]), k
+
+
+def test_project_on_image_keeps_nearest_point_per_pixel():
+    from ponderv2_amd.ponder.datasets import ProjectOnImage
+
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = 100.0
+    K[0, 2] = K[1, 2] = 50.0
+    img = [np.zeros((100, 100, 3))]
+    # camera looks down +z; three points on one pixel ray at depths 9, 4, 6 and one behind
+    coord = np.array([[0.0, 0.0, 9.0], [0.0, 0.0, 4.0], [0.001, 0.0, 6.0], [0.0, 0.0, -2.0],
+                      [10.0, 0.0, 5.0]], dtype=np.float32)
+    out = ProjectOnImage(filter_overlap=True, close_radius=0.0)(
+        dict(coord=coord, img=img, lidar2img=np.stack([K])))
+    # point 0 sits exactly on the sensor axis: radius 0 is not > close_radius -> dropped like 1
+    assert out["img_proj_mask"][0].tolist() == [False, False, True, False, False]
+    out = ProjectOnImage(filter_overlap=True, close_radius=-1.0)(
+        dict(coord=coord, img=img, lidar2img=np.stack([K])))
+    assert out["img_proj_mask"][0].tolist() == [False, True, False, False, False]
+
+
+def test_multi_dataset_loader_schedule():
+    """Ratio interleave + epoch length of MultiDatasetDataloader (datasets/dataloader.py:25-117)."""
+    from ponderv2_amd.ponder.datasets import ConcatDataset, MultiDatasetDataloader
+
+    class Toy(torch.utils.data.Dataset):
+        def __init__(self, tag, n, loop):
+            self.tag, self.n, self.loop = tag, n, loop
+
+        def __len__(self):
+            return self.n * self.loop
+
+        def __getitem__(self, i):
+            return self.tag
+
+        collate_fn = staticmethod(lambda items: items)
+
+    a, b = Toy("a", 5, 2), Toy("b", 3, 1)
+    cat = ConcatDataset([a, b], loop=2)
+    assert len(cat) == (10 + 3) * 2 and cat[0] == "a" and cat[10] == "b" and cat[13] == "a"
+    a, b = Toy("a", 5, 2), Toy("b", 3, 1)
+    loader = MultiDatasetDataloader(ConcatDataset([a, b], loop=2), 1, 0, seed=1)
+    tags = [batch[0] for batch in loader]
+    # main dataset: 5 samples x concat loop 2 = 10 batches; ratio 2:1 -> a a b repeated
+    assert tags == list("aab" * 5) and len(loader) == len(tags) == 15
+    assert set(len(batch) for batch in loader) == {1}
+
+
+def test_block_masking_keeps_the_reference_set():
+    """mask_blocks: per scene exactly round(n_blocks*(1-ratio)) blocks keep their features, and
+    with injected draws the kept set equals argsort(draw)[:n_keep] (ponder_outdoor_base.py:94-105)."""
+    from ponderv2_amd.ponder.models.ponder.masking import mask_blocks
+
+    g = torch.Generator().manual_seed(0)
+    grid = torch.randint(0, 64, (4000, 3), generator=g)
+    offset = torch.tensor([1500, 4000])
+    feat = torch.randn(4000, 4, generator=g)
+    token = torch.full((1, 4), 7.0, requires_grad=True)
+    batch = torch.repeat_interleave(torch.arange(2), torch.tensor([1500, 2500]))
+    block = torch.cat([batch[:, None], torch.div(grid, 8).int()], 1)
+    ublock, inv = block.unique(dim=0, return_inverse=True)
+    draws = torch.rand(len(ublock), generator=g)
+    out = mask_blocks(grid, feat, offset, 8, 0.8, token, rand=draws)
+    masked = (out == 7.0).all(1)
+    for s in range(2):
+        ids = torch.nonzero(ublock[:, 0] == s)[:, 0]
+        n_keep = round(len(ids) * (1 - 0.8))
+        kept_ref = set(ids[draws[ids].argsort()[:n_keep]].tolist())
+        kept = set(inv[(batch == s) & ~masked].unique().tolist())
+        assert kept == kept_ref
+    assert torch.equal(out[~masked], feat[~masked])
+    out.sum().backward()
+    assert torch.allclose(token.grad, torch.full((1, 4), float(masked.sum())))
