@@ -515,6 +515,58 @@ __global__ __launch_bounds__(256) void tall_gemm_nt_kernel(const float* __restri
   }
 }
 
+// C[I, J] += A[M, I]^T . B[M, J] for narrow operands (I, J <= 32): the weight gradients of the
+// 16..32-wide MLP of the outdoor SDF head, M = rays x samples ~ 1e6.  A pure streaming reduction
+// over M (algorithmic traffic M*(I+J)*4 bytes, ~10 flop/byte): no LDS staging, each wave walks a
+// contiguous run of rows and lane (i, h) feeds element i of row m+h straight from global memory
+// into the 32x32x2 MFMA (k = the row pair).  2*kSkinnyUnroll loads per lane are in flight; two
+// accumulators break the MFMA dependency chain.  The four waves of a workgroup merge through
+// LDS, then one atomic per valid element.
+constexpr int kSkinnyUnroll = 8;
+
+__global__ __launch_bounds__(256) void skinny_gemm_tn_kernel(const float* __restrict__ A, int I,
+                                                             const float* __restrict__ B, int J,
+                                                             int64_t M, int64_t rows_per_wave,
+                                                             float* __restrict__ C) {
+  __shared__ float red[4][32 * 32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  const int64_t r1 = min(M, r0 + rows_per_wave);
+  const bool va = i < I, vb = i < J;
+  const float* pa = A + i;
+  const float* pb = B + i;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  for (int64_t m = r0 + h; m < r1; m += 2 * kSkinnyUnroll) {
+    float a[kSkinnyUnroll], b[kSkinnyUnroll];
+#pragma unroll
+    for (int u = 0; u < kSkinnyUnroll; ++u) {
+      const int64_t mm = m + 2 * u;
+      const bool in = mm < r1;
+      a[u] = (va && in) ? pa[mm * I] : 0.f;
+      b[u] = (vb && in) ? pb[mm * J] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kSkinnyUnroll; u += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1], b[u + 1], acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = (r & 3) + 8 * (r >> 2) + 4 * h;  // row of C comes from the A operand
+    red[wave][n * 32 + i] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int n = e >> 5, c = e & 31;
+    if (n < I && c < J)
+      unsafeAtomicAdd(C + n * J + c, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+  }
+}
+
 template <int NB>
 int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -720,6 +772,16 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
               "pv2_gemm_tn: k1 and k2 must be positive multiples of 4");
   PV2_REQUIRE(m >= 0 && m < 0x7fffffffLL, "pv2_gemm_tn: bad row count");
   if (m == 0) return PV2_OK;
+  if (k1 <= 32 && k2 <= 32) {
+    // ~4096 waves in flight, every wave's run a whole number of unrolled row pairs
+    const int64_t quantum = 2 * kSkinnyUnroll;
+    int64_t rows = (m + 4095) / 4096;
+    rows = ((rows < 128 ? 128 : rows) + quantum - 1) / quantum * quantum;
+    const int64_t blocks = (m + 4 * rows - 1) / (4 * rows);
+    hipLaunchKernelGGL(skinny_gemm_tn_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, a, k1, b, k2, m, rows, c);
+    return pv2::check_launch("gemm_tn_skinny");
+  }
   const bool big_n = k1 > 64, big_c = k2 > 64;
   const int n_ntile = (k1 + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
   const int n_ctile = (k2 + (big_c ? 127 : 63)) / (big_c ? 128 : 64);

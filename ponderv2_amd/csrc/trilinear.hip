@@ -22,6 +22,9 @@
 // C=128) and the volume-gradient atomics are contiguous too; with the reference's NCDHW layout the
 // same kernels still work through the stride descriptor, just uncoalesced.  The three grid
 // gradients are wave-reduced with cross-lane shuffles, no LDS.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -297,6 +300,379 @@ __global__ __launch_bounds__(256) void tri_bwdbwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channels-last fp32 fast path (what the render head actually runs: NDHWC volume, (points, C)
+// outputs).  LPP lanes share one sample point, each lane owning 4 consecutive channels of every
+// LPP*4-channel panel, so a wave handles 64/LPP points at once (2 at C=128, 8 at C=32): every
+// corner read is one 16-byte load per lane, per-point geometry is computed 64/LPP times per wave
+// instead of once, and the grid-gradient reductions are log2(LPP) shuffles inside the lane group.
+// Selected by `vec_ok` below; anything else (f64, NCDHW, unaligned views) uses the generic kernels.
+// ---------------------------------------------------------------------------------------------
+struct Geom32 {
+  int off[8];
+  bool inb[8];
+};
+
+__device__ __forceinline__ void make_geom32(const Axis<float>& ax, const Axis<float>& ay,
+                                            const Axis<float>& az, const pv2_volume_desc& v,
+                                            Geom32* g) {
+  const int x0 = (int)ax.i0, y0 = (int)ay.i0, z0 = (int)az.i0;
+  const int W = (int)v.w, H = (int)v.h, D = (int)v.d;
+  const int sw = (int)v.sw, sh = (int)v.sh, sd = (int)v.sd;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ix = x0 + (c & 1), iy = y0 + ((c >> 1) & 1), iz = z0 + (c >> 2);
+    g->inb[c] = ix >= 0 && ix < W && iy >= 0 && iy < H && iz >= 0 && iz < D;
+    g->off[c] = iz * sd + iy * sh + ix * sw;
+  }
+}
+
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+#define PV2_VEC_PROLOGUE                                                                        \
+  constexpr int PPW = 64 / LPP;                                                                 \
+  const int lane = threadIdx.x & 63, sub = lane % LPP, slot = lane / LPP;                       \
+  const int64_t nw = (int64_t)gridDim.x * 4;                                                    \
+  const int c4 = (int)(v.c >> 2);                                                               \
+  for (int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW; p0 < pd.n_points;     \
+       p0 += nw * PPW) {                                                                        \
+    const bool valid = p0 + slot < pd.n_points;                                                 \
+    const int64_t pt = valid ? p0 + slot : pd.n_points - 1;                                     \
+    const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;                           \
+    const Axis<float> ax = make_axis<float>(grid[pt * 3 + 0], v.w, padding, align != 0, smooth != 0); \
+    const Axis<float> ay = make_axis<float>(grid[pt * 3 + 1], v.h, padding, align != 0, smooth != 0); \
+    const Axis<float> az = make_axis<float>(grid[pt * 3 + 2], v.d, padding, align != 0, smooth != 0); \
+    Geom32 g;                                                                                   \
+    make_geom32(ax, ay, az, v, &g);
+
+template <int LPP>
+__global__ __launch_bounds__(256) void tri_fwd_vec_kernel(const float* __restrict__ in,
+                                                          pv2_volume_desc v,
+                                                          const float* __restrict__ grid,
+                                                          pv2_points_desc pd,
+                                                          float* __restrict__ out, int padding,
+                                                          int align, int smooth) {
+  PV2_VEC_PROLOGUE
+    float w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      w[c] = ((c & 1) ? ax.w1 : ax.w0) * ((c & 2) ? ay.w1 : ay.w0) * ((c & 4) ? az.w1 : az.w0);
+    const float* base = in + n * v.sn;
+    float* obase = out + n * pd.o_sn + q * pd.o_sp;
+    for (int ch4 = sub; ch4 < c4; ch4 += LPP) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (g.inb[c]) {
+          const float4 val = *reinterpret_cast<const float4*>(base + g.off[c] + 4 * ch4);
+          acc.x += val.x * w[c];
+          acc.y += val.y * w[c];
+          acc.z += val.z * w[c];
+          acc.w += val.w * w[c];
+        }
+      }
+      if (valid) *reinterpret_cast<float4*>(obase + 4 * ch4) = acc;
+    }
+  }
+}
+
+// ATOM selects how the volume-gradient atomics are issued: 0 = not here (tri_scatter_kernel does
+// them), 1 = from the float4 lanes (each lane 4 consecutive channels, 16-byte lane stride),
+// 2 = transposed (instruction j covers the contiguous channels pb + j*LPP .. +LPP of each group).
+template <int LPP, int ATOM>
+__global__ __launch_bounds__(256) void tri_bwd_vec_kernel(
+    const float* __restrict__ gout, const float* __restrict__ in, pv2_volume_desc v,
+    const float* __restrict__ grid, pv2_points_desc pd, float* __restrict__ gin,
+    float* __restrict__ ggrid, int padding, int align, int smooth) {
+  PV2_VEC_PROLOGUE
+    float w[8], dx[8], dy[8], dz[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float wx = (c & 1) ? ax.w1 : ax.w0, sx = (c & 1) ? ax.dw : -ax.dw;
+      const float wy = (c & 2) ? ay.w1 : ay.w0, sy = (c & 2) ? ay.dw : -ay.dw;
+      const float wz = (c & 4) ? az.w1 : az.w0, sz = (c & 4) ? az.dw : -az.dw;
+      w[c] = wx * wy * wz;
+      dx[c] = sx * wy * wz;
+      dy[c] = wx * sy * wz;
+      dz[c] = wx * wy * sz;
+    }
+    const float* base = in + n * v.sn;
+    float* gbase = gin ? gin + n * v.sn : nullptr;
+    const float* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int C = (int)v.c;
+    for (int pb = 0; pb < C; pb += 4 * LPP) {  // channel panels of 4*LPP
+      const int ch4 = (pb >> 2) + sub;
+      const bool lane_on = ch4 < c4;
+      const float4 go = lane_on ? *reinterpret_cast<const float4*>(gobase + 4 * ch4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      float got[4];
+      if (ATOM == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = pb + j * LPP + sub;
+          got[j] = ch < C ? gobase[ch] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (g.inb[c]) {
+          if (lane_on) {
+            const float4 val = *reinterpret_cast<const float4*>(base + g.off[c] + 4 * ch4);
+            const float d = dot4(go, val);
+            gx += d * dx[c];
+            gy += d * dy[c];
+            gz += d * dz[c];
+          }
+          if (ATOM == 1 && gbase && valid && lane_on) {
+            float* dst = gbase + g.off[c] + 4 * ch4;
+            unsafeAtomicAdd(dst + 0, w[c] * go.x);
+            unsafeAtomicAdd(dst + 1, w[c] * go.y);
+            unsafeAtomicAdd(dst + 2, w[c] * go.z);
+            unsafeAtomicAdd(dst + 3, w[c] * go.w);
+          }
+          if (ATOM == 2 && gbase && valid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch = pb + j * LPP + sub;
+              if (ch < C) unsafeAtomicAdd(gbase + g.off[c] + ch, w[c] * got[j]);
+            }
+          }
+        }
+      }
+    }
+    gx = group_sum<LPP>(gx);
+    gy = group_sum<LPP>(gy);
+    gz = group_sum<LPP>(gz);
+    if (sub == 0 && valid) {
+      ggrid[pt * 3 + 0] = gx;
+      ggrid[pt * 3 + 1] = gy;
+      ggrid[pt * 3 + 2] = gz;
+    }
+  }
+}
+
+template <int LPP, int ATOM>
+__global__ __launch_bounds__(256) void tri_bwdbwd_vec_kernel(
+    const float* __restrict__ hV, const float* __restrict__ hG, const float* __restrict__ in,
+    pv2_volume_desc v, const float* __restrict__ grid, const float* __restrict__ gout,
+    pv2_points_desc pd, float* __restrict__ gin2, float* __restrict__ ggrid2,
+    float* __restrict__ ggout, int padding, int align, int smooth) {
+  PV2_VEC_PROLOGUE
+    const float hx = hG[pt * 3 + 0], hy = hG[pt * 3 + 1], hz = hG[pt * 3 + 2];
+    float w[8], dx[8], dy[8], dz[8], D[8], ex[8], ey[8], ez[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float sgx = (c & 1) ? 1.f : -1.f, sgy = (c & 2) ? 1.f : -1.f, sgz = (c & 4) ? 1.f : -1.f;
+      const float wx = (c & 1) ? ax.w1 : ax.w0, sx = sgx * ax.dw, cx = sgx * ax.d2w;
+      const float wy = (c & 2) ? ay.w1 : ay.w0, sy = sgy * ay.dw, cy = sgy * ay.d2w;
+      const float wz = (c & 4) ? az.w1 : az.w0, sz = sgz * az.dw, cz = sgz * az.d2w;
+      w[c] = wx * wy * wz;
+      dx[c] = sx * wy * wz;
+      dy[c] = wx * sy * wz;
+      dz[c] = wx * wy * sz;
+      D[c] = hx * dx[c] + hy * dy[c] + hz * dz[c];
+      ex[c] = hx * (cx * wy * wz) + hy * (sx * sy * wz) + hz * (sx * wy * sz);
+      ey[c] = hx * (sx * sy * wz) + hy * (wx * cy * wz) + hz * (wx * sy * sz);
+      ez[c] = hx * (sx * wy * sz) + hy * (wx * sy * sz) + hz * (wx * wy * cz);
+    }
+    const float* base = in + n * v.sn;
+    const float* hbase = hV ? hV + n * v.sn : nullptr;
+    float* gbase = gin2 ? gin2 + n * v.sn : nullptr;
+    const float* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    float* ggobase = ggout + n * pd.o_sn + q * pd.o_sp;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int C = (int)v.c;
+    for (int pb = 0; pb < C; pb += 4 * LPP) {
+      const int ch4 = (pb >> 2) + sub;
+      const bool lane_on = ch4 < c4;
+      const float4 go = lane_on ? *reinterpret_cast<const float4*>(gobase + 4 * ch4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      float got[4];
+      if (ATOM == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = pb + j * LPP + sub;
+          got[j] = ch < C ? gobase[ch] : 0.f;
+        }
+      }
+      float4 ggo = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (g.inb[c]) {
+          if (lane_on) {
+            const int o = g.off[c] + 4 * ch4;
+            const float4 val = *reinterpret_cast<const float4*>(base + o);
+            const float4 hv = hbase ? *reinterpret_cast<const float4*>(hbase + o)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            ggo.x += val.x * D[c] + hv.x * w[c];
+            ggo.y += val.y * D[c] + hv.y * w[c];
+            ggo.z += val.z * D[c] + hv.z * w[c];
+            ggo.w += val.w * D[c] + hv.w * w[c];
+            const float dv = dot4(go, val), dh = dot4(go, hv);
+            gx += dh * dx[c] + dv * ex[c];
+            gy += dh * dy[c] + dv * ey[c];
+            gz += dh * dz[c] + dv * ez[c];
+            if (ATOM == 1 && gbase && valid) {
+              float* dst = gbase + o;
+              unsafeAtomicAdd(dst + 0, go.x * D[c]);
+              unsafeAtomicAdd(dst + 1, go.y * D[c]);
+              unsafeAtomicAdd(dst + 2, go.z * D[c]);
+              unsafeAtomicAdd(dst + 3, go.w * D[c]);
+            }
+          }
+          if (ATOM == 2 && gbase && valid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch = pb + j * LPP + sub;
+              if (ch < C) unsafeAtomicAdd(gbase + g.off[c] + ch, got[j] * D[c]);
+            }
+          }
+        }
+      }
+      if (valid && lane_on) *reinterpret_cast<float4*>(ggobase + 4 * ch4) = ggo;
+    }
+    gx = group_sum<LPP>(gx);
+    gy = group_sum<LPP>(gy);
+    gz = group_sum<LPP>(gz);
+    if (sub == 0 && valid) {
+      ggrid2[pt * 3 + 0] = gx;
+      ggrid2[pt * 3 + 1] = gy;
+      ggrid2[pt * 3 + 2] = gz;
+    }
+  }
+}
+#undef PV2_VEC_PROLOGUE
+
+// Volume-gradient scatter on its own (mode 3): G consecutive lanes own one point and walk its
+// channels one per lane, so every atomic instruction covers whole contiguous channel runs.
+// coefficient per corner: w_c (first order) or D_c = sum_a hG_a d_a w_c (second order).
+template <int G, bool SECOND>
+__global__ __launch_bounds__(256) void tri_scatter_kernel(
+    const float* __restrict__ gout, pv2_volume_desc v, const float* __restrict__ grid,
+    const float* __restrict__ hG, pv2_points_desc pd, float* __restrict__ gin, int padding,
+    int align, int smooth) {
+  constexpr int PPW = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int C = (int)v.c;
+  for (int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW; p0 < pd.n_points;
+       p0 += nw * PPW) {
+    const int64_t pt = p0 + slot;
+    if (pt >= pd.n_points) continue;
+    const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
+    const Axis<float> ax = make_axis<float>(grid[pt * 3 + 0], v.w, padding, align != 0, smooth != 0);
+    const Axis<float> ay = make_axis<float>(grid[pt * 3 + 1], v.h, padding, align != 0, smooth != 0);
+    const Axis<float> az = make_axis<float>(grid[pt * 3 + 2], v.d, padding, align != 0, smooth != 0);
+    Geom32 g;
+    make_geom32(ax, ay, az, v, &g);
+    float coef[8];
+    float hx = 0.f, hy = 0.f, hz = 0.f;
+    if (SECOND) {
+      hx = hG[pt * 3 + 0];
+      hy = hG[pt * 3 + 1];
+      hz = hG[pt * 3 + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float wx = (c & 1) ? ax.w1 : ax.w0, sx = (c & 1) ? ax.dw : -ax.dw;
+      const float wy = (c & 2) ? ay.w1 : ay.w0, sy = (c & 2) ? ay.dw : -ay.dw;
+      const float wz = (c & 4) ? az.w1 : az.w0, sz = (c & 4) ? az.dw : -az.dw;
+      coef[c] = SECOND ? hx * (sx * wy * wz) + hy * (wx * sy * wz) + hz * (wx * wy * sz)
+                       : wx * wy * wz;
+    }
+    float* gbase = gin + n * v.sn;
+    const float* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    for (int ch = sub; ch < C; ch += G) {
+      const float go = gobase[ch];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (g.inb[c]) unsafeAtomicAdd(gbase + g.off[c] + ch, coef[c] * go);
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// lanes per point for the vector path, 0 if the layout does not qualify
+inline int vec_lanes(const pv2_volume_desc& v, const pv2_points_desc& pd, const void* vol_ptr,
+                     const void* pts_ptr, const void* extra0, const void* extra1) {
+  const bool ok = v.sc == 1 && pd.o_sc == 1 && (v.c % 4) == 0 && (v.sn % 4) == 0 &&
+                  (v.sd % 4) == 0 && (v.sh % 4) == 0 && (v.sw % 4) == 0 && (pd.o_sn % 4) == 0 &&
+                  (pd.o_sp % 4) == 0 && v.sn < 0x7fffffffLL && aligned16(vol_ptr) &&
+                  aligned16(pts_ptr) && aligned16(extra0) && aligned16(extra1);
+  if (!ok) return 0;
+  const int64_t c4 = v.c / 4;
+  return c4 <= 8 ? 8 : c4 <= 16 ? 16 : c4 <= 32 ? 32 : 64;
+}
+
+// How the volume-gradient atomics are issued, measured on MI355X (tools/bench_sampler.py,
+// profiles/r01_sampler_modes.txt): their cost follows the number of separate contiguous runs an
+// atomic instruction touches, so every lane group should cover >= 128 contiguous bytes.
+//   1  from the float4 lanes (16-byte lane stride)        - 2-3x slower, kept for the comparison
+//   2  transposed inside the vector kernel (runs of LPP*4 bytes per group): best when LPP >= 32
+//   3  separate tri_scatter_kernel with 32/64 lanes per point: best for narrow volumes (C <= 64)
+// Default (4) picks 2 or 3 by LPP.  PV2_TRI_MODE=0..3 forces one (0 = generic kernels only).
+inline int tri_mode() {
+  static const int m = [] {
+    const char* e = getenv("PV2_TRI_MODE");
+    return (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 4;
+  }();
+  return m;
+}
+inline int atomics_mode(int lpp) { return tri_mode() == 4 ? (lpp >= 32 ? 2 : 3) : tri_mode(); }
+
+inline int vec_grid(int64_t n_points, int lpp) {
+  const int64_t waves = (n_points + (64 / lpp) - 1) / (64 / lpp);
+  return pv2::grid_for(waves * 64, 256);
+}
+
+#define PV2_VEC_DISPATCH(LPP_VALUE, KERNEL, ...)                                                 \
+  switch (LPP_VALUE) {                                                                           \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                                 \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                               \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                               \
+    default: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                               \
+  }
+#define PV2_VEC_DISPATCH_ATOM(LPP_VALUE, ATOM_VALUE, KERNEL, ...)                                \
+  switch ((LPP_VALUE) * 4 + (ATOM_VALUE)) {                                                      \
+    case 8 * 4 + 0: hipLaunchKernelGGL((KERNEL<8, 0>), __VA_ARGS__); break;                      \
+    case 8 * 4 + 1: hipLaunchKernelGGL((KERNEL<8, 1>), __VA_ARGS__); break;                      \
+    case 8 * 4 + 2: hipLaunchKernelGGL((KERNEL<8, 2>), __VA_ARGS__); break;                      \
+    case 16 * 4 + 0: hipLaunchKernelGGL((KERNEL<16, 0>), __VA_ARGS__); break;                    \
+    case 16 * 4 + 1: hipLaunchKernelGGL((KERNEL<16, 1>), __VA_ARGS__); break;                    \
+    case 16 * 4 + 2: hipLaunchKernelGGL((KERNEL<16, 2>), __VA_ARGS__); break;                    \
+    case 32 * 4 + 0: hipLaunchKernelGGL((KERNEL<32, 0>), __VA_ARGS__); break;                    \
+    case 32 * 4 + 1: hipLaunchKernelGGL((KERNEL<32, 1>), __VA_ARGS__); break;                    \
+    case 32 * 4 + 2: hipLaunchKernelGGL((KERNEL<32, 2>), __VA_ARGS__); break;                    \
+    case 64 * 4 + 0: hipLaunchKernelGGL((KERNEL<64, 0>), __VA_ARGS__); break;                    \
+    case 64 * 4 + 1: hipLaunchKernelGGL((KERNEL<64, 1>), __VA_ARGS__); break;                    \
+    default: hipLaunchKernelGGL((KERNEL<64, 2>), __VA_ARGS__); break;                            \
+  }
+
+// volume-gradient scatter as its own launch; G = lanes per point
+template <bool SECOND>
+void launch_scatter(const float* gout, const pv2_volume_desc& v, const float* grid,
+                    const float* hG, const pv2_points_desc& pd, float* gin, int padding, int align,
+                    int smooth, hipStream_t s) {
+  if (v.c <= 32) {
+    hipLaunchKernelGGL((tri_scatter_kernel<32, SECOND>), dim3(vec_grid(pd.n_points, 32)),
+                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth);
+  } else {
+    hipLaunchKernelGGL((tri_scatter_kernel<64, SECOND>), dim3(vec_grid(pd.n_points, 64)),
+                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth);
+  }
+}
+
 int check_desc(const pv2_volume_desc* vol, const pv2_points_desc* pts) {
   PV2_REQUIRE(vol != nullptr && pts != nullptr, "trilinear: null descriptor");
   PV2_REQUIRE(vol->c >= 1 && vol->d >= 1 && vol->h >= 1 && vol->w >= 1, "trilinear: empty volume");
@@ -310,6 +686,13 @@ int run_fwd(const T* input, const pv2_volume_desc* vol, const T* grid, const pv2
   if (int e = check_desc(vol, pts)) return e;
   PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
   if (pts->n_points == 0) return PV2_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    if (const int lpp = tri_mode() ? vec_lanes(*vol, *pts, input, output, nullptr, nullptr) : 0) {
+      PV2_VEC_DISPATCH(lpp, tri_fwd_vec_kernel, dim3(vec_grid(pts->n_points, lpp)), dim3(256), 0,
+                       (hipStream_t)stream, input, *vol, grid, *pts, output, padding, align, smooth)
+      return pv2::check_launch("trilinear_forward");
+    }
+  }
   hipLaunchKernelGGL((tri_fwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)), dim3(256),
                      0, (hipStream_t)stream, input, *vol, grid, *pts, output, padding, align,
                      smooth);
@@ -323,6 +706,19 @@ int run_bwd(const T* gout, const T* input, const pv2_volume_desc* vol, const T* 
   if (int e = check_desc(vol, pts)) return e;
   PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
   if (pts->n_points == 0) return PV2_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    if (const int lpp = tri_mode() ? vec_lanes(*vol, *pts, input, gout, gin, nullptr) : 0) {
+      const int mode = atomics_mode(lpp);
+      const int atom = (gin == nullptr || mode == 3) ? 0 : mode;
+      PV2_VEC_DISPATCH_ATOM(lpp, atom, tri_bwd_vec_kernel, dim3(vec_grid(pts->n_points, lpp)),
+                            dim3(256), 0, (hipStream_t)stream, gout, input, *vol, grid, *pts, gin,
+                            ggrid, padding, align, smooth)
+      if (gin != nullptr && mode == 3)
+        launch_scatter<false>(gout, *vol, grid, nullptr, *pts, gin, padding, align, smooth,
+                              (hipStream_t)stream);
+      return pv2::check_launch("trilinear_backward");
+    }
+  }
   hipLaunchKernelGGL((tri_bwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)), dim3(256),
                      0, (hipStream_t)stream, gout, input, *vol, grid, *pts, gin, ggrid, padding,
                      align, smooth);
@@ -336,6 +732,22 @@ int run_bwdbwd(const T* hV, const T* hG, const T* input, const pv2_volume_desc* 
   if (int e = check_desc(vol, pts)) return e;
   PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
   if (pts->n_points == 0) return PV2_OK;
+  if constexpr (std::is_same<T, float>::value) {
+    if (const int lpp = tri_mode() ? vec_lanes(*vol, *pts, input, gout, hV, gin2) : 0) {
+      if (aligned16(ggout)) {
+        const int mode = atomics_mode(lpp);
+        const int atom = (gin2 == nullptr || mode == 3) ? 0 : mode;
+        PV2_VEC_DISPATCH_ATOM(lpp, atom, tri_bwdbwd_vec_kernel,
+                              dim3(vec_grid(pts->n_points, lpp)), dim3(256), 0,
+                              (hipStream_t)stream, hV, hG, input, *vol, grid, gout, *pts, gin2,
+                              ggrid2, ggout, padding, align, smooth)
+        if (gin2 != nullptr && mode == 3)
+          launch_scatter<true>(gout, *vol, grid, hG, *pts, gin2, padding, align, smooth,
+                               (hipStream_t)stream);
+        return pv2::check_launch("trilinear_backward_backward");
+      }
+    }
+  }
   hipLaunchKernelGGL((tri_bwdbwd_kernel<T>), dim3(pv2::grid_for(pts->n_points * 64, 256)),
                      dim3(256), 0, (hipStream_t)stream, hV, hG, input, *vol, grid, gout, *pts,
                      gin2, ggrid2, ggout, padding, align, smooth);

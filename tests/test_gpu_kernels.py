@@ -159,7 +159,7 @@ def test_spconv_wgrad_chunk_sizes(device, tile, c_in, c_out):
 
 # ------------------------------------------------------------------ MLP-head GEMMs
 @pytest.mark.parametrize("k,n", [(64, 128), (128, 128), (128, 65), (134, 128), (131, 128), (128, 3),
-                                 (3, 128), (128, 512)])
+                                 (3, 128), (128, 512), (32, 16), (16, 16), (16, 17), (35, 16)])
 def test_mfma_linear_matches_torch_to_second_order(device, k, n):
     """ponderv2_amd.linear.linear == F.linear (fp64 reference) for value, first-order gradients and
     a second-order term (gradient of a function of d(out)/d(x)), incl. the zero-padded odd sizes."""
@@ -184,6 +184,21 @@ def test_mfma_linear_matches_torch_to_second_order(device, k, n):
     for name, a, r in zip(("y", "dx", "g_x", "g_w", "g_b"), got, ref):
         err = (a.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
         assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize("m", [1, 2, 31, 4097, 300001])
+@pytest.mark.parametrize("i,j", [(16, 16), (32, 16), (20, 32), (4, 8), (32, 32)])
+def test_skinny_gemm_tn(device, m, i, j):
+    """A^T B for narrow operands (the streaming-reduction kernel): odd row counts, one-row inputs,
+    runs that end inside an unrolled group."""
+    from ponderv2_amd.linear import reduce_gemm_tn
+
+    torch.manual_seed(m + i + j)
+    a, b = torch.randn(m, i), torch.randn(m, j)
+    ref = a.double().t() @ b.double()
+    got = reduce_gemm_tn(a.to(device), b.to(device)).double().cpu()
+    scale = (a.double().abs().t() @ b.double().abs()).max().item()
+    assert (got - ref).abs().max().item() < 2e-6 * scale + 1e-12
 
 
 # ------------------------------------------------------------------ fused BatchNorm (+add+ReLU)
@@ -301,24 +316,35 @@ def test_sampler_gradcheck_fp64(device, padding_mode, align_corners, smooth):
     torch.autograd.gradgradcheck(fn, [inp, grid], eps=1e-4, atol=1e-3, rtol=1e-2, nondet_tol=1e-9)
 
 
-@pytest.mark.parametrize("channels_last", [True, False])
-def test_sampler_second_order_vs_oracle_f32(device, channels_last):
-    """fp32, hot-path configuration (zeros / align_corners / no smoothstep), C=128, both layouts;
-    a scalar loss that uses d(out)/d(grid) exercises backward-of-backward like the eikonal term."""
+@pytest.mark.parametrize("C,B,channels_last,padding_mode,smooth", [
+    (128, 1, True, "zeros", False), (128, 1, False, "zeros", False),   # indoor head, both layouts
+    (32, 2, True, "zeros", False),     # outdoor head: 8 points per wave, batched volume
+    (96, 1, True, "zeros", False),     # 24 float4 per point on 32 lanes (idle lanes)
+    (20, 2, True, "zeros", False),     # 5 float4 on 8 lanes
+    (256, 1, True, "zeros", False),    # one full wave per point
+    (512, 1, True, "zeros", False),    # two channel panels per lane
+    (64, 2, True, "border", True), (64, 1, True, "reflection", True),
+    (30, 1, True, "zeros", False),     # C % 4 != 0: generic kernels on a channels-last volume
+])
+def test_sampler_second_order_vs_oracle_f32(device, C, B, channels_last, padding_mode, smooth):
+    """fp32 against the float64 oracle, up to a loss that uses d(out)/d(grid) (backward-of-backward,
+    like the eikonal term).  Channels-last volumes with C % 4 == 0 run the vectorised lane-group
+    kernels (csrc/trilinear.hip), the rest the generic one-wave-per-point kernels; 407 points per
+    volume leave the last wave partially filled."""
     from oracle.sampler import SmoothSampler as OSampler
     from ponderv2_amd.smooth_sampler import SmoothSampler
 
-    torch.manual_seed(5)
-    C, D, H, W, R, S = 128, 6, 9, 10, 37, 11
-    vol = torch.randn(1, C, D, H, W)
-    grid = away_from_kinks(torch.rand(1, 1, R, S, 3) * 2.3 - 1.15, (W, H, D), True)
-    proj = torch.randn(C)
+    torch.manual_seed(5 + C)
+    D, H, W, R, S = 6, 9, 10, 37, 11
+    vol = torch.randn(B, C, D, H, W)
+    grid = away_from_kinks(torch.rand(B, 1, R, S, 3) * 2.3 - 1.15, (W, H, D), True)
+    proj = torch.randn(C) / C ** 0.5
 
     def run(sampler, vol_t, grid_t):
         vol_t = vol_t.requires_grad_(True)
         grid_t = grid_t.requires_grad_(True)
-        out = sampler.apply(vol_t, grid_t, "zeros", True, False)
-        feat = out.squeeze(0).squeeze(1).permute(1, 2, 0)  # (R,S,C)
+        out = sampler.apply(vol_t, grid_t, padding_mode, True, smooth)
+        feat = out.squeeze(2).permute(0, 2, 3, 1)  # (B,R,S,C)
         sdf = torch.tanh(feat @ proj.to(feat))
         (gp,) = torch.autograd.grad(sdf.sum(), grid_t, create_graph=True)
         loss = ((gp.norm(dim=-1) - 1) ** 2).mean() + (feat ** 2).mean() + sdf.mean()
