@@ -56,9 +56,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="indoor", choices=["indoor", "outdoor"],
+    ap.add_argument("--workload", default="indoor", choices=["indoor", "outdoor", "ppt"],
                     help="indoor = BASELINE configs[1] (the headline metric); outdoor = the "
-                         "PonderOutdoor-v2 / nuScenes-shaped step of configs[4] on this GPU's shard")
+                         "PonderOutdoor-v2 / nuScenes-shaped step of configs[4] on this GPU's shard; "
+                         "ppt = configs[3]: multi-dataset indoor pre-training (SpUNet-v1m3 PDNorm, "
+                         "batches alternate Structured3D/ScanNet/S3DIS conditions 4:2:1)")
     ap.add_argument("--scenes-per-gpu", type=int, default=None,
                     help="default 2 (indoor, configs[1]) / 4 (outdoor, the reference's per-GPU batch)")
     ap.add_argument("--rays-per-camera", type=int, default=512, help="outdoor: RaySample.point_nsample")
@@ -76,7 +78,7 @@ def parse():
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     args = ap.parse_args()
     if args.scenes_per_gpu is None:
-        args.scenes_per_gpu = 2 if args.workload == "indoor" else 4
+        args.scenes_per_gpu = 4 if args.workload == "outdoor" else 2
     return args
 
 
@@ -88,6 +90,36 @@ def model_cfg(rays_per_view, dense_dtype="float32"):
     cfg = gc.indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
     cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
     return cfg
+
+
+PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
+PPT_VALID = (tuple(range(25)), tuple(range(20)), tuple(range(13)))  # class counts of the reference
+PPT_SCHEDULE = (0, 0, 0, 0, 1, 1, 2)                                 # sampling ratio 4:2:1
+
+
+def ppt_model_cfg(rays_per_view, dense_dtype="float32"):
+    """configs/scannet/pretrain-ponder-ppt-v1m1-0-sc-s3-st-spunet.py:22-228, restated."""
+    cfg = model_cfg(rays_per_view, dense_dtype)
+    cfg["backbone"] = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_channels=32,
+                           context_channels=256, channels=(32, 64, 128, 256, 256, 128, 96, 96),
+                           layers=(2, 3, 4, 6, 2, 2, 2, 2), cls_mode=False,
+                           conditions=("ScanNet", "S3DIS", "Structured3D"), zero_init=False,
+                           norm_decouple=True, norm_adaptive=True, norm_affine=True)
+    names = tuple(f"class {i}" for i in range(36))
+    cfg.update(conditions=PPT_CONDITIONS, class_name=names, valid_index=PPT_VALID)
+    return cfg
+
+
+def make_ppt_batches(rank, scenes, views, device):
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    out = []
+    for k, cond in enumerate(PPT_CONDITIONS):
+        samples = [make_scene(1000 * rank + 100 * k + i, num_views=views, image_hw=(480, 640),
+                              condition=cond, num_classes=len(PPT_VALID[k])) for i in range(scenes)]
+        batch = collate_fn(samples)
+        out.append({k2: (v.to(device) if torch.is_tensor(v) else v) for k2, v in batch.items()})
+    return out
 
 
 def outdoor_model_cfg(dense_dtype="float32"):
@@ -278,8 +310,13 @@ def main():
     # find-db shipped in miopen_cache/ (written by an earlier search on this GPU / MIOpen version)
     torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
     outdoor = args.workload == "outdoor"
-    cfg = outdoor_model_cfg(args.dense_dtype) if outdoor else model_cfg(args.rays_per_view,
-                                                                          args.dense_dtype)
+    ppt = args.workload == "ppt"
+    if outdoor:
+        cfg = outdoor_model_cfg(args.dense_dtype)
+    elif ppt:
+        cfg = ppt_model_cfg(args.rays_per_view, args.dense_dtype)
+    else:
+        cfg = model_cfg(args.rays_per_view, args.dense_dtype)
     cfg["graph_render_head"] = not args.no_graph
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
@@ -295,9 +332,14 @@ def main():
                               nesterov=True)
         batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
     n_vox = int(batch["offset"][-1])
+    batches, counter = [batch], [0]
+    if ppt:  # one resident batch per condition, visited in the loader's 4:2:1 order
+        per_cond = make_ppt_batches(rank, args.scenes_per_gpu, args.views, device)
+        batches = [per_cond[k] for k in PPT_SCHEDULE]
 
     def step():
-        out = step_model(clone_batch(batch))
+        out = step_model(clone_batch(batches[counter[0] % len(batches)]))
+        counter[0] += 1
         opt.zero_grad(set_to_none=True)
         out["loss"].backward()
         opt.step()
@@ -353,6 +395,8 @@ def main():
         result = {
             "metric": ("pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 nuScenes-shaped"
                        if outdoor else
+                       "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m3 PDNorm multi-dataset"
+                       if ppt else
                        "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 ScanNet-shaped"),
             "value": value, "unit": "scenes/s", "rays_per_s": value * rays_per_scene,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,6 +411,11 @@ def main():
             "config": {"workload": (("configs[4]: PonderV2-outdoor nuScenes pretrain, SpUNet-v1m1, "
                                      f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene:.0f} rays/scene"
                                      " (6 cameras), mask 0.8, train step fwd+bwd+AdamW") if outdoor
+                                    else
+                                    ("configs[3]: multi-dataset indoor pretrain (Structured3D/ScanNet/"
+                                     "S3DIS conditions 4:2:1), SpUNet-v1m3 PDNorm, "
+                                     f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
+                                     "train step fwd+bwd+SGD") if ppt
                                     else
                                     ("configs[1]: PonderV2-indoor ScanNet pretrain, SpUNet-v1m1, "
                                      f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
@@ -400,7 +449,7 @@ def main():
                                   for k, v in r.items()} for r in kernels]
             result["handwritten_kernel_ms_per_step"] = sum(r["total_ms"] for r in kernels) / args.steps
             result["ms_per_step_with_event_instrumentation"] = 1e3 * elapsed_instr / args.steps
-        if world == 1 and not args.no_cpu_baseline and not outdoor:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "indoor":
             result["cpu_baseline"] = cpu_baseline(args)
     if world > 1:
         dist.barrier()

@@ -253,6 +253,46 @@ def ponder_outdoor_case(ConfigDict):
           "rays", batch["ray_offset"].tolist(), "voxels", batch["offset"].tolist())
 
 
+PDNORM_BACKBONE = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_channels=16,
+                       context_channels=32, channels=(16, 32, 48, 64, 64, 48, 32, 32),
+                       layers=(1, 1, 1, 1, 1, 1, 1, 1), conditions=("ScanNet", "S3DIS", "Structured3D"),
+                       zero_init=False, norm_decouple=True, norm_adaptive=True, norm_affine=True)
+
+
+def spunet_pdnorm_case():
+    """Reference SpUNet-v1m3 (spconv_unet_v1m3_pdnorm.py:236-427: per-condition BatchNorm +
+    context modulation) on the oracle sparse-conv runtime, float64, condition "S3DIS"."""
+    from helpers import random_voxels
+    from ponder.models.builder import MODELS
+
+    coords = random_voxels(33, batch=2, extent=(48, 40, 24), n_per_batch=900)
+    counts = np.bincount(coords[:, 0])
+    n = len(coords)
+    feat = formula_tensor("pdnorm.feat", (n, 6), 1.0).double().requires_grad_(True)
+    context = formula_tensor("pdnorm.context", (1, 32), 1.0).double().requires_grad_(True)
+    model = MODELS.build(dict(PDNORM_BACKBONE)).double()
+    fill_deterministic(model)
+    model.train()
+    out = model(dict(grid_coord=torch.from_numpy(coords[:, 1:].astype(np.int64)), feat=feat,
+                     offset=torch.from_numpy(np.cumsum(counts)).long(), condition=["S3DIS"],
+                     context=context))
+    probe = formula_tensor("pdnorm.probe", tuple(out.shape), 1.0).double()
+    (out * probe).sum().backward()
+    params = dict(model.named_parameters())
+    names = ["conv_input.conv.weight", "conv_input.bn.bns.1.weight",
+             "conv_input.bn.modulation.1.weight", "enc.1.block0.bn1.modulation.1.bias",
+             "down.2.bn.bns.1.bias", "dec.0.block0.proj_norm.modulation.1.weight",
+             "dec.3.block0.bn2.bns.1.weight", "up.1.conv.weight"]
+    unused = [k for k, p in params.items() if ".bns.0." in k or ".bns.2." in k]
+    assert unused and all(params[k].grad is None for k in unused)  # other datasets' BN untouched
+    np.savez_compressed(
+        os.path.join(GOLDEN, "spunet_pdnorm_small.npz"), coords=coords, out=out.detach().numpy(),
+        dfeat=feat.grad.numpy(), dcontext=context.grad.numpy(), grad_names=np.array(names),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)})
+    print("spunet_pdnorm_small: out", tuple(out.shape), "mean |out|", out.abs().mean().item(),
+          "|dcontext|", context.grad.abs().max().item())
+
+
 def main():
     ref_shims.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -260,7 +300,7 @@ def main():
 
     only = sys.argv[1:]
     cases = dict(spunet=spunet_case, neus=lambda: neus_case_impl(ConfigDict),
-                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case,
+                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case,
                  outdoor=lambda: ponder_outdoor_case(ConfigDict))
     for name, fn in cases.items():
         if not only or name in only:

@@ -11,6 +11,8 @@
 // Layout trick: a 256-thread block views consecutive rows as one flat run of floats; thread t
 // always sees column t % C (C <= 256) so every load is fully coalesced and the per-column partial
 // sums stay in registers until one LDS pass and one double-precision atomic per column per block.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -155,13 +157,22 @@ __global__ __launch_bounds__(kThreads) void col_sum_kernel(const float* __restri
   }
 }
 
+inline int64_t max_reduce_blocks() {
+  static const int64_t v = [] {
+    const char* e = getenv("PV2_BN_MAXBLOCKS");  // tuning knob (tools/bench_rownorm.py)
+    const long x = e ? atol(e) : 0;
+    return (int64_t)(x > 0 ? x : 1024);  // measured best of 128..2048, profiles/r01_bn_block_cap.txt
+  }();
+  return v;
+}
+
 inline void reduce_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block) {
   // enough blocks to cover the 256 CUs several times over (these matrices are only a few MB, the
   // reduction is latency-bound), at least 8 row-iterations per block
   const int rpi = c >= kThreads ? 1 : kThreads / c;
   int64_t want = (n + (int64_t)rpi * 8 - 1) / ((int64_t)rpi * 8);
   if (want < 1) want = 1;
-  if (want > 2048) want = 2048;
+  if (want > max_reduce_blocks()) want = max_reduce_blocks();
   *blocks = (int)want;
   *rows_per_block = (n + want - 1) / want;
 }

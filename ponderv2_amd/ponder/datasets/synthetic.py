@@ -97,7 +97,7 @@ def _look_at(eye, target):
 
 
 def make_scene(seed, n_raw=120000, keep=0.2, grid_size=0.02, num_views=2, image_hw=(480, 640),
-               n_voxels=None):
+               n_voxels=None, condition="ScanNet", num_classes=20):
     """One synthetic scene as numpy arrays (the per-sample dict a Dataset would return)."""
     rng = np.random.default_rng(seed)
     boxes = _boxes(rng)
@@ -109,7 +109,7 @@ def make_scene(seed, n_raw=120000, keep=0.2, grid_size=0.02, num_views=2, image_
     data = dict(coord=pts[sel].astype(np.float32),
                 color=np.clip(plane_rgb[pid[sel]] + rng.uniform(-20, 20, (len(sel), 3)), 0, 255)
                 .astype(np.float32),
-                normal=nrm[sel].astype(np.float32), segment=(pid[sel] % 20).astype(np.int64))
+                normal=nrm[sel].astype(np.float32), segment=(pid[sel] % num_classes).astype(np.int64))
     state = np.random.get_state()
     np.random.seed(seed)  # GridSample draws from numpy's global generator, as the reference does
     data = GridSample(grid_size=grid_size, hash_type="fnv", mode="train",
@@ -141,11 +141,11 @@ def make_scene(seed, n_raw=120000, keep=0.2, grid_size=0.02, num_views=2, image_
         col = np.clip(col + rng.uniform(-0.05, 0.05, col.shape), 0, 1)
         rgb.append(col.reshape(H, W, 3).astype(np.float32))
         depth.append(z_mm.reshape(H, W).astype(np.float32))
-        sem.append(np.where(p >= 0, p % 20, -1).reshape(H, W).astype(np.int64))
+        sem.append(np.where(p >= 0, p % num_classes, -1).reshape(H, W).astype(np.int64))
         extr.append(E.astype(np.float32))
     data.update(rgb=np.stack(rgb), depth=np.stack(depth), semantic=np.stack(sem),
                 extrinsic=np.stack(extr), intrinsic=np.stack([K.astype(np.float32)] * num_views),
-                depth_scale=np.float32(1.0 / 1000.0), condition="ScanNet")
+                depth_scale=np.float32(1.0 / 1000.0), condition=condition)
     return data
 
 
@@ -171,10 +171,12 @@ class SyntheticRGBDDataset(torch.utils.data.Dataset):
     collate_fn = staticmethod(collate_fn)
 
     def __init__(self, length=64, base_seed=0, num_views=2, image_hw=(480, 640), n_raw=120000,
-                 keep=0.2, grid_size=0.02, n_voxels=None, loop=1, **kwargs):
+                 keep=0.2, grid_size=0.02, n_voxels=None, loop=1, condition="ScanNet",
+                 num_classes=20, **kwargs):
         self.length, self.base_seed, self.loop = length, base_seed, loop
         self.kw = dict(num_views=num_views, image_hw=tuple(image_hw), n_raw=n_raw, keep=keep,
-                       grid_size=grid_size, n_voxels=n_voxels)
+                       grid_size=grid_size, n_voxels=n_voxels, condition=condition,
+                       num_classes=num_classes)
 
     def __len__(self):
         return self.length * self.loop

@@ -50,11 +50,21 @@ class _FusedBNFunction(torch.autograd.Function):
         return dx, dweight, dbias, dres, None, None, None, None, None
 
 
-def fused_bn(bn, x, residual=None, relu=False):
-    """[relu](bn(x) [+ residual]) with ``bn`` an nn.BatchNorm1d."""
-    use_kernel = (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() == 2
-                  and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled())
-    if not use_kernel:
+def can_fuse(bn, x):
+    """True when the rownorm.hip kernels cover this call (training-mode fp32 device matrix)."""
+    return (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() == 2
+            and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled())
+
+
+def fused_bn(bn, x, residual=None, relu=False, weight=None, bias=None):
+    """[relu](bn(x) [+ residual]) with ``bn`` an nn.BatchNorm1d.
+
+    ``weight`` / ``bias`` (C,) replace the module's affine pair in the kernel epilogue: prompt-driven
+    normalisation folds its per-condition modulation ``y * (1 + scale) + shift`` into them
+    (spconv_unet_v1m3_pdnorm.py), gradients flow back to whatever produced them.  Callers that
+    pass them must check ``can_fuse`` first - the module fallback only knows its own parameters."""
+    if not can_fuse(bn, x):
+        assert weight is None and bias is None, "affine overrides need the kernel path (can_fuse)"
         y = bn(x)
         if residual is not None:
             y = y + residual
@@ -63,7 +73,9 @@ def fused_bn(bn, x, residual=None, relu=False):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _FusedBNFunction.apply(x, bn.weight, bn.bias, residual, rm, rv, relu, bn.eps, bn.momentum)
+    w = bn.weight if weight is None else weight.contiguous()
+    b = bn.bias if bias is None else bias.contiguous()
+    return _FusedBNFunction.apply(x, w, b, residual, rm, rv, relu, bn.eps, bn.momentum)
 
 
 class _ColSum(torch.autograd.Function):

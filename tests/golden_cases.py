@@ -241,3 +241,41 @@ def run_ponder_outdoor(device):
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
     return errs
+
+
+PDNORM_BACKBONE = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_channels=16,
+                       context_channels=32, channels=(16, 32, 48, 64, 64, 48, 32, 32),
+                       layers=(1, 1, 1, 1, 1, 1, 1, 1), conditions=("ScanNet", "S3DIS", "Structured3D"),
+                       zero_init=False, norm_decouple=True, norm_adaptive=True, norm_affine=True)
+
+
+def run_spunet_pdnorm(device, dtype):
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "spunet_pdnorm_small.npz"))
+    coords = g["coords"]
+    counts = np.bincount(coords[:, 0])
+    model = build_model(ConfigDict(PDNORM_BACKBONE)).to(dtype)
+    fill_deterministic(model)
+    model = model.to(device).train()
+    n = len(coords)
+    feat = formula_tensor("pdnorm.feat", (n, 6), 1.0).to(dtype).to(device).requires_grad_(True)
+    context = formula_tensor("pdnorm.context", (1, 32), 1.0).to(dtype).to(device).requires_grad_(True)
+    out = model(dict(grid_coord=torch.from_numpy(coords[:, 1:].astype(np.int64)).to(device),
+                     feat=feat, offset=torch.from_numpy(np.cumsum(counts)).long().to(device),
+                     condition=["S3DIS"], context=context))
+    probe = formula_tensor("pdnorm.probe", tuple(out.shape), 1.0).to(dtype).to(device)
+    (out * probe).sum().backward()
+    params = dict(model.named_parameters())
+    errs = {"out": rel_err(out, g["out"]), "dfeat": rel_err(feat.grad, g["dfeat"]),
+            "dcontext": rel_err(context.grad, g["dcontext"])}
+    cos = {"dfeat": cos_err(feat.grad, g["dfeat"]), "dcontext": cos_err(context.grad, g["dcontext"])}
+    for i, name in enumerate(g["grad_names"]):
+        errs[str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+        cos[str(name)] = cos_err(params[str(name)].grad, g[f"grad_{i}"])
+    untouched = [k for k, p in params.items() if ".bns.0." in k or ".bns.2." in k]
+    assert untouched and all(params[k].grad is None for k in untouched)
+    if dtype == torch.float64:
+        return errs
+    return errs, cos

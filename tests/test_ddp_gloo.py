@@ -82,3 +82,45 @@ def test_multi_dataset_trainer_outdoor_two_ranks(tmp_path):
     assert len(rows) == 2 and all("depth_loss" in r and r["loss"] == r["loss"] for r in rows)
     ckpt = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
     assert "mtoken" in ckpt["state_dict"]
+
+
+@pytest.mark.timeout(900)
+def test_multi_dataset_trainer_ppt_two_ranks(tmp_path):
+    """BASELINE config 4 in miniature: PonderIndoor-v2 over SpUNet-v1m3 (PDNorm), two synthetic
+    "datasets" with sampling ratio 2:1; every batch carries one condition, both ranks walk the
+    same schedule (the sets of unused parameters differ per condition)."""
+    import golden_cases as gc
+    from ponderv2_amd.ponder.engines import launch
+    from ponderv2_amd.ponder.utils.config import Config
+
+    model = gc.indoor_model_cfg(dict(gc.PDNORM_BACKBONE, context_channels=256,
+                                     channels=(16, 32, 48, 64, 64, 48, 32, 96),
+                                     conditions=("ScanNet", "S3DIS", "Structured3D")),
+                                grid_shape=(32, 32, 8), ray_nsample=6)
+    model.update(conditions=("Structured3D", "ScanNet"),
+                 valid_index=(tuple(range(0, 13)), tuple(range(5, 20))))
+    scene = dict(type="SyntheticRGBDDataset", num_views=2, image_hw=(24, 32), n_raw=5000)
+    cfg = Config(dict(
+        weight=None, resume=False, evaluate=False, seed=11, save_path=str(tmp_path), num_worker=0,
+        batch_size=2, epoch=1, eval_epoch=1, sync_bn=False, enable_amp=False, empty_cache=False,
+        find_unused_parameters=True, mix_prob=0, param_dicts=None,
+        hooks=[dict(type="CheckpointLoader"), dict(type="IterationTimer", warmup_iter=0),
+               dict(type="InformationWriter"), dict(type="CheckpointSaver", save_freq=None)],
+        train=dict(type="MultiDatasetTrainer"), model=model,
+        optimizer=dict(type="SGD", lr=1e-4, momentum=0.9, weight_decay=1e-4, nesterov=True),
+        scheduler=dict(type="OneCycleLR", max_lr=1e-4, pct_start=0.05, anneal_strategy="cos",
+                       div_factor=10.0, final_div_factor=10000.0),
+        data=dict(train=dict(type="ConcatDataset", loop=1, datasets=[
+            dict(scene, length=4, base_seed=500, condition="Structured3D", num_classes=13, loop=2),
+            dict(scene, length=2, base_seed=600, condition="ScanNet", num_classes=15, loop=1)]))))
+    os.makedirs(tmp_path / "model", exist_ok=True)
+    launch(ddp_worker.trainer_main, num_gpus_per_machine=2, cfg=(cfg,))
+    rows = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+    assert len(rows) == 3 and all(r["loss"] == r["loss"] for r in rows)  # schedule: S3D S3D ScanNet
+    ckpt = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
+    sd = ckpt["state_dict"]
+    assert "backbone.conv_input.bn.bns.2.running_mean" in sd
+    # per-condition statistics: Structured3D (index 2) and ScanNet (0) were updated, S3DIS (1) never
+    assert sd["backbone.conv_input.bn.bns.1.num_batches_tracked"] == 0
+    assert sd["backbone.conv_input.bn.bns.2.num_batches_tracked"] == 2
+    assert sd["backbone.conv_input.bn.bns.0.num_batches_tracked"] == 1

@@ -35,3 +35,9 @@ def test_ponder_outdoor_forward_matches_reference(cpu_kernels):
     losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
     assert max(losses.values()) < 1e-4, errs
     assert max(errs.values()) < 5e-3, errs
+
+
+def test_spunet_pdnorm_matches_reference(cpu_kernels):
+    """SpUNet-v1m3: per-condition BatchNorm selection + context modulation, float64."""
+    errs = gc.run_spunet_pdnorm(torch.device("cpu"), torch.float64)
+    assert max(errs.values()) < 1e-9, errs

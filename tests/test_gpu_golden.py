@@ -162,3 +162,13 @@ def test_outdoor_graphed_render_head_equals_eager(device):
     out = model(b)
     out["loss"].backward()
     assert torch.isfinite(out["loss"]) and torch.isfinite(model.mtoken.grad).all()
+
+
+def test_spunet_pdnorm_gpu_vs_reference_golden(device):
+    """SpUNet-v1m3 on the GPU: the per-condition modulation rides in the fused BatchNorm kernel's
+    affine epilogue.  Same bounds (and conditioning caveat) as the v1m1 backbone test."""
+    errs, cos = gc.run_spunet_pdnorm(device, torch.float32)
+    print(errs, cos)
+    assert errs["out"] < 1e-4, errs
+    assert max(errs.values()) < 0.15, errs
+    assert max(cos.values()) < 5e-3, cos
