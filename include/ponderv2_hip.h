@@ -160,16 +160,20 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
  *             unbiased variance; mean_invstd[2c] = {mean, invstd} is kept for backward.
  *   backward: g = dy * (y > 0) when y is given (fused ReLU), else dy;
  *             dx = weight*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g (optional);
- *             sums_ws[0..c) = sum g (= dbias), sums_ws[c..2c) = sum g*xhat (= dweight), double.
- * sums_ws: device scratch of 2*c doubles.  weight / bias may be NULL (affine=False).
+ *             gsum[0..c) = sum g (= dbias), gsum[c..2c) = sum g*xhat (= dweight).
+ * zeroed_ws: device scratch of 2*c + 1 doubles that MUST BE ALL ZERO on entry; both calls leave it
+ * all zero again (the statistics kernel's last block consumes and clears it), so one buffer,
+ * cleared once at allocation, serves every layer issued on the same stream.
+ * weight / bias may be NULL (affine=False).
  * ------------------------------------------------------------------------------------------ */
 int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const float* bias,
                    const float* residual, int relu, float eps, float momentum,
-                   float* running_mean, float* running_var, double* sums_ws,
+                   float* running_mean, float* running_var, double* zeroed_ws,
                    float* mean_invstd, float* y, pv2_stream_t stream);
 int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     const float* mean_invstd, const float* weight, int64_t n, int c,
-                    double* sums_ws, float* dx, float* dresidual_or_null, pv2_stream_t stream);
+                    double* zeroed_ws, float* gsum, float* dx, float* dresidual_or_null,
+                    pv2_stream_t stream);
 /* out[c] = sum_r x[r, c] */
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
 

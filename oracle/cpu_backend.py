@@ -44,6 +44,25 @@ def build_downsample_rulebook(coords, stride, out_shape):
     return rb, torch.from_numpy(oc)
 
 
+def rulebook_from_table(tbl, K, n_in, n_out):
+    t = tbl.numpy()
+    pin, pout, ks = [], [], [0]
+    for k in range(K):
+        rows = np.nonzero(t[k] >= 0)[0]
+        pin.append(rows)
+        pout.append(t[k][rows])
+        ks.append(ks[-1] + len(rows))
+    return CpuRulebook(K, n_in, n_out, torch.from_numpy(np.concatenate(pin).astype(np.int64)),
+                       torch.from_numpy(np.concatenate(pout).astype(np.int64)), ks)
+
+
+class _ConvIntoApply:
+    @staticmethod
+    def apply(feats, weight_okc, rb, init):
+        return init + sparse_conv(feats, weight_okc, rb.pair_in, rb.pair_out, rb.kstart_host,
+                                  rb.n_out)
+
+
 class _ConvApply:
     @staticmethod
     def apply(feats, weight_okc, rb):
@@ -89,5 +108,7 @@ def install(monkeypatch):
     monkeypatch.setattr(K, "build_subm_rulebook", build_subm_rulebook)
     monkeypatch.setattr(K, "build_downsample_rulebook", build_downsample_rulebook)
     monkeypatch.setattr(K, "SparseConvFunction", _ConvApply)
+    monkeypatch.setattr(K, "SparseConvIntoFunction", _ConvIntoApply)
+    monkeypatch.setattr(K, "rulebook_from_table", rulebook_from_table)
     monkeypatch.setattr(ts, "ScatterRowsFunction", _ScatterApply)
     monkeypatch.setattr(sdf_field, "SmoothSampler", OracleSampler)

@@ -53,7 +53,7 @@ SIGNATURES = {
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_bn_forward": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P,
                                _P, _P, _P]),
-    "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),
     "pv2_col_sum": (c_int, [_P, c_int64, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),

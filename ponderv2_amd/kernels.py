@@ -133,6 +133,16 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     return Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host, center_k=K // 2)
 
 
+def rulebook_from_table(tbl: torch.Tensor, K: int, n_in: int, n_out: int) -> Rulebook:
+    """tbl int32 [K, n_in]: the output row input row i feeds under offset k, or -1 -> rulebook in
+    canonical (offset, input row) order.  Used for convolutions whose geometry is arithmetic (the
+    dense grid's first layer, models/ponder/sparse_input.py) rather than hashed."""
+    _require_device(tbl)
+    assert tbl.dtype == torch.int32 and tbl.shape == (K, n_in)
+    pair_out, pair_in, kstart, kstart_host = _compact(tbl.contiguous().reshape(-1), K, n_in, None)
+    return Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, kstart_host)
+
+
 def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List[int]):
     """Strided conv with kernel == stride, no padding.  Returns (rulebook, out_coords int32 [M,4]);
     out_coords are sorted by (b,x,y,z)."""
@@ -234,6 +244,34 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
         return g_feats, g_w, None
+
+
+class SparseConvIntoFunction(torch.autograd.Function):
+    """``init + conv(feats)``, accumulated in place into ``init`` (which must be a fresh tensor:
+    it is returned as the result).  Lets a caller seed the output with something other than zeros
+    without paying a second pass over it."""
+
+    @staticmethod
+    def forward(ctx, feats, weight_okc, rb: Rulebook, init):
+        assert init.is_contiguous() and init.shape == (rb.n_out, weight_okc.shape[0])
+        ctx.rb = rb
+        ctx.save_for_backward(feats, weight_okc)
+        spconv_forward(feats, weight_okc, rb, out=init)
+        ctx.mark_dirty(init)
+        return init
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, weight_okc = ctx.saved_tensors
+        rb = ctx.rb
+        grad_out = grad_out.contiguous()
+        g_feats = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_feats = spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(),
+                                     rb.transposed())
+        if ctx.needs_input_grad[1]:
+            g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
+        return g_feats, g_w, None, grad_out
 
 
 # --------------------------------------------------------------------------------------------

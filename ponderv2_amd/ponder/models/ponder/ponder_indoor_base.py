@@ -46,7 +46,8 @@ class PonderIndoor(nn.Module):
                  context_channels=256, pool_type="mean", render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True,
-                 proj_autocast=None, batched_render=True, graph_render_head=True):
+                 proj_autocast=None, batched_render=True, graph_render_head=True,
+                 sparse_dense_input=True):
         super().__init__()
         self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
         self.grid_size, self.pool_type = grid_size, pool_type
@@ -57,6 +58,9 @@ class PonderIndoor(nn.Module):
         # as the reference does for the whole model with enable_amp=True; None = fp32 (parity mode)
         self.proj_autocast = proj_autocast
         self.batched_render = batched_render
+        # evaluate the projection network's first conv from the occupied cells only (the dense
+        # 96-channel grid is never built, sparse_input.py); False = the reference's dense path
+        self.sparse_dense_input = sparse_dense_input
         # replay the (static-shape) render head + its backward as one hipGraph during training
         self.graph_render_head = graph_render_head
         self._graphed = None
@@ -298,13 +302,11 @@ class PonderIndoor(nn.Module):
         data_dict["resolution"] = (data_dict["bbox"][:, 1] - data_dict["bbox"][:, 0]).max(dim=1)[0].int() + 1
         return data_dict
 
-    def to_dense(self, data_dict):
-        """Scatter-mean the per-voxel backbone features into a (B, C, Z, Y, X) grid.  Only the
-        down-sampling branch of the reference (:199-216, scene resolution >= grid) is a device
-        path; rooms are always in it (a 0.64 m scene would be needed to leave it)."""
-        feat = data_dict["sparse_backbone_feat"]
+    def _dense_rows(self, data_dict):
+        """Row of every voxel in the (B, Z, Y, X) channels-last (or (B, X, Y, Z)) dense grid.
+        Only the down-sampling branch of the reference (:199-216, scene resolution >= grid) is a
+        device path; rooms are always in it (a 0.64 m scene would be needed to leave it)."""
         batch = offset2batch(data_dict["offset"])
-        B, C = data_dict["offset"].numel(), feat.shape[1]
         G0, G1, G2 = self.grid_shape
         voxel = (data_dict["coord"] // self.grid_size).int()
         res = (data_dict["resolution"] + 1).to(torch.float32)  # current_resolution, (B,)
@@ -314,29 +316,49 @@ class PonderIndoor(nn.Module):
                     "to_dense: a scene is smaller than the dense grid (resolution < "
                     f"{min(self.grid_shape)}); the reference's up-sampling branches are not "
                     "implemented on the device path")
-        shape = torch.tensor(self.grid_shape, dtype=torch.float32, device=feat.device)
+        shape = torch.tensor(self.grid_shape, dtype=torch.float32, device=voxel.device)
         cell = res[:, None] / shape[None, :]            # (B,3) anisotropic bin size in voxels
         g = (voxel // cell[batch]).long()
         if self.dense_channels_last:
             lin = (g[:, 2] * G1 + g[:, 1]) * G0 + g[:, 0]  # memory order (Z,Y,X), channels last
         else:
             lin = (g[:, 0] * G1 + g[:, 1]) * G2 + g[:, 2]  # the reference's (X,Y,Z) order
-        lin = lin + batch * (G0 * G1 * G2)
+        return lin + batch * (G0 * G1 * G2)
+
+    def to_dense(self, data_dict):
+        """Scatter-mean the per-voxel backbone features into a (B, C, Z, Y, X) grid."""
+        feat = data_dict["sparse_backbone_feat"]
+        B, C = data_dict["offset"].numel(), feat.shape[1]
+        G0, G1, G2 = self.grid_shape
+        lin = self._dense_rows(data_dict)
         grid = feat.new_zeros((B * G0 * G1 * G2, C))
         grid = scatter(feat, lin[:, None], dim=0, reduce=self.pool_type, out=grid)
         if self.dense_channels_last:
             return grid.view(B, G2, G1, G0, C).permute(0, 4, 1, 2, 3)  # channels_last_3d view
         return grid.view(B, G0, G1, G2, C).permute(0, 4, 3, 2, 1).contiguous()
 
+    def _use_cells(self):
+        return (self.sparse_dense_input and self.dense_channels_last and self.pool_type == "mean"
+                and hasattr(self.proj_net, "forward_cells"))
+
     def prepare_volume(self, data_dict):
         data_dict = self.grid_sample(data_dict)
-        dense = self.to_dense(data_dict)
-        if self.proj_autocast is not None and dense.is_cuda:
+        if self._use_cells():
+            from .sparse_input import cells_from_voxels
+
+            G0, G1, G2 = self.grid_shape
+            dense = cells_from_voxels(data_dict["sparse_backbone_feat"], self._dense_rows(data_dict),
+                                      data_dict["offset"].numel(), (G2, G1, G0))
+            project = self.proj_net.forward_cells
+        else:
+            dense = self.to_dense(data_dict)
+            project = self.proj_net
+        if self.proj_autocast is not None and data_dict["coord"].is_cuda:
             with torch.autocast("cuda", dtype=getattr(torch, self.proj_autocast)):
-                volume = self.proj_net(dense)
+                volume = project(dense)
             volume = volume.float()
         else:
-            volume = self.proj_net(dense)
+            volume = project(dense)
         if self.dense_channels_last:
             volume = volume.contiguous(memory_format=torch.channels_last_3d)
         return [volume]

@@ -47,7 +47,7 @@ class PonderOutdoor(nn.Module):
                  pool_type="mean", share_volume=True, render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  dense_channels_last=True, proj_autocast=None, batched_render=True,
-                 graph_render_head=True):
+                 graph_render_head=True, sparse_dense_input=True):
         super().__init__()
         self.grid_shape = _per_condition(grid_shape)
         self.grid_size = _per_condition(grid_size)
@@ -57,6 +57,7 @@ class PonderOutdoor(nn.Module):
         self.dense_channels_last = dense_channels_last
         self.proj_autocast = proj_autocast
         self.batched_render, self.graph_render_head = batched_render, graph_render_head
+        self.sparse_dense_input = sparse_dense_input  # first conv from occupied cells only
         self._graphed = None
         if mask is not None:
             p = nn.Parameter(torch.zeros(1, mask.channel))
@@ -132,22 +133,27 @@ class PonderOutdoor(nn.Module):
         return ray_dict
 
     # ------------------------------------------------------------------ dense volume
-    def to_dense(self, data_dict):
-        """Scatter-mean the backbone features into the fixed scene grid -> (B, C, Z, Y, X)."""
-        coord, feat, offset = data_dict["coord"], data_dict["sparse_backbone_feat"], data_dict["offset"]
-        assert len(coord) == len(feat)
+    def _dense_rows(self, data_dict):
+        coord, offset = data_dict["coord"], data_dict["offset"]
         idx = self._condition_index(data_dict)
         box = self._const("scene_bbox", idx, coord.device, coord.dtype)
         size = self._const("grid_size", idx, coord.device, coord.dtype)
         G0, G1, G2 = self.grid_shape[idx]
         batch = offset2batch(offset)
-        B, C = offset.numel(), feat.shape[1]
         g = ((coord - box[:3]) / size).long()
         if self.dense_channels_last:
             lin = (g[:, 2] * G1 + g[:, 1]) * G0 + g[:, 0]  # memory order (Z,Y,X), channels last
         else:
             lin = (g[:, 0] * G1 + g[:, 1]) * G2 + g[:, 2]  # the reference's (X,Y,Z) order
-        lin = lin + batch * (G0 * G1 * G2)
+        return lin + batch * (G0 * G1 * G2)
+
+    def to_dense(self, data_dict):
+        """Scatter-mean the backbone features into the fixed scene grid -> (B, C, Z, Y, X)."""
+        feat, offset = data_dict["sparse_backbone_feat"], data_dict["offset"]
+        assert len(data_dict["coord"]) == len(feat)
+        G0, G1, G2 = self.grid_shape[self._condition_index(data_dict)]
+        B, C = offset.numel(), feat.shape[1]
+        lin = self._dense_rows(data_dict)
         grid = feat.new_zeros((B * G0 * G1 * G2, C))
         grid = scatter(feat, lin[:, None], dim=0, reduce=self.pool_type, out=grid)
         if self.dense_channels_last:
@@ -155,13 +161,23 @@ class PonderOutdoor(nn.Module):
         return grid.view(B, G0, G1, G2, C).permute(0, 4, 3, 2, 1).contiguous()
 
     def prepare_volume(self, data_dict):
-        dense = self.to_dense(data_dict)
-        if self.proj_autocast is not None and dense.is_cuda:
+        if (self.sparse_dense_input and self.dense_channels_last and self.pool_type == "mean"
+                and hasattr(self.proj_net, "forward_cells")):
+            from .sparse_input import cells_from_voxels
+
+            G0, G1, G2 = self.grid_shape[self._condition_index(data_dict)]
+            dense = cells_from_voxels(data_dict["sparse_backbone_feat"], self._dense_rows(data_dict),
+                                      data_dict["offset"].numel(), (G2, G1, G0))
+            project = self.proj_net.forward_cells
+        else:
+            dense = self.to_dense(data_dict)
+            project = self.proj_net
+        if self.proj_autocast is not None and data_dict["coord"].is_cuda:
             with torch.autocast("cuda", dtype=getattr(torch, self.proj_autocast)):
-                volume = self.proj_net(dense)
+                volume = project(dense)
             volume = volume.float()
         else:
-            volume = self.proj_net(dense)
+            volume = project(dense)
         if self.dense_channels_last:
             volume = volume.contiguous(memory_format=torch.channels_last_3d)
         return [volume]

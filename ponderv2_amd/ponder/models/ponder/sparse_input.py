@@ -1,0 +1,151 @@
+"""The first dense convolution of the projection network, evaluated from the occupied cells only.
+
+``to_dense`` (ponder_indoor_base.py:177-342, ponder_outdoor_base.py:176-209) scatters the backbone
+features into a dense grid that is >= 90 % empty (ScanNet: ~30 k occupied of 524 288 cells per
+scene), and the projection network's first 3x3x3 convolution - 52 % of the dense U-Net's FLOPs at
+96 input channels - then multiplies mostly zeros.  A dense conv IS a sparse conv with a full
+rulebook, so the same layer is computed here with the sparse-conv kernels on a rulebook that only
+lists (occupied cell, tap) pairs; the dense 96-channel grid is never materialised.
+
+  out[p] = b + sum_k W_k . in[p + k - 1],      in[q] = y0 + [q occupied] * delta_q
+
+  * ``delta`` lives on the Nc occupied cells; ``y0`` is the value of every EMPTY cell (zero for a
+    plain conv; ``beta - mean * invstd * gamma`` when a BatchNorm3d precedes the conv, as in
+    UNet3D's "bcr" levels - then ``delta = x * invstd * gamma`` because BN is affine per channel);
+  * the constant part ``sum_k W_k . y0`` only depends on which taps fall inside the grid, i.e. on
+    one of 27 border classes: it is expanded from a (3,3,3,Cout) table and initialises the output;
+  * the occupied part is accumulated on top by ``spconv_forward`` (out rows = dense positions, so
+    the result IS the channels-last dense tensor); backward reuses the sparse grad-input /
+    grad-weight kernels, the constant part differentiates through plain einsums.
+BatchNorm3d statistics over ALL cells follow from the occupied cells' sums (the rest are zeros).
+"""
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from ponderv2_amd import kernels as K
+from ponderv2_amd.torch_scatter import scatter
+
+
+@dataclass
+class DenseCells:
+    """Occupied cells of a (batch, Z, Y, X) grid in ascending row order of its channels-last
+    layout; ``feat`` carries gradients back to the sparse backbone."""
+
+    feat: torch.Tensor          # (Nc, C)
+    lin: torch.Tensor           # (Nc,) int64 row = ((b*Z + z)*Y + y)*X + x
+    batch: int
+    dims: Tuple[int, int, int]  # (Z, Y, X)
+    _rulebook: Optional[object] = field(default=None, repr=False)
+
+    @property
+    def n_rows(self):
+        z, y, x = self.dims
+        return self.batch * z * y * x
+
+    def rulebook(self):
+        if self._rulebook is None:
+            self._rulebook = K.rulebook_from_table(_tap_table(self), 27, self.lin.shape[0],
+                                                   self.n_rows)
+        return self._rulebook
+
+
+def cells_from_voxels(feat, lin, batch, dims, reduce="mean"):
+    """Pool per-voxel rows into their dense cells WITHOUT building the dense grid: a flag grid and
+    its prefix sum number the occupied cells (one host read for their count)."""
+    z, y, x = dims
+    total = batch * z * y * x
+    flags = torch.zeros(total, dtype=torch.int32, device=feat.device)
+    flags.index_fill_(0, lin, 1)
+    cell_id = torch.cumsum(flags, 0, dtype=torch.int32)
+    n_cells = int(cell_id[-1])
+    cell_of_voxel = cell_id[lin].long() - 1
+    cell_lin = torch.empty(n_cells, dtype=torch.int64, device=feat.device)
+    cell_lin[cell_of_voxel] = lin  # duplicates write the same value
+    pooled = scatter(feat, cell_of_voxel[:, None], dim=0, reduce=reduce,
+                     out=feat.new_zeros((n_cells, feat.shape[1])))
+    return DenseCells(pooled, cell_lin, batch, (z, y, x))
+
+
+def _tap_table(cells):
+    """int32 [27, Nc]: output row that cell i feeds through tap k = (kz*3 + ky)*3 + kx, or -1.
+    Cross-correlation: out[p] += W_k . in[p + k - 1], so cell q reaches p = q - (k - 1)."""
+    zs, ys, xs = cells.dims
+    lin = cells.lin
+    x = lin % xs
+    y = torch.div(lin, xs, rounding_mode="floor") % ys
+    z = torch.div(lin, xs * ys, rounding_mode="floor") % zs
+    base = lin - ((z * ys + y) * xs + x)
+    k = torch.arange(27, device=lin.device)[:, None]
+    pz = z[None] - (torch.div(k, 9, rounding_mode="floor") - 1)
+    py = y[None] - (torch.div(k, 3, rounding_mode="floor") % 3 - 1)
+    px = x[None] - (k % 3 - 1)
+    ok = (pz >= 0) & (pz < zs) & (py >= 0) & (py < ys) & (px >= 0) & (px < xs)
+    row = base[None] + (pz * ys + py) * xs + px
+    return torch.where(ok, row, torch.full_like(row, -1)).to(torch.int32).contiguous()
+
+
+def _inside(size, device, dtype):
+    """(3, size): 1 where tap k of a size-3 kernel reads inside [0, size) at position p."""
+    q = torch.arange(size, device=device)[None] + torch.arange(3, device=device)[:, None] - 1
+    return ((q >= 0) & (q < size)).to(dtype)
+
+
+def _constant_part(weight, y0, bias, batch, dims):
+    """(batch*Z*Y*X, Cout): response of the zero-padded conv to the constant field y0 (+ bias)."""
+    zs, ys, xs = dims
+    c_out = weight.shape[0]
+    if y0 is None:
+        if bias is None:
+            return K.zeros_by_kernel((batch * zs * ys * xs, c_out), weight.dtype, weight.device) \
+                if weight.is_cuda else weight.new_zeros((batch * zs * ys * xs, c_out))
+        return bias.expand(batch * zs * ys * xs, c_out).clone(memory_format=torch.contiguous_format)
+    u = torch.einsum("ocijk,c->ijko", weight, y0)
+    t = torch.einsum("ijko,kx->ijxo", u, _inside(xs, u.device, u.dtype))
+    t = torch.einsum("ijxo,jy->iyxo", t, _inside(ys, u.device, u.dtype))
+    t = torch.einsum("iyxo,iz->zyxo", t, _inside(zs, u.device, u.dtype))
+    if bias is not None:
+        t = t + bias
+    # repeat(): always a fresh, non-view buffer - the sparse part is accumulated into it in place,
+    # and autograd mis-routes a custom Function's gradients when its dirtied input is a view
+    return t.reshape(zs * ys * xs, c_out).repeat(batch, 1)
+
+
+def conv3d_on_cells(cells, delta, weight, y0=None, bias=None):
+    """3x3x3 / stride 1 / padding 1 convolution of the field ``y0 + occupied * delta``.
+    weight (Cout, Cin, 3, 3, 3) as nn.Conv3d holds it -> (B, Cout, Z, Y, X), channels-last."""
+    assert tuple(weight.shape[2:]) == (3, 3, 3)
+    c_out, c_in = weight.shape[:2]
+    init = _constant_part(weight, y0, bias, cells.batch, cells.dims)
+    w_okc = weight.permute(0, 2, 3, 4, 1).reshape(c_out, 27, c_in).contiguous()
+    out = K.SparseConvIntoFunction.apply(delta, w_okc, cells.rulebook(), init)
+    zs, ys, xs = cells.dims
+    return out.view(cells.batch, zs, ys, xs, c_out).permute(0, 4, 1, 2, 3)
+
+
+def bn_conv_relu_on_cells(bn, conv, cells):
+    """relu(conv(batchnorm3d(dense))) - one "bcr" level of UNet3D (unet3d.py SingleConv) - from the
+    occupied cells.  Training-mode statistics run over all batch*Z*Y*X positions."""
+    x = cells.feat
+    n_tot = float(cells.n_rows)
+    if bn.training or not bn.track_running_stats:
+        mean = x.sum(0) / n_tot
+        var = ((x * x).sum(0) / n_tot - mean * mean).clamp_min(0.0)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var * (n_tot / max(n_tot - 1.0, 1.0)), alpha=m)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    scale = torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        scale = scale * bn.weight
+    y0 = -mean * scale
+    if bn.affine:
+        y0 = y0 + bn.bias
+    out = conv3d_on_cells(cells, x * scale, conv.weight, y0=y0, bias=conv.bias)
+    return F.relu_(out)

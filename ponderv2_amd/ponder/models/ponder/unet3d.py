@@ -27,6 +27,16 @@ class SimpleConv3D(nn.Module):
     def forward(self, x):
         return self.conv(x)
 
+    def forward_cells(self, cells):
+        """Same result from the occupied cells of the (mostly empty) input grid: the conv runs on
+        the sparse-conv kernels (sparse_input.py), BatchNorm3d + ReLU on its dense 32-channel
+        output as usual."""
+        from .sparse_input import conv3d_on_cells
+
+        conv, bn, relu = self.conv[0], self.conv[1], self.conv[2]
+        assert conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and conv.padding == (1, 1, 1)
+        return relu(bn(conv3d_on_cells(cells, cells.feat, conv.weight, bias=conv.bias)))
+
 
 class SingleConv(nn.Sequential):
     """One conv level; ``order`` spells the op sequence: b(atchnorm) g(roupnorm) c(onv) r(elu)
@@ -117,10 +127,24 @@ class UNet3Dv1m2(nn.Module):
         if is_segmentation:
             self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
 
-    def forward(self, x):
+    def forward_cells(self, cells):
+        """Forward from the occupied cells of the input grid: level 0 ("bcr": BatchNorm3d -> conv
+        -> ReLU on the 96-channel grid, half of this network's FLOPs) is computed sparsely
+        (sparse_input.py), the rest of the U-Net runs on its dense output."""
+        from .sparse_input import bn_conv_relu_on_cells
+
+        first = self.encoders[0].basic_module
+        names = [n for n, _ in first.named_children()]
+        if self.encoders[0].pooling is not None or names != ["batchnorm", "conv", "ReLU"]:
+            raise NotImplementedError("forward_cells needs a BatchNorm3d -> Conv3d -> ReLU first level")
+        with torch.autocast("cuda", enabled=False):  # the sparse kernels are fp32
+            x = bn_conv_relu_on_cells(first.batchnorm, first.conv, cells)
+        return self.forward(None, first=x)
+
+    def forward(self, x, first=None):
         skips = []
-        for encoder in self.encoders:
-            x = encoder(x)
+        for level, encoder in enumerate(self.encoders):
+            x = first if (level == 0 and first is not None) else encoder(x)
             skips.insert(0, x)
         for decoder, skip in zip(self.decoders, skips[1:]):
             x = decoder(skip, x)

@@ -13,6 +13,21 @@ from . import _lib
 from .kernels import _ptr, _require_device, _stream
 
 
+_WORKSPACES = {}
+
+
+def _zeroed_workspace(device, channels):
+    """The statistics kernels' scratch: 2C doubles + a ticket word, all zero between launches (the
+    kernels clean up after themselves, csrc/rownorm.hip), so ONE buffer per stream - cleared when
+    it is allocated - serves every layer.  Grown (re-allocated, re-zeroed) on demand."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < 2 * channels + 1:
+        ws = torch.zeros(max(2 * channels + 1, 1025), dtype=torch.float64, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, relu, eps, momentum):
@@ -22,7 +37,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         y = torch.empty_like(x)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        sums = _zeroed_workspace(x.device, c)
         mean_invstd = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().pv2_bn_forward(
             _ptr(x), n, c, _ptr(weight), _ptr(bias), _ptr(residual), int(relu), float(eps),
@@ -40,13 +55,13 @@ class _FusedBNFunction(torch.autograd.Function):
         n, c = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_residual else None
-        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        gsum = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().pv2_bn_backward(
-            _ptr(dy), _ptr(x), _ptr(y), _ptr(mean_invstd), _ptr(weight), n, c, _ptr(sums),
-            _ptr(dx), _ptr(dres), _stream(x)), "pv2_bn_backward")
-        s32 = sums.float()
-        dweight = s32[c:] if weight is not None else None
-        dbias = s32[:c] if ctx.has_bias else None
+            _ptr(dy), _ptr(x), _ptr(y), _ptr(mean_invstd), _ptr(weight), n, c,
+            _ptr(_zeroed_workspace(x.device, c)), _ptr(gsum), _ptr(dx), _ptr(dres), _stream(x)),
+            "pv2_bn_backward")
+        dweight = gsum[c:] if weight is not None else None
+        dbias = gsum[:c] if ctx.has_bias else None
         return dx, dweight, dbias, dres, None, None, None, None, None
 
 

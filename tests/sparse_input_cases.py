@@ -1,0 +1,77 @@
+"""Shared driver: the sparse first layer (models/ponder/sparse_input.py) against the dense layer
+it replaces, built with stock torch modules in float64."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def make_case(seed, B=2, dims=(5, 12, 9), c_in=8, c_out=6, n_vox=220):
+    g = torch.Generator().manual_seed(seed)
+    Z, Y, X = dims
+    total = B * Z * Y * X
+    lin = torch.randint(0, total, (n_vox,), generator=g)
+    # make sure border and corner cells are occupied, and that several voxels share a cell
+    lin[:6] = torch.tensor([0, X - 1, (Y - 1) * X, Z * Y * X - 1, Z * Y * X, total - 1])
+    lin[6:12] = lin[:6]
+    feat = torch.randn(n_vox, c_in, generator=g, dtype=torch.float64)
+    return lin, feat, B, dims
+
+
+def dense_reference(lin, feat, B, dims, bn, conv, with_bn):
+    """scatter-mean -> [BatchNorm3d] -> Conv3d -> ReLU exactly as the dense path does."""
+    Z, Y, X = dims
+    C = feat.shape[1]
+    grid = torch.zeros(B * Z * Y * X, C, dtype=feat.dtype)
+    cnt = torch.zeros(B * Z * Y * X, dtype=feat.dtype)
+    grid = grid.index_add(0, lin, feat)
+    cnt = cnt.index_add(0, lin, torch.ones_like(feat[:, 0]))
+    grid = grid / cnt.clamp(min=1)[:, None]
+    dense = grid.view(B, Z, Y, X, C).permute(0, 4, 1, 2, 3)
+    if with_bn:
+        return F.relu(conv(bn(dense)))
+    return conv(dense)
+
+
+def run(device, dtype, with_bn, seed=0):
+    from ponderv2_amd.ponder.models.ponder.sparse_input import (bn_conv_relu_on_cells,
+                                                                 cells_from_voxels, conv3d_on_cells)
+
+    lin, feat, B, dims = make_case(seed)
+    c_in, c_out = feat.shape[1], 6
+    torch.manual_seed(seed + 1)
+    bn_ref = nn.BatchNorm3d(c_in, eps=1e-3, momentum=0.1).double()
+    conv_ref = nn.Conv3d(c_in, c_out, 3, padding=1, bias=not with_bn).double()
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.uniform_(-0.5, 0.5)
+    import copy
+
+    bn_new, conv_new = copy.deepcopy(bn_ref).to(dtype).to(device), copy.deepcopy(conv_ref).to(dtype).to(device)
+    probe = torch.randn(B, c_out, *dims, dtype=torch.float64)
+
+    f_ref = feat.clone().requires_grad_(True)
+    out_ref = dense_reference(lin, f_ref, B, dims, bn_ref.train(), conv_ref, with_bn)
+    (out_ref * probe).sum().backward()
+
+    f_new = feat.to(dtype).to(device).requires_grad_(True)
+    cells = cells_from_voxels(f_new, lin.to(device), B, dims)
+    if with_bn:
+        out_new = bn_conv_relu_on_cells(bn_new.train(), conv_new, cells)
+    else:
+        out_new = conv3d_on_cells(cells, cells.feat, conv_new.weight, bias=conv_new.bias)
+    (out_new * probe.to(dtype).to(device)).sum().backward()
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+    errs = {"out": rel(out_new.detach(), out_ref.detach()), "dfeat": rel(f_new.grad, f_ref.grad),
+            "dweight": rel(conv_new.weight.grad, conv_ref.weight.grad)}
+    if with_bn:
+        errs.update(dgamma=rel(bn_new.weight.grad, bn_ref.weight.grad),
+                    dbeta=rel(bn_new.bias.grad, bn_ref.bias.grad),
+                    running_mean=rel(bn_new.running_mean, bn_ref.running_mean),
+                    running_var=rel(bn_new.running_var, bn_ref.running_var))
+        assert int(bn_new.num_batches_tracked) == 1
+    else:
+        errs["dbias"] = rel(conv_new.bias.grad, conv_ref.bias.grad)
+    return errs

@@ -41,3 +41,14 @@ def test_spunet_pdnorm_matches_reference(cpu_kernels):
     """SpUNet-v1m3: per-condition BatchNorm selection + context modulation, float64."""
     errs = gc.run_spunet_pdnorm(torch.device("cpu"), torch.float64)
     assert max(errs.values()) < 1e-9, errs
+
+
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_sparse_first_layer_equals_dense_layer(cpu_kernels, with_bn):
+    """scatter-mean -> [BatchNorm3d ->] Conv3d(3x3x3, pad 1) [-> ReLU] computed from the occupied
+    cells (sparse_input.py) == the dense layers, float64: output, input / weight / BatchNorm
+    gradients and running statistics, with occupied border and corner cells."""
+    import sparse_input_cases as sic
+
+    errs = sic.run(torch.device("cpu"), torch.float64, with_bn)
+    assert max(errs.values()) < 1e-10, errs

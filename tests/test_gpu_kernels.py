@@ -359,3 +359,13 @@ def test_sampler_second_order_vs_oracle_f32(device, C, B, channels_last, padding
     for name, a, b in zip(("out", "dgrid", "gvol", "ggrid"), got, ref):
         err = (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
         assert err < 2e-4, (name, err)
+
+
+# ------------------------------------------------------------------ sparse first dense layer
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_sparse_first_layer_equals_dense_layer_gpu(device, with_bn):
+    """Same check as the CPU one, on the HIP sparse-conv kernels in fp32 (reference: float64)."""
+    import sparse_input_cases as sic
+
+    errs = sic.run(device, torch.float32, with_bn)
+    assert max(errs.values()) < 2e-5, errs
