@@ -41,6 +41,7 @@ __global__ __launch_bounds__(kThreads) void col_reduce2_kernel(
   __shared__ float s1[kThreads];
   __shared__ bool is_last;
   const int tid = threadIdx.x;
+  double landed = 0.0;
   for (int cb = 0; cb < c; cb += kThreads) {  // column panels of <= 256
     const int cw = min(c - cb, kThreads);
     const int rpi = kThreads / cw;             // rows covered per iteration
@@ -78,18 +79,24 @@ __global__ __launch_bounds__(kThreads) void col_reduce2_kernel(
         t0 += s0[q * cw + tid];
         t1 += s1[q * cw + tid];
       }
-      atomicAdd(&sums[cb + tid], (double)t0);
-      atomicAdd(&sums[c + cb + tid], (double)t1);
+      // RETURNING atomics: the old value comes back from the device coherence point, so once it
+      // has arrived the addition has been performed there (see the ticket below)
+      landed += atomicAdd(&sums[cb + tid], (double)t0);
+      landed += atomicAdd(&sums[c + cb + tid], (double)t1);
     }
     __syncthreads();
   }
 
   // Ticket.  All cross-block traffic here is device-scope atomics, which execute at the device
-  // coherence point; the barrier above (workgroup release: every wave has waited for its
-  // outstanding atomics to be acknowledged) therefore orders this block's sums before its ticket.
-  // A device-scope __threadfence() would also be correct but costs an L2 write-back per block on
-  // this multi-XCD part (measured: +3.5 ms per training step over the 118 BatchNorm launches).
+  // coherence point.  Every thread that added to the sums has RECEIVED the previous values back
+  // (the dependency on `landed` below), i.e. its additions are done, before the barrier lets
+  // thread 0 draw the block's ticket - so whoever draws the last ticket reads complete sums.
+  // Two things that do NOT work here on this 8-XCD part: non-returning atomics + the workgroup
+  // barrier alone (observed: occasionally stale sums -> wrong statistics), and a device-scope
+  // __threadfence() per block (correct, but an L2 write-back each: +3.5 ms per training step).
   unsigned int* counter = reinterpret_cast<unsigned int*>(sums + 2 * c);
+  asm volatile("" ::"v"(landed));
+  __syncthreads();
   if (tid == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!is_last) return;

@@ -346,7 +346,8 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   for (int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW; p0 < pd.n_points;     \
        p0 += nw * PPW) {                                                                        \
     const bool valid = p0 + slot < pd.n_points;                                                 \
-    const int64_t pt = valid ? p0 + slot : pd.n_points - 1;                                     \
+    int64_t pt = valid ? p0 + slot : pd.n_points - 1;                                           \
+    if (perm) pt = (int64_t)((uint64_t)pt * perm % (uint64_t)pd.n_points);                      \
     const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;                           \
     const Axis<float> ax = make_axis<float>(grid[pt * 3 + 0], v.w, padding, align != 0, smooth != 0); \
     const Axis<float> ay = make_axis<float>(grid[pt * 3 + 1], v.h, padding, align != 0, smooth != 0); \
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void tri_fwd_vec_kernel(const float* __restric
                                                           const float* __restrict__ grid,
                                                           pv2_points_desc pd,
                                                           float* __restrict__ out, int padding,
-                                                          int align, int smooth) {
+                                                          int align, int smooth, uint32_t perm) {
   PV2_VEC_PROLOGUE
     float w[8];
 #pragma unroll
@@ -392,7 +393,7 @@ template <int LPP, int ATOM>
 __global__ __launch_bounds__(256) void tri_bwd_vec_kernel(
     const float* __restrict__ gout, const float* __restrict__ in, pv2_volume_desc v,
     const float* __restrict__ grid, pv2_points_desc pd, float* __restrict__ gin,
-    float* __restrict__ ggrid, int padding, int align, int smooth) {
+    float* __restrict__ ggrid, int padding, int align, int smooth, uint32_t perm) {
   PV2_VEC_PROLOGUE
     float w[8], dx[8], dy[8], dz[8];
 #pragma unroll
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void tri_bwdbwd_vec_kernel(
     const float* __restrict__ hV, const float* __restrict__ hG, const float* __restrict__ in,
     pv2_volume_desc v, const float* __restrict__ grid, const float* __restrict__ gout,
     pv2_points_desc pd, float* __restrict__ gin2, float* __restrict__ ggrid2,
-    float* __restrict__ ggout, int padding, int align, int smooth) {
+    float* __restrict__ ggout, int padding, int align, int smooth, uint32_t perm) {
   PV2_VEC_PROLOGUE
     const float hx = hG[pt * 3 + 0], hy = hG[pt * 3 + 1], hz = hG[pt * 3 + 2];
     float w[8], dx[8], dy[8], dz[8], D[8], ex[8], ey[8], ez[8];
@@ -560,15 +561,16 @@ template <int G, bool SECOND>
 __global__ __launch_bounds__(256) void tri_scatter_kernel(
     const float* __restrict__ gout, pv2_volume_desc v, const float* __restrict__ grid,
     const float* __restrict__ hG, pv2_points_desc pd, float* __restrict__ gin, int padding,
-    int align, int smooth) {
+    int align, int smooth, uint32_t perm) {
   constexpr int PPW = 64 / G;
   const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
   const int64_t nw = (int64_t)gridDim.x * 4;
   const int C = (int)v.c;
   for (int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW; p0 < pd.n_points;
        p0 += nw * PPW) {
-    const int64_t pt = p0 + slot;
+    int64_t pt = p0 + slot;
     if (pt >= pd.n_points) continue;
+    if (perm) pt = (int64_t)((uint64_t)pt * perm % (uint64_t)pd.n_points);
     const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
     const Axis<float> ax = make_axis<float>(grid[pt * 3 + 0], v.w, padding, align != 0, smooth != 0);
     const Axis<float> ay = make_axis<float>(grid[pt * 3 + 1], v.h, padding, align != 0, smooth != 0);
@@ -631,6 +633,22 @@ inline int tri_mode() {
 }
 inline int atomics_mode(int lpp) { return tri_mode() == 4 ? (lpp >= 32 ? 2 : 3) : tri_mode(); }
 
+// The kernels that issue volume-gradient atomics visit the points in a scrambled order
+// pt = (i * a) mod n (a prime that does not divide n: a bijection).  In ray order, the lane groups
+// of one wave and the waves in flight together hold consecutive samples of the same few rays,
+// which share corner voxels - their atomics then pile up on the same addresses.  PV2_TRI_PERMUTE=0
+// keeps ray order (for the comparison in profiles/).
+inline uint32_t point_permutation(int64_t n_points) {
+  static const bool on = [] {
+    const char* e = getenv("PV2_TRI_PERMUTE");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (!on || n_points < 64 || n_points >= 0x7fffffffLL) return 0;
+  for (uint32_t a : {7919u, 7907u, 7901u, 7883u})
+    if (n_points % a != 0) return a;
+  return 0;
+}
+
 inline int vec_grid(int64_t n_points, int lpp) {
   const int64_t waves = (n_points + (64 / lpp) - 1) / (64 / lpp);
   return pv2::grid_for(waves * 64, 256);
@@ -666,10 +684,12 @@ void launch_scatter(const float* gout, const pv2_volume_desc& v, const float* gr
                     int smooth, hipStream_t s) {
   if (v.c <= 32) {
     hipLaunchKernelGGL((tri_scatter_kernel<32, SECOND>), dim3(vec_grid(pd.n_points, 32)),
-                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth);
+                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth,
+                       point_permutation(pd.n_points));
   } else {
     hipLaunchKernelGGL((tri_scatter_kernel<64, SECOND>), dim3(vec_grid(pd.n_points, 64)),
-                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth);
+                       dim3(256), 0, s, gout, v, grid, hG, pd, gin, padding, align, smooth,
+                       point_permutation(pd.n_points));
   }
 }
 
@@ -689,7 +709,7 @@ int run_fwd(const T* input, const pv2_volume_desc* vol, const T* grid, const pv2
   if constexpr (std::is_same<T, float>::value) {
     if (const int lpp = tri_mode() ? vec_lanes(*vol, *pts, input, output, nullptr, nullptr) : 0) {
       PV2_VEC_DISPATCH(lpp, tri_fwd_vec_kernel, dim3(vec_grid(pts->n_points, lpp)), dim3(256), 0,
-                       (hipStream_t)stream, input, *vol, grid, *pts, output, padding, align, smooth)
+                       (hipStream_t)stream, input, *vol, grid, *pts, output, padding, align, smooth, 0u)
       return pv2::check_launch("trilinear_forward");
     }
   }
@@ -712,7 +732,7 @@ int run_bwd(const T* gout, const T* input, const pv2_volume_desc* vol, const T* 
       const int atom = (gin == nullptr || mode == 3) ? 0 : mode;
       PV2_VEC_DISPATCH_ATOM(lpp, atom, tri_bwd_vec_kernel, dim3(vec_grid(pts->n_points, lpp)),
                             dim3(256), 0, (hipStream_t)stream, gout, input, *vol, grid, *pts, gin,
-                            ggrid, padding, align, smooth)
+                            ggrid, padding, align, smooth, atom ? point_permutation(pts->n_points) : 0u)
       if (gin != nullptr && mode == 3)
         launch_scatter<false>(gout, *vol, grid, nullptr, *pts, gin, padding, align, smooth,
                               (hipStream_t)stream);
@@ -740,7 +760,8 @@ int run_bwdbwd(const T* hV, const T* hG, const T* input, const pv2_volume_desc* 
         PV2_VEC_DISPATCH_ATOM(lpp, atom, tri_bwdbwd_vec_kernel,
                               dim3(vec_grid(pts->n_points, lpp)), dim3(256), 0,
                               (hipStream_t)stream, hV, hG, input, *vol, grid, gout, *pts, gin2,
-                              ggrid2, ggout, padding, align, smooth)
+                              ggrid2, ggout, padding, align, smooth,
+                              atom ? point_permutation(pts->n_points) : 0u)
         if (gin2 != nullptr && mode == 3)
           launch_scatter<true>(gout, *vol, grid, hG, *pts, gin2, padding, align, smooth,
                                (hipStream_t)stream);
