@@ -47,7 +47,7 @@ class PonderOutdoor(nn.Module):
                  pool_type="mean", share_volume=True, render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  dense_channels_last=True, proj_autocast=None, batched_render=True,
-                 graph_render_head=True, sparse_dense_input=True):
+                 graph_render_head=False, sparse_dense_input=True):
         super().__init__()
         self.grid_shape = _per_condition(grid_shape)
         self.grid_size = _per_condition(grid_size)

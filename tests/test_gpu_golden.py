@@ -175,3 +175,41 @@ def test_spunet_pdnorm_gpu_vs_reference_golden(device):
     assert errs["out"] < 1e-4, errs
     assert max(errs.values()) < 0.15, errs
     assert max(cos.values()) < 5e-3, cos
+
+
+@pytest.mark.xfail(strict=False, reason="open issue (DESIGN.md section 6): with the full-size model and an "
+                   "optimizer step between replays, the graphed head's sdf / free-space / eikonal loss "
+                   "terms were observed to turn into garbage on some steps while the eager head trains "
+                   "smoothly (profiles/r01_graph_head_loss_trace.txt); the head is eager by default")
+def test_graphed_head_training_trajectory_equals_eager(device):
+    """Six SGD steps of the full-size indoor model on one batch, eager head vs graph-replayed head,
+    sampler jitter off: every logged loss term must follow the same trajectory."""
+    import copy
+
+    import bench
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    cfg = bench.model_cfg(256)
+    cfg["renderer"] = copy.deepcopy(cfg["renderer"])
+    cfg["renderer"]["sampler"]["train_stratified"] = False
+    batch = bench.make_batch(0, 2, 2, device)
+    traces = {}
+    for graphed in (False, True):
+        cfg["graph_render_head"] = graphed
+        torch.manual_seed(0)
+        model = build_model(ConfigDict(cfg)).to(device).train()
+        opt = torch.optim.SGD(model.parameters(), lr=1.25e-4, momentum=0.9, weight_decay=1e-4,
+                              nesterov=True)
+        rows = []
+        for step in range(6):
+            torch.manual_seed(100 + step)  # same pixel choice in both runs
+            out = model(bench.clone_batch(batch))
+            opt.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            opt.step()
+            rows.append({k: float(v.detach()) for k, v in out.items()})
+        traces[graphed] = rows
+    for e, g in zip(traces[False], traces[True]):
+        for k in e:
+            assert abs(e[k] - g[k]) <= 2e-2 * abs(e[k]) + 1e-3, (k, traces)
