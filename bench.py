@@ -328,13 +328,21 @@ def main():
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)
-    if outdoor:  # configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py:95
+    # optimiser + OneCycleLR exactly as the reference's run_step drives them every iteration
+    # (engines/train.py:185-203): the schedule starts at max_lr / div_factor
+    if outdoor:  # configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py:95-104
         opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, total_steps=100000,
+                                                    pct_start=0.4, anneal_strategy="cos",
+                                                    div_factor=10.0, final_div_factor=100.0)
         batch = make_outdoor_batch(rank, args.scenes_per_gpu, args.rays_per_camera, device)
-    else:
-        lr = 0.0005 * (args.scenes_per_gpu * world) / 8
+    else:       # configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:156-170 (ppt: lr 1e-4 * bs / 8)
+        lr = (0.0001 if ppt else 0.0005) * (args.scenes_per_gpu * world) / 8
         opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4,
                               nesterov=True)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=100000,
+                                                    pct_start=0.05, anneal_strategy="cos",
+                                                    div_factor=10.0, final_div_factor=10000.0)
         batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
     n_vox = int(batch["offset"][-1])
     batches, counter = [batch], [0]
@@ -348,6 +356,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         out["loss"].backward()
         opt.step()
+        sched.step()
         if args.print_losses and rank == 0:
             print("loss", {k: round(float(v.detach()), 5) for k, v in out.items()}, flush=True)
         return out
@@ -371,11 +380,17 @@ def main():
             dt = float(t)
         return dt, t_cpu, out
 
+    first_loss_t = None
     for _ in range(args.warmup):
         out = step()
+        if first_loss_t is None:
+            first_loss_t = out["loss"].detach().clone()
     # pass 1: the measurement (no instrumentation inside the timed region)
     elapsed, host_enqueue, out = timed_pass(args.steps)
     loss = float(out["loss"].detach())
+    first_loss = float(first_loss_t) if first_loss_t is not None else loss
+    # a training step that is fast but computes garbage is not a measurement: say so in the line
+    loss_sane = bool(loss == loss and abs(loss) < 50.0 * max(abs(first_loss), 1.0))
     # pass 2: the SAME K steps again with HIP events around every hand-written kernel launch
     timer, elapsed_instr = None, None
     if not args.no_kernel_timing:
@@ -427,7 +442,8 @@ def main():
                                      "train step fwd+bwd+SGD")),
                        "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
-            "final_loss": loss,
+            "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
+            "render_head": "hipGraph replay" if cfg["graph_render_head"] else "eager",
         }
         if kernels:
             dom = kernels[0]
