@@ -293,6 +293,18 @@ def spunet_pdnorm_case():
           "|dcontext|", context.grad.abs().max().item())
 
 
+def transform_chain_case():
+    """The reference's own transform classes (datasets/transform.py) on the ScanNet pre-training
+    chain, fixed python / numpy seeds."""
+    import test_transforms as tt
+
+    T = ref_shims.load_reference_file("ponder/datasets/transform.py")
+    seed = 7
+    out = tt.flatten(tt.run_chain(T.Compose, tt.SCANNET_CHAIN, tt.raw_scene(), seed))
+    np.savez_compressed(os.path.join(GOLDEN, "transform_chain.npz"), seed=np.array(seed), **out)
+    print("transform_chain:", {k: v.shape for k, v in out.items()})
+
+
 def main():
     ref_shims.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -300,7 +312,7 @@ def main():
 
     only = sys.argv[1:]
     cases = dict(spunet=spunet_case, neus=lambda: neus_case_impl(ConfigDict),
-                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case,
+                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case, transforms=transform_chain_case,
                  outdoor=lambda: ponder_outdoor_case(ConfigDict))
     for name, fn in cases.items():
         if not only or name in only:

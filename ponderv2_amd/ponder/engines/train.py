@@ -10,7 +10,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ..datasets import (ConcatDataset, MultiDatasetDataloader, SyntheticLidarDataset,
+from ..datasets import (ConcatDataset, MultiDatasetDataloader, NuScenesDataset, S3DISRGBDDataset,
+                        ScanNetRGBDDataset, Structured3DRGBDDataset, SyntheticLidarDataset,
                         SyntheticRGBDDataset, collate_fn)
 from ..models import build_model
 from ..utils import comm
@@ -23,6 +24,8 @@ TRAINERS = Registry("trainers")
 DATASETS = Registry("datasets")
 DATASETS.register_module(module=SyntheticRGBDDataset, name="SyntheticRGBDDataset")
 DATASETS.register_module(module=SyntheticLidarDataset, name="SyntheticLidarDataset")
+for _reader in (ScanNetRGBDDataset, Structured3DRGBDDataset, S3DISRGBDDataset, NuScenesDataset):
+    DATASETS.register_module(module=_reader, name=_reader.__name__)
 
 
 def build_dataset(cfg):
@@ -30,8 +33,8 @@ def build_dataset(cfg):
         return ConcatDataset([build_dataset(d) for d in cfg["datasets"]], loop=cfg.get("loop", 1))
     if cfg["type"] not in DATASETS:
         raise KeyError(
-            f"dataset {cfg['type']!r}: on-disk dataset readers are not part of this round's hot "
-            "path; run with --options data.train.type=SyntheticRGBDDataset")
+            f"dataset {cfg['type']!r} is not registered; the pre-training readers are "
+            f"{sorted(DATASETS.module_dict)}")
     return DATASETS.build(cfg)
 
 
