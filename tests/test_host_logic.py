@@ -225,3 +225,25 @@ def test_block_masking_keeps_the_reference_set():
     assert torch.equal(out[~masked], feat[~masked])
     out.sum().backward()
     assert torch.allclose(token.grad, torch.full((1, 4), float(masked.sum())))
+
+
+def test_capture_safe_reductions_are_the_plain_ops_outside_capture():
+    """capture_safe.* must be numerically the ordinary torch reductions whenever no graph is being
+    captured (CPU here), including their gradients."""
+    from ponderv2_amd import capture_safe as cs
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5000, 3, generator=g, dtype=torch.double, requires_grad=True)
+    s = torch.tensor([1.7], dtype=torch.double, requires_grad=True)
+    mask = torch.rand(5000, 3, generator=g) > 0.5
+    assert cs.sum_all(mask).item() == mask.sum().item()
+    a = cs.mean_all(cs.scale_by_scalar(x, s) ** 2) + cs.sum_all(x * mask)
+    b = ((x * s) ** 2).mean() + (x * mask).sum()
+    ga, gb = torch.autograd.grad(a, [x, s]), torch.autograd.grad(b, [x, s])
+    assert torch.equal(a, b) and all(torch.equal(p, q) for p, q in zip(ga, gb))
+    y = torch.randn(3, 8 * 11, generator=g)
+    lo, hi = cs.rowwise_min_max(y, group=11)
+    assert torch.equal(lo, y.amin(1)) and torch.equal(hi, y.amax(1))
+    # the custom Function behind scale_by_scalar, exercised directly (it only engages during capture)
+    torch.autograd.gradcheck(cs._ScaleByScalar.apply, (x[:50], s))
+    torch.autograd.gradgradcheck(cs._ScaleByScalar.apply, (x[:20], s))
