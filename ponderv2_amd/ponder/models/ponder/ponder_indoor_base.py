@@ -306,20 +306,22 @@ class PonderIndoor(nn.Module):
         data_dict["resolution"] = (data_dict["bbox"][:, 1] - data_dict["bbox"][:, 0]).max(dim=1)[0].int() + 1
         return data_dict
 
+    def _small_scenes(self, data_dict):
+        """Scenes whose voxel resolution is below the smallest grid side (< 0.64 m at the ScanNet
+        settings): the reference up-samples those instead of pooling them (:218-247).  One host
+        read per batch, cached in the dict."""
+        if "small_scenes" not in data_dict:
+            res = data_dict["resolution"] + 1
+            data_dict["small_scenes"] = torch.nonzero(res < min(self.grid_shape)).flatten().tolist()
+        return data_dict["small_scenes"]
+
     def _dense_rows(self, data_dict):
-        """Row of every voxel in the (B, Z, Y, X) channels-last (or (B, X, Y, Z)) dense grid.
-        Only the down-sampling branch of the reference (:199-216, scene resolution >= grid) is a
-        device path; rooms are always in it (a 0.64 m scene would be needed to leave it)."""
+        """Row of every voxel in the (B, Z, Y, X) channels-last (or (B, X, Y, Z)) dense grid for
+        the pooling branch of the reference (:199-216, scene resolution >= grid)."""
         batch = offset2batch(data_dict["offset"])
         G0, G1, G2 = self.grid_shape
         voxel = (data_dict["coord"] // self.grid_size).int()
         res = (data_dict["resolution"] + 1).to(torch.float32)  # current_resolution, (B,)
-        if "resolution_host_checked" not in data_dict:
-            if bool((res < min(self.grid_shape)).any()):
-                raise NotImplementedError(
-                    "to_dense: a scene is smaller than the dense grid (resolution < "
-                    f"{min(self.grid_shape)}); the reference's up-sampling branches are not "
-                    "implemented on the device path")
         shape = torch.tensor(self.grid_shape, dtype=torch.float32, device=voxel.device)
         cell = res[:, None] / shape[None, :]            # (B,3) anisotropic bin size in voxels
         g = (voxel // cell[batch]).long()
@@ -329,14 +331,44 @@ class PonderIndoor(nn.Module):
             lin = (g[:, 0] * G1 + g[:, 1]) * G2 + g[:, 2]  # the reference's (X,Y,Z) order
         return lin + batch * (G0 * G1 * G2)
 
+    def _upsampled_scene(self, data_dict, i):
+        """(G, C) rows of scene i for a scene SMALLER than the grid: scatter-mean at its own
+        resolution, then trilinear resize to the grid (reference :218-247)."""
+        edges = [0] + offsets_host(data_dict)
+        feat = data_dict["sparse_backbone_feat"][edges[i]:edges[i + 1]]
+        voxel = (data_dict["coord"][edges[i]:edges[i + 1]] // self.grid_size).long()
+        cur = int(data_dict["resolution"][i] + 1)
+        G0, G1, G2 = self.grid_shape
+        index = (voxel[:, 0] * cur + voxel[:, 1]) * cur + voxel[:, 2]
+        own = scatter(feat, index[:, None], dim=0, reduce=self.pool_type,
+                      out=feat.new_zeros((cur ** 3, feat.shape[1])))
+        own = own.view(1, cur, cur, cur, -1).permute(0, 4, 3, 2, 1)          # (1, C, z, y, x)
+        up = F.interpolate(own, size=(G2, G1, G0), mode="trilinear")          # (1, C, G2, G1, G0)
+        if self.dense_channels_last:
+            return up.permute(0, 2, 3, 4, 1).reshape(G0 * G1 * G2, -1)
+        return up.permute(0, 4, 3, 2, 1).reshape(G0 * G1 * G2, -1)
+
     def to_dense(self, data_dict):
-        """Scatter-mean the per-voxel backbone features into a (B, C, Z, Y, X) grid."""
+        """Per-voxel backbone features -> (B, C, Z, Y, X) grid: scatter-mean pooling for scenes at
+        least as large as the grid (one launch for all of them), resize for smaller ones."""
         feat = data_dict["sparse_backbone_feat"]
         B, C = data_dict["offset"].numel(), feat.shape[1]
         G0, G1, G2 = self.grid_shape
+        G = G0 * G1 * G2
         lin = self._dense_rows(data_dict)
-        grid = feat.new_zeros((B * G0 * G1 * G2, C))
+        small = self._small_scenes(data_dict)
+        if small:
+            batch = offset2batch(data_dict["offset"])
+            pooled = torch.ones_like(batch, dtype=torch.bool)
+            for i in small:
+                pooled &= batch != i
+            feat, lin = feat[pooled], lin[pooled]
+        grid = feat.new_zeros((B * G, C))
         grid = scatter(feat, lin[:, None], dim=0, reduce=self.pool_type, out=grid)
+        if small:
+            parts = [self._upsampled_scene(data_dict, i) if i in small else grid[i * G:(i + 1) * G]
+                     for i in range(B)]
+            grid = torch.cat(parts, dim=0)
         if self.dense_channels_last:
             return grid.view(B, G2, G1, G0, C).permute(0, 4, 1, 2, 3)  # channels_last_3d view
         return grid.view(B, G0, G1, G2, C).permute(0, 4, 3, 2, 1).contiguous()
@@ -347,7 +379,7 @@ class PonderIndoor(nn.Module):
 
     def prepare_volume(self, data_dict):
         data_dict = self.grid_sample(data_dict)
-        if self._use_cells():
+        if self._use_cells() and not self._small_scenes(data_dict):
             from .sparse_input import cells_from_voxels
 
             G0, G1, G2 = self.grid_shape

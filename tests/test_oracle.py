@@ -152,3 +152,49 @@ def test_fnv_hash_known_answers():
     assert h.tolist() == expect
     assert ravel_hash_vec(arr).tolist() == [0, (1 * 679 + 2) * 18 + 3, (399 * 679 + 0) * 18 + 17,
                                              (12345 * 679 + 678) * 18 + 9]
+
+
+@pytest.mark.skipif(not ref_shims.reference_available(), reason="reference checkout not present")
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_to_dense_matches_reference_including_small_scenes(channels_last, monkeypatch):
+    """PonderIndoor.to_dense against the reference's method (ponder_indoor_base.py:177-342) on a
+    batch mixing a scene smaller than the grid (resize branch), one larger (pooling branch) and
+    one with resolution == min(grid) (boundary of the branch condition), with gradients."""
+    import types
+
+    from oracle import cpu_backend
+    from ponderv2_amd.ponder.models.ponder.ponder_indoor_base import PonderIndoor
+
+    ref_shims.install()
+    from ponder.models.ponder.ponder_indoor_base import PonderIndoor as RefIndoor  # the reference's
+
+    cpu_backend.install(monkeypatch)
+    grid_shape, grid_size, C = (16, 16, 8), 0.02, 5
+    g = torch.Generator().manual_seed(0)
+    resolutions = [5, 40, 7]          # current_resolution = resolution + 1 -> 6 (<8), 41, 8 (== min)
+    coords, counts = [], []
+    for r in resolutions:
+        n = 60 * (r + 1)
+        coords.append(torch.rand(n, 3, generator=g) * (r + 0.999) * grid_size)
+        counts.append(n)
+    coord = torch.cat(coords)
+    offset = torch.tensor(np.cumsum(counts))
+    feat = torch.randn(len(coord), C, generator=g)
+    probe = torch.randn(3, C, grid_shape[2], grid_shape[1], grid_shape[0], generator=g)
+
+    def run(fn, self_obj):
+        f = feat.clone().requires_grad_(True)
+        out = fn(self_obj, dict(coord=coord.clone(), offset=offset, sparse_backbone_feat=f,
+                                resolution=torch.tensor(resolutions)))
+        (out * probe).sum().backward()
+        return out.detach(), f.grad
+
+    ref_self = types.SimpleNamespace(grid_shape=grid_shape, grid_size=grid_size, pool_type="mean")
+    ours = types.SimpleNamespace(grid_shape=grid_shape, grid_size=grid_size, pool_type="mean",
+                                 dense_channels_last=channels_last)
+    for name in ("_small_scenes", "_dense_rows", "_upsampled_scene"):
+        setattr(ours, name, types.MethodType(getattr(PonderIndoor, name), ours))
+    out_ref, g_ref = run(RefIndoor.to_dense, ref_self)
+    out, g_ours = run(PonderIndoor.to_dense, ours)
+    assert out.shape == out_ref.shape
+    assert torch.allclose(out, out_ref, atol=1e-6) and torch.allclose(g_ours, g_ref, atol=1e-6)
