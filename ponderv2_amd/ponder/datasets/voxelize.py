@@ -66,3 +66,66 @@ class GridSample:
         for k in self.keys:
             data_dict[k] = data_dict[k][idx_unique]
         return data_dict
+
+
+# ---------------------------------------------------------------------------------------------
+# Device-side voxelisation: the same transform on torch tensors, so it
+# can run on the GPU after the raw cloud has been uploaded instead of in a DataLoader worker.
+# ---------------------------------------------------------------------------------------------
+_SIGN = -(1 << 63)
+
+
+def _as_i64(u):
+    u = int(u)
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def fnv_hash_torch(grid):
+    """``fnv_hash_vec`` on an integer tensor: int64 arithmetic wraps mod 2^64 exactly like the
+    uint64 arithmetic of the numpy version, so the BIT PATTERNS of the keys are identical."""
+    import torch
+
+    h = torch.full((grid.shape[0],), _as_i64(_FNV_OFFSET), dtype=torch.int64, device=grid.device)
+    prime = _as_i64(_FNV_PRIME)
+    for j in range(grid.shape[1]):
+        h = (h * prime) ^ grid[:, j].to(torch.int64)
+    return h
+
+
+def ravel_hash_torch(grid):
+    import torch
+
+    a = (grid - grid.amin(0)).to(torch.int64)
+    ext = a.amax(0) + 1
+    keys = torch.zeros(a.shape[0], dtype=torch.int64, device=grid.device)
+    for j in range(a.shape[1] - 1):
+        keys = (keys + a[:, j]) * ext[j + 1]
+    return keys + a[:, -1]
+
+
+def grid_sample_torch(coord, grid_size, hash_type="fnv", pick=None):
+    """Train-mode ``GridSample`` on tensors (any device): -> (idx_unique, grid_coord) with
+    ``idx_unique`` one point index per occupied voxel, voxels in ascending UNSIGNED key order (the
+    order numpy's argsort on uint64 keys produces) and ``grid_coord`` their integer coordinates.
+
+    ``pick`` (n_voxels,) integers plays the role of the reference's
+    ``np.random.randint(0, count.max(), n_voxels)``: the representative of a voxel is its
+    ``pick % count``-th member in point-index order (a stable sort; numpy's unstable argsort may
+    order the members of a voxel differently, so representatives - not voxels - can differ from the
+    host transform even for equal draws).  ``None`` draws them on the tensor's device."""
+    import torch
+
+    scaled = coord.double() / grid_size  # the host transform divides by a float64 array
+    grid = torch.floor(scaled).to(torch.int64)
+    grid = grid - grid.amin(0)
+    key = fnv_hash_torch(grid) if hash_type == "fnv" else ravel_hash_torch(grid)
+    order = torch.sort(key ^ _SIGN, stable=True).indices  # signed order of key^2^63 == unsigned order
+    skey = key[order]
+    first = torch.ones_like(skey, dtype=torch.bool)
+    first[1:] = skey[1:] != skey[:-1]
+    start = torch.nonzero(first).flatten()
+    count = torch.diff(start, append=start.new_tensor([skey.numel()]))
+    if pick is None:
+        pick = torch.randint(0, int(count.max()), (count.numel(),), device=coord.device)
+    idx_unique = order[start + pick.to(start.device) % count]
+    return idx_unique, grid[idx_unique]

@@ -247,3 +247,35 @@ def test_capture_safe_reductions_are_the_plain_ops_outside_capture():
     # the custom Function behind scale_by_scalar, exercised directly (it only engages during capture)
     torch.autograd.gradcheck(cs._ScaleByScalar.apply, (x[:50], s))
     torch.autograd.gradgradcheck(cs._ScaleByScalar.apply, (x[:20], s))
+
+
+@pytest.mark.parametrize("hash_type", ["fnv", "ravel"])
+def test_device_grid_sample_same_voxels_as_host_transform(hash_type):
+    """grid_sample_torch (runs on any device) against the host GridSample: identical hash bit
+    patterns, identical voxel set in identical (unsigned key) order, every representative a member
+    of its voxel."""
+    from ponderv2_amd.ponder.datasets import GridSample, fnv_hash_vec, ravel_hash_vec
+    from ponderv2_amd.ponder.datasets.voxelize import (fnv_hash_torch, grid_sample_torch,
+                                                       ravel_hash_torch)
+
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 500, size=(4000, 3))
+    host_hash = (fnv_hash_vec if hash_type == "fnv" else ravel_hash_vec)(arr)
+    dev_hash = (fnv_hash_torch if hash_type == "fnv" else ravel_hash_torch)(torch.from_numpy(arr))
+    assert np.array_equal(dev_hash.numpy().view(np.uint64), host_hash)
+
+    pts = rng.uniform(-1.5, 2.0, size=(20000, 3)).astype(np.float32)
+    np.random.seed(3)
+    host = GridSample(grid_size=0.05, hash_type=hash_type, mode="train", keys=("coord",),
+                      return_grid_coord=True)(dict(coord=pts.copy()))
+    idx, grid = grid_sample_torch(torch.from_numpy(pts), 0.05, hash_type)
+    assert np.array_equal(grid.numpy(), host["grid_coord"])          # same voxels, same order
+    own = np.floor(pts[idx.numpy()] / 0.05).astype(int) - np.floor(pts / 0.05).astype(int).min(0)
+    assert np.array_equal(own, grid.numpy())                         # representative lies in its voxel
+    assert len(np.unique(idx.numpy())) == len(idx)
+    # with pick == 0 the representative is the lowest point index of the voxel
+    idx0, _ = grid_sample_torch(torch.from_numpy(pts), 0.05, hash_type,
+                                pick=torch.zeros(len(idx), dtype=torch.int64))
+    cell = np.floor(pts / 0.05).astype(int)
+    _, first_member = np.unique(cell, axis=0, return_index=True)
+    assert sorted(idx0.tolist()) == sorted(first_member.tolist())
