@@ -27,6 +27,8 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
+ABI_VERSION = 2
+
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
     "pv2_last_error": (c_char_p, []),
@@ -86,6 +88,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if handle.pv2_abi_version() != ABI_VERSION:  # a stale .so with other signatures
+            raise RuntimeError(f"{LIB_PATH} has ABI version {handle.pv2_abi_version()}, this package "
+                               f"binds version {ABI_VERSION}: rebuild with `make -C ponderv2_amd/csrc`")
         _lib = handle
     return _lib
 
