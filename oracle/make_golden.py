@@ -305,6 +305,60 @@ def transform_chain_case():
     print("transform_chain:", {k: v.shape for k, v in out.items()})
 
 
+PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
+PPT_VALID = (tuple(range(0, 13)), tuple(range(5, 25)), tuple(range(20, 36)))
+
+
+def ponder_ppt_case(ConfigDict):
+    """Reference PonderIndoor.forward over SpUNet-v1m3 (BASELINE config 4 in miniature): context
+    embedding per condition, PDNorm backbone, the condition's valid class subset for the language
+    targets and the ppt loss; one batch of condition "ScanNet" (index 1 of the model's conditions,
+    index 0 of the backbone's)."""
+    from ponder.models.builder import MODELS
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    cfg = _render_cfg()
+    mcfg = cfg.model.to_dict()
+    mcfg["backbone"] = dict(PDNORM_BACKBONE, context_channels=256,
+                            channels=(16, 32, 48, 64, 64, 48, 32, 96))
+    mcfg.update(grid_shape=(32, 32, 8), ray_nsample=20, conditions=PPT_CONDITIONS,
+                class_name=tuple(f"class {i}" for i in range(36)), valid_index=PPT_VALID,
+                template=("a", "b"))
+    ref_shims.install(num_classes=36)
+    torch.manual_seed(0)
+    model = MODELS.build(ConfigDict(mcfg))
+    fill_deterministic(model)
+    model.train()
+    scene_kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64), condition="ScanNet", num_classes=20)
+    batch = collate_fn([make_scene(300, **scene_kw), make_scene(301, **scene_kw)])
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()
+           if not k.endswith("_host")}
+    torch.manual_seed(77)
+    with Recorder() as rec:
+        out = model(inp)
+    out["loss"].backward()
+    B, V, H, W = batch["depth"].shape
+    pix = np.zeros((B, V, 20, 2), dtype=np.int64)
+    it = iter(rec.perm)
+    for b in range(B):
+        for v in range(V):
+            ys, xs = torch.where(batch["depth"][b, v] > 0)
+            sel = next(it)[:20]
+            pix[b, v, :, 0], pix[b, v, :, 1] = ys[sel].numpy(), xs[sel].numpy()
+    params = dict(model.named_parameters())
+    gnames = ["embedding_table.weight", "backbone.conv_input.conv.weight",
+              "backbone.conv_input.bn.modulation.1.weight", "backbone.dec.0.block0.bn2.bns.0.weight",
+              "proj_net.final_conv.bias", "renderer.field.semantic_decoder.lin0.weight"]
+    np.savez_compressed(
+        os.path.join(GOLDEN, "ponder_ppt_small.npz"), ray_pixels=pix, rands=np.array(len(rec.rand)),
+        **{f"rand_{i}": r.numpy() for i, r in enumerate(rec.rand)},
+        out_names=np.array(list(out.keys())), out_values=np.array([float(v) for v in out.values()]),
+        grad_names=np.array(gnames),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    ref_shims.install()  # back to the default 20-class text table
+    print("ponder_ppt_small:", {k: round(float(v), 6) for k, v in out.items()})
+
+
 def main():
     ref_shims.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -312,7 +366,7 @@ def main():
 
     only = sys.argv[1:]
     cases = dict(spunet=spunet_case, neus=lambda: neus_case_impl(ConfigDict),
-                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case, transforms=transform_chain_case,
+                 indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case, transforms=transform_chain_case, ppt=lambda: ponder_ppt_case(ConfigDict),
                  outdoor=lambda: ponder_outdoor_case(ConfigDict))
     for name, fn in cases.items():
         if not only or name in only:

@@ -279,3 +279,40 @@ def run_spunet_pdnorm(device, dtype):
     if dtype == torch.float64:
         return errs
     return errs, cos
+
+
+PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
+PPT_VALID = (tuple(range(0, 13)), tuple(range(5, 25)), tuple(range(20, 36)))
+
+
+def run_ponder_ppt(device):
+    """PonderIndoor over SpUNet-v1m3, batch of condition "ScanNet" (BASELINE config 4 in miniature)."""
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "ponder_ppt_small.npz"))
+    cfg = indoor_model_cfg(dict(PDNORM_BACKBONE, context_channels=256,
+                                channels=(16, 32, 48, 64, 64, 48, 32, 96)),
+                           grid_shape=(32, 32, 8), ray_nsample=20)
+    cfg.update(conditions=PPT_CONDITIONS, class_name=tuple(f"class {i}" for i in range(36)),
+               valid_index=PPT_VALID, template=("a", "b"), graph_render_head=False)
+    model = build_model(ConfigDict(cfg))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
+    kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64), condition="ScanNet", num_classes=20)
+    batch = collate_fn([make_scene(300, **kw), make_scene(301, **kw)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch["ray_pixels"] = torch.from_numpy(g["ray_pixels"])
+    out = model(batch)
+    out["loss"].backward()
+    errs = {}
+    for name, val in zip(g["out_names"], g["out_values"]):
+        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+    params = dict(model.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs

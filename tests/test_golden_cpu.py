@@ -52,3 +52,12 @@ def test_sparse_first_layer_equals_dense_layer(cpu_kernels, with_bn):
 
     errs = sic.run(torch.device("cpu"), torch.float64, with_bn)
     assert max(errs.values()) < 1e-10, errs
+
+
+def test_ponder_ppt_forward_matches_reference(cpu_kernels):
+    """PonderIndoor + SpUNet-v1m3 with three conditions: context embedding, per-condition norm
+    statistics, the condition's valid-class subset in the language targets and the ppt loss."""
+    errs = gc.run_ponder_ppt(torch.device("cpu"))
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    assert max(errs.values()) < 5e-3, errs
