@@ -61,3 +61,38 @@ def test_ponder_ppt_forward_matches_reference(cpu_kernels):
     losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
     assert max(losses.values()) < 1e-4, errs
     assert max(errs.values()) < 5e-3, errs
+
+
+def test_capture_mode_reductions_give_the_same_model_results(cpu_kernels, monkeypatch):
+    """The code paths capture_safe takes WHILE A GRAPH IS BEING CAPTURED (column-sum kernel for
+    the large loss reductions, custom scalar-scale Function, two-step min/max), forced on here on
+    the host with a stand-in for the kernel: the end-to-end indoor golden must still hold, i.e.
+    shapes, dtypes and the first/second-order autograd wiring of those paths are right."""
+    from ponderv2_amd import capture_safe
+
+    class HostColSum(torch.autograd.Function):  # same contract as rownorm._ColSum: (M,1) -> (1,)
+        @staticmethod
+        def forward(ctx, x):
+            assert x.dim() == 2 and x.shape[1] == 1 and x.dtype == torch.float32
+            ctx.rows = x.shape[0]
+            return x.sum(0)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.unsqueeze(0).expand(ctx.rows, -1)
+
+    used = {"n": 0}
+
+    def capturing(t):
+        used["n"] += 1
+        return True
+
+    monkeypatch.setattr(capture_safe, "capturing", capturing)
+    monkeypatch.setattr(capture_safe, "_ColSum", HostColSum)
+    errs = gc.run_ponder_indoor(torch.device("cpu"))
+    assert used["n"] > 10
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    assert max(errs.values()) < 5e-3, errs
+    errs = gc.run_ponder_outdoor(torch.device("cpu"))
+    assert max(v for k, v in errs.items() if not k.startswith("grad_")) < 1e-4, errs

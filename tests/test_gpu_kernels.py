@@ -251,7 +251,7 @@ def test_col_sum(device):
     from ponderv2_amd.rownorm import col_sum
 
     torch.manual_seed(0)
-    for m, n in ((135168, 128), (5000, 65), (70000, 3), (4096, 512)):
+    for m, n in ((135168, 128), (5000, 65), (70000, 3), (4096, 512), (200000, 1)):
         x = torch.randn(m, n)
         got = col_sum(x.to(device)).double().cpu()
         ref = x.double().sum(0)
