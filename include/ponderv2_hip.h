@@ -178,6 +178,30 @@ int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Alpha compositing along rays ("ray march" of SURVEY.md section 8b).  Replaces the cumprod /
+ * elementwise / reduction chain of
+ *   ponder/models/ponder/render_utils/rays.py:83-105   get_weights_and_transmittance_from_alphas
+ *   ponder/models/ponder/render_utils/renderers.py:5-75  RGB / Depth / Normal / Semantic renderers
+ * All arrays fp32, row-major, rays outermost: alpha / weights [n_rays, n_samples],
+ * transmittance [n_rays, n_samples + 1] (optional), values [n_rays, n_samples, n_features].
+ *   weights  : T_s = prod_{j<s}(1 - alpha_j + 1e-7),  w_s = alpha_s * T_s   (n_samples <= 256)
+ *              backward: grad_alpha from grad_weights (the transmittance output carries no gradient)
+ *   accumulate: out[r, f] = sum_s w[r, s] * values[r, s, f]                  (n_features <= 512)
+ *              backward: grad_weights[r, s] = sum_f values * grad_out, grad_values = w * grad_out;
+ *              either output pointer may be NULL
+ * ------------------------------------------------------------------------------------------ */
+int pv2_raymarch_weights_forward(const float* alpha, int64_t n_rays, int n_samples, float* weights,
+                                 float* transmittance_or_null, pv2_stream_t stream);
+int pv2_raymarch_weights_backward(const float* alpha, const float* grad_weights, int64_t n_rays,
+                                  int n_samples, float* grad_alpha, pv2_stream_t stream);
+int pv2_raymarch_accumulate_forward(const float* weights, const float* values, int64_t n_rays,
+                                    int n_samples, int n_features, float* out, pv2_stream_t stream);
+int pv2_raymarch_accumulate_backward(const float* weights, const float* values, const float* grad_out,
+                                     int64_t n_rays, int n_samples, int n_features,
+                                     float* grad_weights_or_null, float* grad_values_or_null,
+                                     pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,
  * reduce="mean"|"sum", out=...) at ponder/models/ponder/ponder_indoor_base.py:214 and
  * ponder_outdoor_base.py:204.

@@ -75,6 +75,38 @@ class _ScatterApply:
         return oracle_scatter(src, index, dim=0, out=out, reduce="mean" if mean else "sum")
 
 
+class _HostCompositeWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alphas):
+        from oracle import raymarch as orm
+
+        ctx.save_for_backward(alphas)
+        w, t = orm.weights_from_alphas(alphas)
+        ctx.mark_non_differentiable(t)
+        return w, t
+
+    @staticmethod
+    def backward(ctx, gw, _gt):
+        from oracle import raymarch as orm
+
+        return orm.grad_alpha_closed_form(ctx.saved_tensors[0], gw)
+
+
+class _HostWeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, values):
+        from oracle import raymarch as orm
+
+        ctx.save_for_backward(weights, values)
+        return orm.weighted_sum(weights, values)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from oracle import raymarch as orm
+
+        return orm.weighted_sum_grads_closed_form(*ctx.saved_tensors, gout)
+
+
 class _Patcher:
     """Minimal monkeypatch look-alike for use outside pytest."""
 
@@ -112,3 +144,10 @@ def install(monkeypatch):
     monkeypatch.setattr(K, "rulebook_from_table", rulebook_from_table)
     monkeypatch.setattr(ts, "ScatterRowsFunction", _ScatterApply)
     monkeypatch.setattr(sdf_field, "SmoothSampler", OracleSampler)
+    # compositing kernels (csrc/raymarch.hip): host doubles that use the kernels' closed-form
+    # gradients, so the opt-in path (raymarch.ENABLED) can be exercised end to end on the host
+    import ponderv2_amd.raymarch as rm
+
+    monkeypatch.setattr(rm, "supported", lambda t, values=None: t.dim() == 3 and t.shape[-1] == 1)
+    monkeypatch.setattr(rm, "composite_weights", _HostCompositeWeights.apply)
+    monkeypatch.setattr(rm, "weighted_sum", _HostWeightedSum.apply)

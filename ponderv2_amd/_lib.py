@@ -57,6 +57,10 @@ SIGNATURES = {
                                _P, _P, _P]),
     "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),
     "pv2_col_sum": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "pv2_raymarch_weights_forward": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "pv2_raymarch_weights_backward": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
+    "pv2_raymarch_accumulate_forward": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
+    "pv2_raymarch_accumulate_backward": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

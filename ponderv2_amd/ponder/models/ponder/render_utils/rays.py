@@ -7,6 +7,8 @@ Plain Python objects here (the reference makes them nn.Modules without parameter
 """
 import torch
 
+from ponderv2_amd import raymarch
+
 
 _CONST_CACHE = {}
 
@@ -67,6 +69,8 @@ class _CumprodNoZero(torch.autograd.Function):
 
 def alphas_to_weights(alphas):
     """w_k = alpha_k * prod_{j<k} (1 - alpha_j + 1e-7); also returns the (S+1) transmittance."""
+    if raymarch.ENABLED and raymarch.supported(alphas):
+        return raymarch.composite_weights(alphas)  # one launch each way (csrc/raymarch.hip)
     ones = torch.ones((alphas.shape[0], 1, 1), device=alphas.device, dtype=alphas.dtype)
     transmittance = _CumprodNoZero.apply(torch.cat([ones, 1.0 - alphas + 1e-7], dim=1))
     return alphas * transmittance[:, :-1, :], transmittance

@@ -3,10 +3,18 @@ depth :31-51 incl. the clip to the global [min, max] of the sample starts :50, n
 semantic :66-75)."""
 import torch
 
+from ponderv2_amd import raymarch
 from ponderv2_amd.capture_safe import rowwise_min_max
 from torch import nn
 
 from .rays import device_constant
+
+
+def _composite(weights, values):
+    """sum over the sample axis of weights (R,S,1) * values (R,S,F) -> (R,F)."""
+    if raymarch.ENABLED and raymarch.supported(weights, values):
+        return raymarch.weighted_sum(weights, values)  # one launch each way (csrc/raymarch.hip)
+    return torch.sum(weights * values, dim=-2)
 
 
 class RGBRenderer(nn.Module):
@@ -15,7 +23,7 @@ class RGBRenderer(nn.Module):
         self.background_color = background_color
 
     def forward(self, rgb, weights):
-        comp = torch.sum(weights * rgb, dim=-2)
+        comp = _composite(weights, rgb)
         acc = torch.sum(weights, dim=-2)
         comp = comp + device_constant(self.background_color, comp.device, comp.dtype) * (1.0 - acc)
         if not self.training:
@@ -26,7 +34,7 @@ class RGBRenderer(nn.Module):
 class DepthRenderer(nn.Module):
     def forward(self, ray_samples, weights):
         steps = ray_samples.frustums.starts
-        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        depth = _composite(weights, steps) / (torch.sum(weights, -2) + 1e-10)
         B = getattr(ray_samples, "num_scenes", 1)
         if B == 1:
             return torch.clip(depth, steps.min(), steps.max())
@@ -39,9 +47,9 @@ class DepthRenderer(nn.Module):
 
 class NormalRenderer(nn.Module):
     def forward(self, normals, weights):
-        return torch.sum(weights * normals, dim=-2)
+        return _composite(weights, normals)
 
 
 class SemanticRenderer(nn.Module):
     def forward(self, semantic, weights):
-        return torch.sum(weights * semantic, dim=-2)
+        return _composite(weights, semantic)

@@ -407,3 +407,48 @@ def test_capture_safe_sum_survives_graph_replay(device):
 def test_aten_large_sum_under_graph_replay_canary(device):
     for got, want in _replay_sums(lambda t: t.sum(), device):
         assert abs(got - want) <= 1e-3 * max(abs(want), 1.0) + 0.5, (got, want)
+
+
+# ------------------------------------------------------------------ compositing (raymarch.hip)
+@pytest.mark.xfail(strict=False, reason="kernels written after the round's GPU budget was spent; first "
+                   "hardware run is the round-end driver's.  Not on the default path yet.")
+@pytest.mark.parametrize("rays,samples", [(1, 1), (5, 64), (1030, 132), (300, 96), (17, 256)])
+def test_raymarch_weights_vs_oracle(device, rays, samples):
+    from oracle import raymarch as orm
+    from ponderv2_amd.raymarch import composite_weights
+
+    torch.manual_seed(rays + samples)
+    alphas = torch.rand(rays, samples, 1) * 0.95
+    if rays > 4:
+        alphas[0, samples // 2:] = 1.0
+        alphas[1] = 0.0
+    gw = torch.randn(rays, samples, 1)
+    w_ref, t_ref = orm.weights_from_alphas(alphas.double())
+    ga_ref = orm.grad_alpha_closed_form(alphas.double(), gw.double())
+    a_dev = alphas.to(device).requires_grad_(True)
+    w, t = composite_weights(a_dev)
+    (ga,) = torch.autograd.grad(w, a_dev, gw.to(device))
+    for name, got, ref in (("weights", w, w_ref), ("transmittance", t, t_ref), ("galpha", ga, ga_ref)):
+        err = (got.double().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        assert err < 1e-5, (name, err)
+
+
+@pytest.mark.xfail(strict=False, reason="kernels written after the round's GPU budget was spent; first "
+                   "hardware run is the round-end driver's.  Not on the default path yet.")
+@pytest.mark.parametrize("features", [1, 3, 31, 32, 128, 131, 512])
+def test_raymarch_weighted_sum_vs_oracle(device, features):
+    from oracle import raymarch as orm
+    from ponderv2_amd.raymarch import weighted_sum
+
+    torch.manual_seed(features)
+    rays, samples = 130, 132
+    w, x = torch.rand(rays, samples, 1), torch.randn(rays, samples, features)
+    gout = torch.randn(rays, features)
+    ref = orm.weighted_sum(w.double(), x.double())
+    gw_ref, gx_ref = orm.weighted_sum_grads_closed_form(w.double(), x.double(), gout.double())
+    w_dev, x_dev = w.to(device).requires_grad_(True), x.to(device).requires_grad_(True)
+    out = weighted_sum(w_dev, x_dev)
+    gw, gx = torch.autograd.grad(out, [w_dev, x_dev], gout.to(device))
+    for name, got, r in (("out", out, ref), ("gw", gw, gw_ref), ("gx", gx, gx_ref)):
+        err = (got.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
+        assert err < 1e-5, (name, err)

@@ -198,3 +198,24 @@ def test_to_dense_matches_reference_including_small_scenes(channels_last, monkey
     out, g_ours = run(PonderIndoor.to_dense, ours)
     assert out.shape == out_ref.shape
     assert torch.allclose(out, out_ref, atol=1e-6) and torch.allclose(g_ours, g_ref, atol=1e-6)
+
+
+def test_compositing_closed_form_gradients():
+    """The backward formulas implemented by csrc/raymarch.hip (restated in oracle/raymarch.py)
+    equal autograd through the reference's cumprod / weighted-sum formulation."""
+    from oracle import raymarch as orm
+
+    g = torch.Generator().manual_seed(0)
+    alphas = (torch.rand(7, 132, 1, generator=g, dtype=torch.double) * 0.9).requires_grad_(True)
+    alphas.data[0, 5:9] = 1.0          # fully opaque samples (factor 1e-7 in the product)
+    alphas.data[1, :] = 0.0            # empty ray
+    values = torch.randn(7, 132, 5, generator=g, dtype=torch.double, requires_grad=True)
+    gout = torch.randn(7, 5, generator=g, dtype=torch.double)
+    w, t = orm.weights_from_alphas(alphas)
+    out = orm.weighted_sum(w, values)
+    ga, gx = torch.autograd.grad(out, [alphas, values], gout, retain_graph=True)
+    (gw,) = torch.autograd.grad(out, w, gout, retain_graph=True)
+    gw_cf, gx_cf = orm.weighted_sum_grads_closed_form(w.detach(), values.detach(), gout)
+    assert torch.allclose(gw, gw_cf) and torch.allclose(gx, gx_cf)
+    assert torch.allclose(ga, orm.grad_alpha_closed_form(alphas.detach(), gw), rtol=1e-9, atol=1e-12)
+    assert t.shape == (7, 133, 1) and torch.allclose(t[:, -1], (1 - alphas + 1e-7).prod(1))
