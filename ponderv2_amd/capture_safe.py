@@ -1,7 +1,9 @@
 """Reductions that stay correct inside a captured hipGraph.
 
-ATen splits a large reduction with few outputs over several workgroups that meet at a semaphore
-array, and clears that array with ``hipMemsetAsync`` right before the launch.  On this ROCm build
+ATen splits a reduction over several workgroups once a thread would fold >= 256 values (>= 131 072
+inputs per output with its 512-thread blocks; torch/include/ATen/native/cuda/Reduce.cuh:1173-1183);
+the workgroups meet at a semaphore array that the kernel only increments (:690-702) and that the
+host clears with ``cudaMemsetAsync`` before every launch (:1294-1301).  On this ROCm build
 memset nodes of a captured graph are not reliably re-executed on replay (csrc/common.h records the
 same finding for this library's own memsets), so from the second replay on the semaphores are stale
 and the reduction's output is whatever its buffer last held.  That is what turned the render head's
