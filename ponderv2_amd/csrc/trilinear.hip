@@ -17,11 +17,13 @@
 //     gV2[ch,c]+= gO[ch] D_c
 //     gG2_b     = sum_ch gO[ch] sum_c ( hV[ch,c] d_b w_c + V[ch,c] sum_a hG_a d_a d_b w_c )
 //
-// Mapping to the machine: ONE WAVE PER SAMPLE POINT, lanes run along the channel axis.  With a
-// channels-last (NDHWC) volume each of the 8 corners is one contiguous C*4-byte read (512 B at
-// C=128) and the volume-gradient atomics are contiguous too; with the reference's NCDHW layout the
-// same kernels still work through the stride descriptor, just uncoalesced.  The three grid
-// gradients are wave-reduced with cross-lane shuffles, no LDS.
+// Mapping to the machine, generic kernels (any strides, float / double): ONE WAVE PER SAMPLE POINT,
+// lanes run along the channel axis.  With a channels-last (NDHWC) volume each of the 8 corners is
+// one contiguous C*4-byte read (512 B at C=128) and the volume-gradient atomics are contiguous
+// too; with the reference's NCDHW layout the same kernels still work through the stride
+// descriptor, just uncoalesced.  The three grid gradients are wave-reduced with cross-lane
+// shuffles, no LDS.  The fp32 channels-last fast path (lane groups per point, float4 corner reads,
+// measured atomic mappings, scrambled visiting order) follows further down.
 #include <cstdlib>
 #include <type_traits>
 

@@ -3,7 +3,8 @@ a column-sum, on the gfx950 kernels of csrc/rownorm.hip.
 
 ``fused_bn(bn_module, x, residual=None, relu=False)`` uses the parameters and running buffers of a
 stock ``nn.BatchNorm1d`` (so state_dicts stay reference-compatible) and computes
-``[relu](bn(x) [+ residual])`` in three short launches; the backward is two.  Anything the kernels
+``[relu](bn(x) [+ residual])`` in two short launches, and two for the backward (the statistics
+kernel's last block finalises them and clears the shared workspace, csrc/rownorm.hip).  Anything the kernels
 do not cover (eval mode, other dtypes, host tensors under the test doubles) takes the module path.
 """
 import torch
