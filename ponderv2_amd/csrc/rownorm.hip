@@ -6,7 +6,8 @@
 // ponder/models/sparse_unet/spconv_unet_v1m1_base.py:70-83 (BasicBlock.forward) and :108,120-121
 // (norm_fn = BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU inside SparseSequential).  59 BN layers
 // per forward make this launch-latency territory: the stock path costs ~5 launches and >50 us per
-// layer per direction; here a layer is 3 short launches (statistics, finalise, apply).
+// layer per direction; here a layer is 2 short launches per direction: statistics (whose
+// last-arriving block also finalises them and clears the workspace) and apply.
 //
 // Layout trick: a 256-thread block views consecutive rows as one flat run of floats; thread t
 // always sees column t % C (C <= 256) so every load is fully coalesced and the per-column partial
