@@ -124,3 +124,48 @@ def test_multi_dataset_trainer_ppt_two_ranks(tmp_path):
     assert sd["backbone.conv_input.bn.bns.1.num_batches_tracked"] == 0
     assert sd["backbone.conv_input.bn.bns.2.num_batches_tracked"] == 2
     assert sd["backbone.conv_input.bn.bns.0.num_batches_tracked"] == 1
+
+
+@pytest.mark.timeout(600)
+def test_resume_continues_from_checkpoint(tmp_path):
+    """CheckpointSaver -> CheckpointLoader(resume=True): the second run starts at the saved epoch
+    with the saved optimiser / scheduler state and trains only the remaining epoch."""
+    import golden_cases as gc
+    from ponderv2_amd.ponder.utils.config import Config
+
+    model = gc.outdoor_model_cfg(dict(gc.SMALL_BACKBONE, in_channels=4,
+                                      channels=(16, 32, 48, 64, 64, 48, 32, 96)), **gc.OUTDOOR_SMALL)
+
+    def cfg(**over):
+        base = dict(
+            weight=None, resume=False, evaluate=False, seed=9, save_path=str(tmp_path), num_worker=0,
+            batch_size=2, epoch=2, eval_epoch=2, sync_bn=False, enable_amp=False, empty_cache=False,
+            find_unused_parameters=True, mix_prob=0, param_dicts=None,
+            hooks=[dict(type="CheckpointLoader"), dict(type="IterationTimer", warmup_iter=0),
+                   dict(type="InformationWriter"), dict(type="CheckpointSaver", save_freq=1)],
+            train=dict(type="MultiDatasetTrainer"), model=model,
+            optimizer=dict(type="AdamW", lr=2e-4, weight_decay=0.01),
+            scheduler=dict(type="OneCycleLR", max_lr=2e-4, pct_start=0.4, anneal_strategy="cos",
+                           div_factor=10.0, final_div_factor=100.0),
+            data=dict(train=dict(type="ConcatDataset", datasets=[
+                dict(type="SyntheticLidarDataset", length=2, base_seed=700, loop=1,
+                     **gc.OUTDOOR_SCENE_KW)])))
+        base.update(over)
+        return Config(base)
+
+    os.makedirs(tmp_path / "model", exist_ok=True)
+    ddp_worker.trainer_main(cfg())                       # two epochs of one iteration each
+    first = torch.load(tmp_path / "model" / "epoch_1.pth", weights_only=False)
+    last = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
+    assert first["epoch"] == 1 and last["epoch"] == 2
+    rows_full = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+    assert len(rows_full) == 2
+    os.remove(tmp_path / "scalars.jsonl")
+    ddp_worker.trainer_main(cfg(weight=str(tmp_path / "model" / "epoch_1.pth"), resume=True))
+    rows_resumed = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+    assert len(rows_resumed) == 1                        # only epoch 2 was run
+    again = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)
+    assert again["epoch"] == 2
+    # same scheduler position as the uninterrupted run
+    assert again["scheduler"]["last_epoch"] == last["scheduler"]["last_epoch"] == 2
+    assert again["optimizer"]["state"][0]["step"] == last["optimizer"]["state"][0]["step"]
