@@ -1,10 +1,12 @@
-"""Batch assembly for point-cloud samples (ponder/datasets/utils.py: collate_fn :16-57,
-point_collate_fn :60-72).
+"""Batch assembly for point-cloud samples (behaviour of ponder/datasets/utils.py: collate_fn
+:16-57, point_collate_fn :60-72).
 
-Per-point tensors of different samples are concatenated along dim 0; every key containing
-"offset" holds one length per sample and becomes the cumulative row count; strings are listed;
-anything else goes through torch's default collation.  ``mix_prob`` merges neighbouring pairs of
-samples into one scene (Mix3D) by dropping every other offset.
+Rules, applied recursively per key: tensors are concatenated along dim 0 (point clouds have no
+common length to stack on); strings are collected into a list; a list-style sample gets its row
+count appended and cumulated; every dict key containing "offset" holds one length per sample and
+becomes the running total of rows; anything else goes through torch's default collation.
+``max_point`` skips samples that would push the batch over a point budget; ``mix_prob`` merges
+neighbouring pairs of samples into one scene (Mix3D) by keeping every second offset.
 """
 import random
 from collections.abc import Mapping, Sequence
@@ -13,36 +15,48 @@ import torch
 from torch.utils.data.dataloader import default_collate
 
 
+def _within_budget(samples, max_point):
+    kept, total = [], 0
+    for sample in samples:
+        n = sample["coord"].shape[0]
+        if total + n > max_point:
+            print("SKIP: accum_num_points", total, "num_coords", n)
+        else:
+            total += n
+            kept.append(sample)
+    return kept
+
+
+def _merge_dicts(samples):
+    merged = {}
+    for key in samples[0]:
+        column = collate_fn([sample[key] for sample in samples])
+        merged[key] = torch.cumsum(column, dim=0) if "offset" in key else column
+    return merged
+
+
+def _merge_lists(samples):
+    for sample in samples:
+        sample.append(torch.tensor([sample[0].shape[0]]))
+    columns = [collate_fn(list(column)) for column in zip(*samples)]
+    columns[-1] = torch.cumsum(columns[-1], dim=0).int()
+    return columns
+
+
 def collate_fn(batch, max_point=-1):
     if not isinstance(batch, Sequence):
         raise TypeError(f"{type(batch)} is not supported.")
-    if max_point > 0:  # drop samples that would push the batch over the point budget
-        kept, total = [], 0
-        for sample in batch:
-            n = sample["coord"].shape[0]
-            if total + n > max_point:
-                print("SKIP: accum_num_points", total, "num_coords", n)
-                continue
-            total += n
-            kept.append(sample)
-        return collate_fn(kept)
-    first = batch[0]
-    if isinstance(first, torch.Tensor):
+    if max_point > 0:
+        return collate_fn(_within_budget(batch, max_point))
+    head = batch[0]
+    if isinstance(head, torch.Tensor):
         return torch.cat(list(batch))
-    if isinstance(first, str):
+    if isinstance(head, str):  # before Sequence: a str is one too
         return list(batch)
-    if isinstance(first, Sequence):  # list-style samples: append the row count, cumulate it
-        for sample in batch:
-            sample.append(torch.tensor([sample[0].shape[0]]))
-        out = [collate_fn(column) for column in zip(*batch)]
-        out[-1] = torch.cumsum(out[-1], dim=0).int()
-        return out
-    if isinstance(first, Mapping):
-        out = {key: collate_fn([sample[key] for sample in batch]) for key in first}
-        for key in out:
-            if "offset" in key:
-                out[key] = torch.cumsum(out[key], dim=0)
-        return out
+    if isinstance(head, Sequence):
+        return _merge_lists(batch)
+    if isinstance(head, Mapping):
+        return _merge_dicts(batch)
     return default_collate(batch)
 
 
@@ -50,6 +64,6 @@ def point_collate_fn(batch, mix_prob=0, max_point=-1):
     assert isinstance(batch[0], Mapping), "only dict samples are supported"
     batch = collate_fn(batch, max_point=max_point)
     if "offset" in batch and random.random() < mix_prob:
-        batch["offset"] = torch.cat([batch["offset"][1:-1:2], batch["offset"][-1].unsqueeze(0)],
-                                    dim=0)
+        offset = batch["offset"]
+        batch["offset"] = torch.cat([offset[1:-1:2], offset[-1:]], dim=0)
     return batch

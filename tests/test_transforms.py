@@ -138,3 +138,37 @@ def test_cameras_follow_the_cloud():
     pts2 = np.concatenate([out["coord"], np.ones((len(out["coord"]), 1), np.float32)], 1)
     after = np.einsum("vij,nj->vni", out["extrinsic"], pts2.astype(np.float64))
     assert np.allclose(before[..., :3], after[..., :3], atol=2e-4)
+
+
+@pytest.mark.skipif(not ref_shims.reference_available(), reason="reference checkout not present")
+def test_point_collate_fn_identical_to_reference():
+    from ponderv2_amd.ponder.datasets import point_collate_fn
+
+    ref_shims.install()
+    U = ref_shims.load_reference_file("ponder/datasets/utils.py")
+    g = torch.Generator().manual_seed(0)
+
+    def sample(n):
+        return dict(coord=torch.randn(n, 3, generator=g), offset=torch.tensor([n]),
+                    ray_offset=torch.tensor([n // 2]), name="scene%d" % n, rgb=torch.randn(1, 2, 4, generator=g),
+                    nested=dict(a=torch.randn(n, 1, generator=g)), scalar=3)
+
+    batch = [sample(5), sample(9), sample(4), sample(7)]
+    for kwargs in (dict(), dict(max_point=20), dict(mix_prob=1.0)):
+        random.seed(1)
+        ours = point_collate_fn([dict(s, nested=dict(s["nested"])) for s in batch], **kwargs)
+        random.seed(1)
+        theirs = U.point_collate_fn([dict(s, nested=dict(s["nested"])) for s in batch], **kwargs)
+        assert sorted(ours) == sorted(theirs)
+        for k in ours:
+            if torch.is_tensor(ours[k]):
+                assert torch.equal(ours[k], theirs[k]) and ours[k].dtype == theirs[k].dtype, (k, kwargs)
+            elif isinstance(ours[k], dict):
+                assert torch.equal(ours[k]["a"], theirs[k]["a"])
+            else:
+                assert ours[k] == theirs[k], (k, kwargs)
+    # list-style samples
+    ours = __import__("ponderv2_amd.ponder.datasets.collate", fromlist=["collate_fn"]).collate_fn(
+        [[torch.ones(3, 2)], [torch.ones(5, 2)]])
+    theirs = U.collate_fn([[torch.ones(3, 2)], [torch.ones(5, 2)]])
+    assert all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(ours, theirs))
