@@ -69,7 +69,8 @@ class _FusedBNFunction(torch.autograd.Function):
 def can_fuse(bn, x):
     """True when the rownorm.hip kernels cover this call (training-mode fp32 device matrix)."""
     return (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() == 2
-            and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled())
+            and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled()
+            and not isinstance(bn, torch.nn.SyncBatchNorm))  # SyncBN reduces across ranks itself
 
 
 def fused_bn(bn, x, residual=None, relu=False, weight=None, bias=None):
