@@ -375,7 +375,8 @@ class PonderIndoor(nn.Module):
 
     def _use_cells(self):
         return (self.sparse_dense_input and self.dense_channels_last and self.pool_type == "mean"
-                and hasattr(self.proj_net, "forward_cells"))
+                and hasattr(self.proj_net, "forward_cells")
+                and getattr(self.proj_net, "cells_supported", lambda: True)())
 
     def prepare_volume(self, data_dict):
         data_dict = self.grid_sample(data_dict)

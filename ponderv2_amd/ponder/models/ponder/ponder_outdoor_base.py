@@ -162,7 +162,8 @@ class PonderOutdoor(nn.Module):
 
     def prepare_volume(self, data_dict):
         if (self.sparse_dense_input and self.dense_channels_last and self.pool_type == "mean"
-                and hasattr(self.proj_net, "forward_cells")):
+                and hasattr(self.proj_net, "forward_cells")
+                and getattr(self.proj_net, "cells_supported", lambda: True)()):
             from .sparse_input import cells_from_voxels
 
             G0, G1, G2 = self.grid_shape[self._condition_index(data_dict)]

@@ -127,16 +127,24 @@ class UNet3Dv1m2(nn.Module):
         if is_segmentation:
             self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
 
+    def cells_supported(self):
+        """The sparse first level needs "bcr" (BatchNorm3d -> Conv3d 3x3x3 -> ReLU) without pooling,
+        and a BatchNorm whose statistics are local to this rank (not SyncBatchNorm)."""
+        first = self.encoders[0]
+        names = [n for n, _ in first.basic_module.named_children()]
+        return (first.pooling is None and names == ["batchnorm", "conv", "ReLU"]
+                and not isinstance(first.basic_module.batchnorm, nn.SyncBatchNorm)
+                and tuple(first.basic_module.conv.kernel_size) == (3, 3, 3))
+
     def forward_cells(self, cells):
         """Forward from the occupied cells of the input grid: level 0 ("bcr": BatchNorm3d -> conv
         -> ReLU on the 96-channel grid, half of this network's FLOPs) is computed sparsely
         (sparse_input.py), the rest of the U-Net runs on its dense output."""
         from .sparse_input import bn_conv_relu_on_cells
 
+        if not self.cells_supported():
+            raise NotImplementedError("forward_cells needs a local BatchNorm3d -> Conv3d(3) -> ReLU first level")
         first = self.encoders[0].basic_module
-        names = [n for n, _ in first.named_children()]
-        if self.encoders[0].pooling is not None or names != ["batchnorm", "conv", "ReLU"]:
-            raise NotImplementedError("forward_cells needs a BatchNorm3d -> Conv3d -> ReLU first level")
         with torch.autocast("cuda", enabled=False):  # the sparse kernels are fp32
             x = bn_conv_relu_on_cells(first.batchnorm, first.conv, cells)
         return self.forward(None, first=x)
