@@ -154,6 +154,14 @@ def test_resume_continues_from_checkpoint(tmp_path):
         return Config(base)
 
     os.makedirs(tmp_path / "model", exist_ok=True)
+    threads = torch.get_num_threads()   # trainer_main pins 2 threads (it is written for spawned ranks)
+    try:
+        _run_and_resume(tmp_path, cfg)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _run_and_resume(tmp_path, cfg):
     ddp_worker.trainer_main(cfg())                       # two epochs of one iteration each
     first = torch.load(tmp_path / "model" / "epoch_1.pth", weights_only=False)
     last = torch.load(tmp_path / "model" / "model_last.pth", weights_only=False)

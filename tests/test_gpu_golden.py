@@ -94,14 +94,8 @@ def test_ponder_outdoor_gpu_vs_reference_golden(device):
     variance network."""
     errs = gc.run_ponder_outdoor(device)
     print(errs)
-    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
-    assert max(losses.values()) < 1e-4, errs
-    # probes inside / upstream of the backbone's BatchNorm chain get the conditioning bound used
-    # for the indoor model (measured here: 2-3e-3); everything downstream of the backbone
-    # (projection conv, SDF MLP, variance) is held to 1e-3 (measured: <= 2e-4)
-    deep = [errs.pop(k) for k in list(errs) if k.startswith("grad_backbone.") or k == "grad_mtoken"]
-    assert len(deep) == 3 and max(deep) < 0.2, deep
-    assert max(errs.values()) < 1e-3, errs
+    # measured on MI355X: loss 3e-6, backbone-chain gradients 2-3e-3, the rest <= 2e-4
+    gc.check_model_errors(errs, rest_tol=1e-3, flip_tol=2e-3)
 
 
 def test_outdoor_graphed_render_head_equals_eager(device):
