@@ -33,15 +33,13 @@ def test_neus_head_gpu_vs_reference_golden(device):
 def test_ponder_indoor_gpu_vs_reference_golden(device):
     errs = gc.run_ponder_indoor(device)
     print(errs)
-    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
-    assert max(losses.values()) < 1e-4, errs  # the north-star bound: loss within 1e-4 relative
-    # The stem weight gradient sits at the end of a backward chain through ~60 BatchNorm layers,
-    # some over a few dozen voxels: on the CPU oracle a 1e-7 relative perturbation of the input
-    # features moves it by 3e-2 (and the dec.0 gradient by 1e-4) while the loss moves by 2e-7.
-    # Its bound reflects that conditioning; every other probe is held to 1e-3.
-    stem = errs.pop("grad_backbone.conv_input.0.weight")
-    assert stem < 0.2, stem
-    assert max(errs.values()) < 1e-3, errs
+    # the north-star bound: loss within 1e-4 relative (measured 4e-6).  The stem weight gradient
+    # sits at the end of a backward chain through ~60 BatchNorm layers, some over a few dozen
+    # voxels: on the CPU oracle a 1e-7 relative perturbation of the input features moves it by
+    # 3e-2 (and the dec.0 gradient by 1e-4) while the loss moves by 2e-7 - hence the separate
+    # bound for backbone-chain gradients; every other probe is held to 1e-3.  flip_tol: see
+    # golden_cases.check_model_errors (one importance sample landing in the neighbouring bin).
+    gc.check_model_errors(errs, rest_tol=1e-3, flip_tol=5e-3)
 
 
 def test_graphed_render_head_equals_eager(device):
@@ -216,8 +214,4 @@ def test_ponder_ppt_gpu_vs_reference_golden(device):
     fused BatchNorm epilogue) against the reference run on the host."""
     errs = gc.run_ponder_ppt(device)
     print(errs)
-    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
-    assert max(losses.values()) < 1e-4, errs
-    deep = [errs.pop(k) for k in list(errs) if k.startswith("grad_backbone.") or k == "grad_embedding_table.weight"]
-    assert max(deep) < 0.2, deep          # backbone-chain conditioning, as in the other goldens
-    assert max(errs.values()) < 2e-3, errs
+    gc.check_model_errors(errs, rest_tol=2e-3, flip_tol=5e-3)
