@@ -56,23 +56,32 @@ def rulebook_from_table(tbl, K, n_in, n_out):
                        torch.from_numpy(np.concatenate(pout).astype(np.int64)), ks)
 
 
+def _no_autocast():
+    """The device kernels are plain fp32 launches that autocast never touches; the doubles behave
+    the same way."""
+    return torch.autocast("cpu", enabled=False)
+
+
 class _ConvIntoApply:
     @staticmethod
     def apply(feats, weight_okc, rb, init):
-        return init + sparse_conv(feats, weight_okc, rb.pair_in, rb.pair_out, rb.kstart_host,
-                                  rb.n_out)
+        with _no_autocast():
+            return init + sparse_conv(feats, weight_okc, rb.pair_in, rb.pair_out, rb.kstart_host,
+                                      rb.n_out)
 
 
 class _ConvApply:
     @staticmethod
     def apply(feats, weight_okc, rb):
-        return sparse_conv(feats, weight_okc, rb.pair_in, rb.pair_out, rb.kstart_host, rb.n_out)
+        with _no_autocast():
+            return sparse_conv(feats, weight_okc, rb.pair_in, rb.pair_out, rb.kstart_host, rb.n_out)
 
 
 class _ScatterApply:
     @staticmethod
     def apply(src, index, out, mean):
-        return oracle_scatter(src, index, dim=0, out=out, reduce="mean" if mean else "sum")
+        with _no_autocast():
+            return oracle_scatter(src, index, dim=0, out=out, reduce="mean" if mean else "sum")
 
 
 class _HostCompositeWeights(torch.autograd.Function):

@@ -279,3 +279,33 @@ def test_device_grid_sample_same_voxels_as_host_transform(hash_type):
     cell = np.floor(pts / 0.05).astype(int)
     _, first_member = np.unique(cell, axis=0, return_index=True)
     assert sorted(idx0.tolist()) == sorted(first_member.tolist())
+
+
+def test_whole_model_autocast_runs_through_the_host_code(monkeypatch):
+    """The reference's ScanNet config trains with enable_amp=True, i.e. the WHOLE model under
+    autocast.  The kernels are fp32 launches autocast never touches; everything around them must
+    hand them fp32 tensors.  Forward + backward of both models under bf16 autocast on the host."""
+    import golden_cases as gc
+    from oracle import cpu_backend
+    from ponderv2_amd.ponder.datasets import (collate_fn, lidar_collate_fn, make_lidar_scene,
+                                              make_scene)
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    cpu_backend.install(monkeypatch)
+    torch.manual_seed(0)
+    small = dict(gc.SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96))
+    indoor = build_model(ConfigDict(gc.indoor_model_cfg(small, grid_shape=(32, 32, 8), ray_nsample=16))).train()
+    kw = dict(n_raw=8000, num_views=2, image_hw=(24, 32))
+    outdoor = build_model(ConfigDict(gc.outdoor_model_cfg(dict(small, in_channels=4),
+                                                          **gc.OUTDOOR_SMALL))).train()
+    cases = [(indoor, collate_fn([make_scene(100, **kw), make_scene(101, **kw)])),
+             (outdoor, lidar_collate_fn([make_lidar_scene(200, **gc.OUTDOOR_SCENE_KW),
+                                         make_lidar_scene(201, **gc.OUTDOOR_SCENE_KW)]))]
+    for model, batch in cases:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = model(batch)
+        out["loss"].backward()
+        assert torch.isfinite(out["loss"])
+        grads = [p.grad for p in model.backbone.parameters() if p.grad is not None]
+        assert grads and all(g.dtype == torch.float32 and torch.isfinite(g).all() for g in grads)
