@@ -202,6 +202,73 @@ int pv2_raymarch_accumulate_backward(const float* weights, const float* values, 
                                      pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused ray march of the NeuS render head (SURVEY.md section 8b `raymarch_{fwd,bwd}`): sampling,
+ * trilinear feature lookup, SDF / colour MLPs on f32 MFMA, grad sdf, NeuS alpha; together with the
+ * compositing entry points above this is the whole per-sample part of
+ *   ponder/models/ponder/render_utils/ray_samplers.py:55-107,227-322,355-463   (samplers)
+ *   ponder/models/ponder/render_utils/rays.py:118-153                          (merge)
+ *   ponder/models/ponder/render_utils/fields/sdf_field.py:122-146,148-197,211-284
+ *   ponder/models/ponder/render_utils/decoders.py:6-76
+ * for the shipped head shape (configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:33-57): volume
+ * [B, Z, Y, X, 128] channels-last fp32, first 64 channels -> SDF MLP (hidden 128, one block,
+ * Softplus(beta=100)) -> 1 + 64, colour head 134 -> 3 with no hidden block, points_factor 0, zeros
+ * padding, align_corners.  pv2_neus_head_dims reports the compiled-in widths.  Layers without an
+ * activation between them are passed COLLAPSED (row-major fp32):
+ *   mw [256,64] = [W0 Wc0 ; Wc1], c0 [128] = W0 bc0 + b0, bc1 [128], w1 [65,128], b1 [65],
+ *   m_t [64,128] = (mw[:128])^T, q0 [64] = mw[128:]^T w1[0], a_rgb [3,134] = Wr1 Wrc,
+ *   b_rgb [3] = Wr1 brc + br1, inv_s [1] (device scalar), w1g_t [128,64] = (w1[1:])^T,
+ *   wc1_t [64,128] = (mw[128:])^T.
+ * Rays are scene-major with n_rays / vol_b rays per scene; sample n = ray * n_samples + k.
+ *
+ * coarse_sample: per ray, n_coarse stratified bins (lin_bins [n_coarse+1] = linspace(0,1); t_rand
+ *   [n_rays, 1 | n_coarse+1] or NULL), SDF of the UN-normalised start positions, fixed-inv_s
+ *   weights, n_importance inverse-CDF samples (lin_u [n_importance+1] = linspace(0, 1-1/nb, nb);
+ *   u_rand [n_rays, 1 | nb] or NULL), sorted merge.  Writes bins [n_rays, S+1] (spacing), starts and
+ *   deltas [n_rays, S] (ray distance), S = n_coarse + n_importance.  dbg_* may be NULL.
+ * field_forward: per sample sdf, alpha and the value row
+ *   values[n, 140] = f'(64) geo(64) grad(3) normal(3) rgb(3) t 1 0
+ *   (composite it with pv2_raymarch_weights_forward + pv2_raymarch_accumulate_forward), and the
+ *   activations the backward needs: save_f [N,64], save_h0 [N,128], save_a1 [N,128], save_q [N,64].
+ * field_backward: given g_alpha [N] (pv2_raymarch_weights_backward of the accumulate backward's
+ *   grad_weights), weights [N], g_comp [n_rays,140] (gradient of the composited value row), optional
+ *   g_sdf [N] / g_grad [N,3]: writes gfeat [N,128], gvec [N,4] (total d loss / d grad sdf), the
+ *   weight-gradient GEMM operands gz [N,256] = [gh0 | ga1], tmat [N,128], gq [N,64], gh [N,68] =
+ *   [gsdf, ggeo, 0..], gy [N,4], the column sums `sums` (layout in raymarch_fused.hip; length from
+ *   pv2_neus_head_dims) and, when grad_volume != NULL (ZERO-initialised or holding other
+ *   contributions), scatter-adds the volume gradient including the second-order term.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_neus_head_dims(int* hidden, int* f_sdf, int* f_rest, int* geo, int* value_row, int* sums_len);
+int pv2_neus_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                           int vol_c, const float* origins, const float* dirs, const float* nears,
+                           const float* fars, int64_t n_rays, int n_coarse, int n_importance,
+                           const float* lin_bins, const float* t_rand, int t_rand_cols,
+                           const float* lin_u, const float* u_rand, int u_rand_cols,
+                           const float* mw, const float* c0, const float* bc1, const float* w1,
+                           const float* b1, float base_inv_s, float* bins_out, float* starts_out,
+                           float* deltas_out, int32_t* dbg_idx, float* dbg_sdf, float* dbg_w,
+                           pv2_stream_t stream);
+int pv2_neus_field_forward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                           int vol_c, const float* origins, const float* dirs, const float* starts,
+                           const float* deltas, int64_t n_rays, int n_samples, const float* mw,
+                           const float* c0, const float* bc1, const float* w1, const float* b1,
+                           const float* m_t, const float* q0, const float* a_rgb,
+                           const float* b_rgb, const float* inv_s, int norm_pts, float norm_div,
+                           float* sdf, float* alpha, float* values, float* save_f, float* save_h0,
+                           float* save_a1, float* save_q, pv2_stream_t stream);
+int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                            int vol_c, const float* origins, const float* dirs, const float* starts,
+                            const float* deltas, int64_t n_rays, int n_samples, const float* mw,
+                            const float* w1, const float* m_t, const float* w1g_t,
+                            const float* wc1_t, const float* a_rgb, const float* inv_s,
+                            int norm_pts, float norm_div, const float* sdf, const float* values,
+                            const float* save_h0, const float* save_q, const float* weights,
+                            const float* g_alpha, const float* g_sdf, const float* g_grad,
+                            const float* g_comp, float* gfeat, float* gvec, float* gz, float* tmat,
+                            float* gq, float* gh, float* gy, float* sums, float* grad_volume,
+                            pv2_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------
  * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,
  * reduce="mean"|"sum", out=...) at ponder/models/ponder/ponder_indoor_base.py:214 and
  * ponder_outdoor_base.py:204.

@@ -116,6 +116,52 @@ class _HostWeightedSum(torch.autograd.Function):
         return orm.weighted_sum_grads_closed_form(*ctx.saved_tensors, gout)
 
 
+class _HostFieldRender(torch.autograd.Function):
+    """Host double of ponderv2_amd.fused_head.field_render: forward from the restatement, backward
+    from the HAND-DERIVED formulas the HIP kernels implement (oracle/fused_head.py)."""
+
+    @staticmethod
+    def forward(ctx, vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
+                norm_pts, norm_div):
+        from oracle import fused_head as fh
+
+        args = [t.detach() for t in (vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A,
+                                     b_rgb, inv_s.reshape(()))]
+        ctx.save_for_backward(*args)
+        ctx.norm = (bool(norm_pts), float(norm_div) - 1.0 - 10e-4)
+        ctx.inv_s_shape = inv_s.shape
+        with torch.no_grad():
+            out = fh.field_render(*args, norm_pts=ctx.norm[0], norm_padding=ctx.norm[1])
+        ctx.mark_non_differentiable(out["weights"])
+        return out["sdf"], out["grad"], out["weights"], out["comp"]
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad, _gw, g_comp):
+        from oracle import fused_head as fh
+
+        args = ctx.saved_tensors
+        R, S = args[3].shape
+        z = lambda g, shape: torch.zeros(shape, dtype=args[0].dtype) if g is None else g
+        g = fh.field_render_backward(*args, z(g_sdf, (R, S)), z(g_grad, (R, S, 3)),
+                                     z(g_comp, (R, args[0].shape[-1] + 12)),
+                                     norm_pts=ctx.norm[0], norm_padding=ctx.norm[1])
+        return (g["vol"], None, None, None, None, g["MW"], g["c0"], g["bc1"], g["W1"], g["b1"], g["A"],
+                g["b_rgb"], g["inv_s"].reshape(ctx.inv_s_shape), None, None)
+
+
+def _host_coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_rand,
+                        n_importance, MW, c0, bc1, W1, b1, base_inv_s, debug=False):
+    from oracle import fused_head as fh
+
+    with torch.no_grad():
+        res = fh.coarse_sample(vol5, origins, dirs, nears, fars, lin_bins.to(vol5.dtype), t_rand,
+                               u_rand, n_importance, MW, c0, bc1, W1[0], b1[0], base_inv_s,
+                               return_debug=debug)
+        bins, dbg = res if debug else (res, None)
+        starts, deltas = fh.bins_to_samples(bins, nears, fars)
+    return (bins, starts, deltas, dbg) if debug else (bins, starts, deltas)
+
+
 class _Patcher:
     """Minimal monkeypatch look-alike for use outside pytest."""
 
@@ -160,3 +206,9 @@ def install(monkeypatch):
     monkeypatch.setattr(rm, "supported", lambda t, values=None: t.dim() == 3 and t.shape[-1] == 1)
     monkeypatch.setattr(rm, "composite_weights", _HostCompositeWeights.apply)
     monkeypatch.setattr(rm, "weighted_sum", _HostWeightedSum.apply)
+    # fused ray march (csrc/raymarch_fused.hip): host doubles from oracle/fused_head.py
+    import ponderv2_amd.fused_head as fhead
+
+    monkeypatch.setattr(fhead, "device_ok", lambda t: True)
+    monkeypatch.setattr(fhead, "coarse_sample", _host_coarse_sample)
+    monkeypatch.setattr(fhead, "field_render", _HostFieldRender.apply)

@@ -27,7 +27,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -61,6 +61,16 @@ SIGNATURES = {
     "pv2_raymarch_weights_backward": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "pv2_raymarch_accumulate_forward": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_raymarch_accumulate_backward": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "pv2_neus_head_dims": (c_int, [POINTER(c_int)] * 6),
+    "pv2_neus_coarse_sample": (
+        c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P,
+                c_int, _P, _P, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pv2_neus_field_forward": (
+        c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int] + [_P] * 10
+        + [c_int, c_float] + [_P] * 7 + [_P]),
+    "pv2_neus_field_backward": (
+        c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int] + [_P] * 7
+        + [c_int, c_float] + [_P] * 9 + [_P] * 9 + [_P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

@@ -1,0 +1,1108 @@
+// Fused ray-march kernels of the NeuS render head for gfx950 (MI355X).
+//
+// Stand in for the per-sample part of the reference's render head, which the stock path runs as
+// ~1000 small autograd ops per step (paths relative to the reference checkout):
+//   ponder/models/ponder/render_utils/ray_samplers.py:55-107   stratified uniform bins
+//   .../ray_samplers.py:355-463                                coarse SDF pass + fixed-inv_s weights
+//   .../ray_samplers.py:227-322, rays.py:118-153               inverse-CDF importance samples + merge
+//   .../fields/sdf_field.py:122-146,148-197,211-284            feature lookup, SDF MLP, grad sdf, alpha
+//   .../decoders.py:6-76                                       SDF / colour heads
+//
+// Head shape served (the shipped ScanNet configuration, configs/scannet/pretrain-ponder-spunet-
+// v1m1-0-base.py:33-57): 128-channel channels-last volume split 64 | 64 (share_volume=False),
+// SDF MLP 64 -> 128 -(softplus beta=100)-> 128 -> 1+64 with ONE hidden block, colour head with
+// none, points_factor = 0, zeros padding / align_corners / no smoothstep.  Layers without an
+// activation between them arrive COLLAPSED (host side, by torch, so autograd reaches the
+// nn.Linear parameters):
+//     MW = [W0 Wc0 ; Wc1] (2H x F)   c0 = W0 bc0 + b0   bc1   W1 (1+G x H)   b1
+//     A  = Wr1 Wrc (3 x 134)         b_rgb = Wr1 brc + br1
+//
+// Per sample k (p = point in grid-normalised [0,1]^3, f | f' = trilinear features, J = d f / d p):
+//     h0 = M f + c0      s0 = softplus(h0)   sg = softplus'(h0)   a1 = s0 + Wc1 f + bc1
+//     [sdf ; geo] = W1 a1 + b1               t = W1[0] * sg       q = M^T t + Wc1^T W1[0]
+//     g = J^T q  (= grad sdf, by a second 64-channel gather: g_a = sum_c dw_c/dp_a <V[:64,c], q>)
+//     rgb = sigmoid(A [g, f', geo, d] + b_rgb)
+//     alpha = clip((e1 - e2 + 1e-5) / (e1 + 1e-5), 0, 1),  e1/2 = sigmoid(inv_s (sdf -/+ min(g.d,0) delta/2))
+// Backward (hand-derived, second-order terms through g included; oracle/fused_head.py states the
+// same formulas in torch and tests check them against autograd):
+//     gq = J gg  (gather with weights D_c = sum_a gg_a dw_c/dp_a)       gt = M gq
+//     ga1 = W1^T [gsdf ; ggeo]       gh0 = ga1 sg + gt W1[0] softplus''(h0)
+//     gf  = M^T gh0 + Wc1^T ga1      gV[:, c] += w_c [gf ; gf'] + D_c [q ; 0]
+//
+// Mapping to the machine: one wave owns a tile of 32 consecutive samples; the tile's activation
+// matrices live in wave-private LDS (two 32 x 132 fp32 buffers) and every matrix product is a
+// 32-row f32 MFMA GEMM (v_mfma_f32_32x32x2_f32: A from LDS, 16 bytes per lane along the reduction
+// axis, B = the weight rows straight from L2, same 16-byte pieces, so no operand is transposed).
+// Feature gathers use lane groups (32 lanes x float4 = 128 channels, 16 lanes x float4 = 64) on the
+// channels-last volume.  The coarse pass is one workgroup per ray: its S0 <= 128 samples are staged
+// in LDS, and the fixed-inv_s weights, the inverse-CDF samples and the sorted merge never leave it.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kH = 128;   // hidden width of the SDF MLP
+constexpr int kF = 64;    // volume channels feeding the SDF MLP
+constexpr int kF2 = 64;   // volume channels feeding the colour / semantic heads
+constexpr int kG = 64;    // geometry feature width
+constexpr int kC = kF + kF2;
+constexpr int kNV = 140;  // per-sample value row: f'(64) geo(64) g(3) n(3) rgb(3) t 1 0
+constexpr int kLd = kC + 4;       // LDS row stride of a 32-row tile (conflict-free b128 reads)
+constexpr int kNA = 3 + kF2 + kG + 3;  // colour head input width (134)
+constexpr int kGH = 68;   // row width of the [gsdf, ggeo] operand (1+G padded to a multiple of 4)
+
+struct Vol {
+  const float* p;
+  int B, Z, Y, X;
+  int64_t rays_per_scene;
+};
+
+struct Head {
+  const float* MW;    // [2H, F]
+  const float* c0;    // [H]
+  const float* bc1;   // [H]
+  const float* W1;    // [1+G, H]
+  const float* b1;    // [1+G]
+  const float* Mt;    // [F, H]   (MW[:H])^T
+  const float* q0;    // [F]      MW[H:]^T W1[0]
+  const float* A;     // [3, kNA]
+  const float* brgb;  // [3]
+  const float* inv_s; // [1]
+  const float* W1gt;  // [H, G]   (W1[1:])^T        (backward only)
+  const float* Wc1t;  // [F, H]   (MW[H:])^T        (backward only)
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// torch.nn.Softplus(beta=100, threshold=20) and its first two derivatives
+__device__ __forceinline__ void softplus100(float h, float* sp, float* d1, float* d2) {
+  const float bx = 100.f * h;
+  if (bx > 20.f) {
+    *sp = h;
+    *d1 = 1.f;
+    *d2 = 0.f;
+  } else {
+    const float e = expf(bx);
+    *sp = log1pf(e) * 0.01f;
+    const float s = e / (1.f + e);
+    *d1 = s;
+    *d2 = 100.f * s * (1.f - s);
+  }
+}
+
+// Trilinear corner model, zeros padding, align_corners, no smoothstep.  p in [0,1]^3 (x, y, z).
+struct Axes {
+  int ix, iy, iz;
+  float tx, ty, tz;
+};
+
+__device__ __forceinline__ Axes make_axes(float px, float py, float pz, const Vol& v) {
+  Axes a;
+  const float x = px * (float)(v.X - 1), y = py * (float)(v.Y - 1), z = pz * (float)(v.Z - 1);
+  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+  a.tx = x - fx;
+  a.ty = y - fy;
+  a.tz = z - fz;
+  // clamp before the int conversion: far-away points (the coarse pass samples un-normalised
+  // coordinates) must not overflow; any index outside [-1, size] is out of bounds either way
+  a.ix = (int)fminf(fmaxf(fx, -2.f), (float)v.X + 1.f);
+  a.iy = (int)fminf(fmaxf(fy, -2.f), (float)v.Y + 1.f);
+  a.iz = (int)fminf(fmaxf(fz, -2.f), (float)v.Z + 1.f);
+  return a;
+}
+
+// corner c (bit0 = x, bit1 = y, bit2 = z): in-bounds flag, element offset of its channel 0, weight
+// and d weight / d p (0 when out of bounds)
+__device__ __forceinline__ bool corner(const Axes& a, const Vol& v, int scene, int c, int64_t* off,
+                                       float* w, float* dx, float* dy, float* dz) {
+  const int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+  const int x = a.ix + bx, y = a.iy + by, z = a.iz + bz;
+  const bool ok = x >= 0 && x < v.X && y >= 0 && y < v.Y && z >= 0 && z < v.Z;
+  const float wx = bx ? a.tx : 1.f - a.tx, wy = by ? a.ty : 1.f - a.ty, wz = bz ? a.tz : 1.f - a.tz;
+  const float sx = (bx ? 1.f : -1.f) * (float)(v.X - 1);
+  const float sy = (by ? 1.f : -1.f) * (float)(v.Y - 1);
+  const float sz = (bz ? 1.f : -1.f) * (float)(v.Z - 1);
+  *off = ok ? ((((int64_t)scene * v.Z + z) * v.Y + y) * v.X + x) * kC : 0;
+  *w = ok ? wx * wy * wz : 0.f;
+  *dx = ok ? sx * wy * wz : 0.f;
+  *dy = ok ? wx * sy * wz : 0.f;
+  *dz = ok ? wx * wy * sz : 0.f;
+  return ok;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// D = A (32 x K, LDS rows of stride lda) . W[n0:n0+32*NB, 0:K]^T ; W row-major with row stride ldw.
+// Lane (i, h): A fragment = 16 bytes of row i at k = kk + 4h.., B fragment = the same 16 bytes of
+// weight row n; result element (row (r&3)+8(r>>2)+4h, column nb*32+i) in acc[nb][r].
+template <int NB>
+__device__ __forceinline__ void tile_gemm(const float* sA, int lda, const float* __restrict__ W,
+                                          int ldw, int K, f32x16 (&acc)[NB], int lane) {
+  const int i = lane & 31, h = lane >> 5;
+  const float* arow = sA + i * lda + 4 * h;
+  const float* wrow = W + (int64_t)i * ldw + 4 * h;
+#pragma unroll 2
+  for (int kk = 0; kk < K; kk += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(arow + kk);
+    float4 b[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b[nb] = ldg4(wrow + (int64_t)nb * 32 * ldw + kk);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nb].x, acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nb].y, acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nb].z, acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nb].w, acc[nb], 0, 0, 0);
+    }
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// sum over the 32 lanes that share h (the column direction of an accumulator block)
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+
+// SDF MLP up to a1 for a 32-row feature tile in sF (columns 0..F-1).  Leaves a1 in `a1` and
+// t = W1[0] * softplus'(h0) in `tt` (accumulator layout); h0 goes to `save_h0` when given.
+__device__ __forceinline__ void mlp_hidden(const float* sF, int lda, const Head& P, int lane,
+                                           f32x16 (&a1)[4], f32x16 (&tt)[4], float* save_h0,
+                                           int64_t base, int64_t n_total) {
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[4];
+  zero_acc(acc);
+  tile_gemm<4>(sF, lda, P.MW, kF, kF, acc, lane);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int col = nb * 32 + i;
+    const float cb = P.c0[col], v1 = P.W1[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float h0 = acc[nb][r] + cb;
+      if (save_h0) {
+        const int64_t n = base + acc_row(r, h);
+        if (n < n_total) save_h0[n * kH + col] = h0;
+      }
+      float sp, d1, d2;
+      softplus100(h0, &sp, &d1, &d2);
+      a1[nb][r] = sp;
+      tt[nb][r] = v1 * d1;
+    }
+  }
+  zero_acc(acc);
+  tile_gemm<4>(sF, lda, P.MW + kH * kF, kF, kF, acc, lane);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const float bb = P.bc1[nb * 32 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[nb][r] += acc[nb][r] + bb;
+  }
+}
+
+// sdf of each tile row from a1 (accumulator layout) into s_sdf[32] (LDS)
+__device__ __forceinline__ void sdf_rows(const f32x16 (&a1)[4], const Head& P, int lane,
+                                         float* s_sdf) {
+  const int i = lane & 31, h = lane >> 5;
+  const float b = P.b1[0];
+  float v1[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) v1[nb] = P.W1[nb * 32 + i];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float p = a1[0][r] * v1[0] + a1[1][r] * v1[1] + a1[2][r] * v1[2] + a1[3][r] * v1[3];
+    p = half_wave_sum(p);
+    if (i == 0) s_sdf[acc_row(r, h)] = p + b;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void store_acc_lds(float* sD, int ldd, const f32x16 (&acc)[NB], int lane) {
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sD[acc_row(r, h) * ldd + nb * 32 + i] = acc[nb][r];
+}
+
+// The sample's point: ray r = n / S, distance t, optional normalisation into the unit cube
+// (sdf_field.py:58-74)
+__device__ __forceinline__ void sample_point(int64_t n, int S, const float* __restrict__ origins,
+                                             const float* __restrict__ dirs,
+                                             const float* __restrict__ starts, int norm_pts,
+                                             float norm_div, float* p) {
+  const int64_t ray = n / S;
+  const float t = starts[n];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float v = origins[ray * 3 + a] + dirs[ray * 3 + a] * t;
+    if (norm_pts) {
+      v = v / norm_div + 0.5f;
+      if (v >= 1.f) v = 1.f - 10e-4f;
+      if (v < 0.f) v = 0.f;
+    }
+    p[a] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Main pass, forward.  One wave per 32-sample tile.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void field_fwd_kernel(
+    Vol vol, Head P, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ starts, const float* __restrict__ deltas, int64_t n_total, int S,
+    int norm_pts, float norm_div, float* __restrict__ sdf_out, float* __restrict__ alpha_out,
+    float* __restrict__ vals, float* __restrict__ save_f, float* __restrict__ save_h0,
+    float* __restrict__ save_a1, float* __restrict__ save_q) {
+  __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
+  __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
+  __shared__ float s_pt[32 * 4];
+  __shared__ float s_g[32 * 4];
+  __shared__ float s_sdf[32];
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int64_t base = (int64_t)blockIdx.x * 32;
+
+  if (lane < 32) {
+    const int64_t n = base + lane;
+    float p[3] = {0.f, 0.f, 0.f};
+    float scene = 0.f;
+    if (n < n_total) {
+      sample_point(n, S, origins, dirs, starts, norm_pts, norm_div, p);
+      scene = (float)((n / S) / vol.rays_per_scene);
+    }
+    s_pt[lane * 4 + 0] = p[0];
+    s_pt[lane * 4 + 1] = p[1];
+    s_pt[lane * 4 + 2] = p[2];
+    s_pt[lane * 4 + 3] = scene;
+  }
+  __syncthreads();
+
+  // 128-channel gather: 32 lanes x float4 per sample, two samples per pass
+  {
+    const int cq = lane & 31, sub = lane >> 5;
+#pragma unroll 2
+    for (int pass = 0; pass < 16; ++pass) {
+      const int s = pass * 2 + sub;
+      const int64_t n = base + s;
+      const Axes ax = make_axes(s_pt[s * 4 + 0], s_pt[s * 4 + 1], s_pt[s * 4 + 2], vol);
+      const int scene = (int)s_pt[s * 4 + 3];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < n_total) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int64_t off;
+          float w, dx, dy, dz;
+          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
+            const float4 v = ldg4(vol.p + off + 4 * cq);
+            acc.x += w * v.x;
+            acc.y += w * v.y;
+            acc.z += w * v.z;
+            acc.w += w * v.w;
+          }
+        }
+        if (cq < kF / 4) *reinterpret_cast<float4*>(save_f + n * kF + 4 * cq) = acc;
+        else *reinterpret_cast<float4*>(vals + n * kNV + 4 * (cq - kF / 4)) = acc;
+      }
+      *reinterpret_cast<float4*>(&bufA[s * kLd + 4 * cq]) = acc;
+    }
+  }
+  __syncthreads();
+
+  f32x16 a1[4], tt[4];
+  mlp_hidden(bufA, kLd, P, lane, a1, tt, save_h0, base, n_total);
+  store_acc_lds<4>(bufB, kLd, a1, lane);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t n = base + acc_row(r, h);
+      if (n < n_total) save_a1[n * kH + nb * 32 + i] = a1[nb][r];
+    }
+  sdf_rows(a1, P, lane, s_sdf);
+  __syncthreads();
+
+  // geo = a1 . W1[1:]^T + b1[1:]  -> bufA columns 0..63 (f is no longer needed there), vals
+  {
+    f32x16 geo[2];
+    zero_acc(geo);
+    tile_gemm<2>(bufB, kLd, P.W1 + kH, kH, kH, geo, lane);
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = nb * 32 + i;
+      const float bb = P.b1[1 + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, h);
+        const float v = geo[nb][r] + bb;
+        bufA[row * kLd + col] = v;
+        const int64_t n = base + row;
+        if (n < n_total) vals[n * kNV + kF2 + col] = v;
+      }
+    }
+  }
+  // q = t . M + q0 : t -> bufB, then the GEMM against M^T rows
+  store_acc_lds<4>(bufB, kLd, tt, lane);
+  __syncthreads();
+  {
+    f32x16 q[2];
+    zero_acc(q);
+    tile_gemm<2>(bufB, kLd, P.Mt, kH, kH, q, lane);
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = nb * 32 + i;
+      const float qb = P.q0[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, h);
+        const float v = q[nb][r] + qb;
+        bufB[row * kLd + col] = v;
+        const int64_t n = base + row;
+        if (n < n_total) save_q[n * kF + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // g = J^T q : second gather over the SDF half of the channels, 16 lanes x float4 per sample
+  {
+    const int cq = lane & 15, sub = lane >> 4;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int s = pass * 4 + sub;
+      const Axes ax = make_axes(s_pt[s * 4 + 0], s_pt[s * 4 + 1], s_pt[s * 4 + 2], vol);
+      const int scene = (int)s_pt[s * 4 + 3];
+      const float4 qv = *reinterpret_cast<const float4*>(&bufB[s * kLd + 4 * cq]);
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int64_t off;
+        float w, dx, dy, dz;
+        float d = 0.f;
+        if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) d = dot4(ldg4(vol.p + off + 4 * cq), qv);
+        gx += dx * d;
+        gy += dy * d;
+        gz += dz * d;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        gx += __shfl_xor(gx, o);
+        gy += __shfl_xor(gy, o);
+        gz += __shfl_xor(gz, o);
+      }
+      if (cq == 0) {
+        s_g[s * 4 + 0] = gx;
+        s_g[s * 4 + 1] = gy;
+        s_g[s * 4 + 2] = gz;
+      }
+    }
+  }
+  __syncthreads();
+
+  // per-sample scalars: lane (i, h) owns sample i; h = 0 sums the f' terms, h = 1 the geo terms
+  {
+    const int64_t n = base + i;
+    const bool valid = n < n_total;
+    const float* xrow = bufA + i * kLd + (h ? 0 : kF);          // geo | f'
+    const int acol = 3 + (h ? kF2 : 0);
+    float y[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = 0; j < 64; j += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + j);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* ar = P.A + c * kNA + acol + j;
+        y[c] += xv.x * ar[0] + xv.y * ar[1] + xv.z * ar[2] + xv.w * ar[3];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] += __shfl_xor(y[c], 32);
+    if (h == 0 && valid) {
+      const int64_t ray = n / S;
+      const float g0 = s_g[i * 4 + 0], g1 = s_g[i * 4 + 1], g2 = s_g[i * 4 + 2];
+      const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
+      float rgb[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* ar = P.A + c * kNA;
+        const float yy = y[c] + ar[0] * g0 + ar[1] * g1 + ar[2] * g2 + ar[kNA - 3] * d0 +
+                         ar[kNA - 2] * d1 + ar[kNA - 1] * d2 + P.brgb[c];
+        rgb[c] = sigmoidf_(yy);
+      }
+      const float gn = fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-12f);
+      const float sdf = s_sdf[i];
+      const float cosv = g0 * d0 + g1 * d1 + g2 * d2;
+      const float half = fminf(cosv, 0.f) * deltas[n] * 0.5f;
+      const float inv_s = P.inv_s[0];
+      const float e1 = sigmoidf_((sdf - half) * inv_s), e2 = sigmoidf_((sdf + half) * inv_s);
+      float alpha = (e1 - e2 + 1e-5f) / (e1 + 1e-5f);
+      alpha = fminf(fmaxf(alpha, 0.f), 1.f);
+      sdf_out[n] = sdf;
+      alpha_out[n] = alpha;
+      float* v = vals + n * kNV + kF2 + kG;
+      v[0] = g0;
+      v[1] = g1;
+      v[2] = g2;
+      v[3] = g0 / gn;
+      v[4] = g1 / gn;
+      v[5] = g2 / gn;
+      v[6] = rgb[0];
+      v[7] = rgb[1];
+      v[8] = rgb[2];
+      v[9] = starts[n];
+      v[10] = 1.f;
+      v[11] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Main pass, backward.  One wave per 32-sample tile.  Consumes d alpha (from the compositing
+// backward), the weights, the upstream gradient of the composited row per ray and of sdf / grad
+// per sample; produces d feature (for the volume scatter), gg (d loss / d grad sdf, total), the
+// operands of the weight-gradient GEMMs and the bias-like column sums (atomics into `sums`).
+// sums layout: c0[H] bc1[H] v1x[H] b1[1+G -> 68] qsum[F] brgb[4] inv_s[1]
+// ------------------------------------------------------------------------------------------
+constexpr int kSumC0 = 0, kSumBc1 = kH, kSumV1 = 2 * kH, kSumB1 = 3 * kH, kSumQ = 3 * kH + kGH,
+              kSumRgb = kSumQ + kF, kSumInvS = kSumRgb + 4, kSumTotal = kSumInvS + 4;
+
+__global__ __launch_bounds__(64) void field_bwd_kernel(
+    Vol vol, Head P, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ starts, const float* __restrict__ deltas, int64_t n_total, int S,
+    int norm_pts, float norm_div, const float* __restrict__ sdf_in, const float* __restrict__ vals,
+    const float* __restrict__ save_h0, const float* __restrict__ weights,
+    const float* __restrict__ g_alpha, const float* __restrict__ g_sdf_up,
+    const float* __restrict__ g_grad_up, const float* __restrict__ g_comp,
+    float* __restrict__ gfeat, float* __restrict__ gvec, float* __restrict__ gz,
+    float* __restrict__ tmat, float* __restrict__ gq, float* __restrict__ gh,
+    float* __restrict__ gy_out, float* __restrict__ sums) {
+  __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
+  __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
+  __shared__ float s_pt[32 * 4];
+  __shared__ float s_gg[32 * 4];
+  __shared__ float s_coef[32 * 4];
+  __shared__ float s_gs[32];
+  __shared__ int s_ray[32];
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int64_t base = (int64_t)blockIdx.x * 32;
+
+  // ---- per-sample scalars (lanes 0..31)
+  {
+    float inv_part = 0.f, gyv[3] = {0.f, 0.f, 0.f}, gs = 0.f;
+    if (lane < 32) {
+      const int64_t n = base + lane;
+      float p[3] = {0.f, 0.f, 0.f}, gg[3] = {0.f, 0.f, 0.f};
+      float scene = 0.f, wk = 0.f;
+      int ray = 0;
+      if (n < n_total) {
+        sample_point(n, S, origins, dirs, starts, norm_pts, norm_div, p);
+        ray = (int)(n / S);
+        scene = (float)(ray / vol.rays_per_scene);
+        const float* v = vals + n * kNV + kF2 + kG;
+        const float g0 = v[0], g1 = v[1], g2 = v[2];
+        const float n0 = v[3], n1 = v[4], n2 = v[5];
+        const float rgb[3] = {v[6], v[7], v[8]};
+        const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
+        const float* u = g_comp + (int64_t)ray * kNV + kF2 + kG;  // g(3) n(3) rgb(3) t 1
+        wk = weights[n];
+        // alpha -> sdf, cos, inv_s
+        const float sdf = sdf_in[n], dl = deltas[n], inv_s = P.inv_s[0];
+        const float cosv = g0 * d0 + g1 * d1 + g2 * d2;
+        const float half = fminf(cosv, 0.f) * dl * 0.5f;
+        const float e1 = sigmoidf_((sdf - half) * inv_s), e2 = sigmoidf_((sdf + half) * inv_s);
+        const float raw = (e1 - e2 + 1e-5f) / (e1 + 1e-5f);
+        const float graw = (raw >= 0.f && raw <= 1.f) ? g_alpha[n] : 0.f;
+        const float ge1 = graw * e2 / ((e1 + 1e-5f) * (e1 + 1e-5f));
+        const float ge2 = -graw / (e1 + 1e-5f);
+        const float gu1 = ge1 * e1 * (1.f - e1), gu2 = ge2 * e2 * (1.f - e2);
+        gs = (g_sdf_up ? g_sdf_up[n] : 0.f) + inv_s * (gu1 + gu2);
+        const float ghalf = inv_s * (gu2 - gu1);
+        inv_part = gu1 * (sdf - half) + gu2 * (sdf + half);
+        const float gc = cosv < 0.f ? ghalf * dl * 0.5f : 0.f;
+        gg[0] = gc * d0;
+        gg[1] = gc * d1;
+        gg[2] = gc * d2;
+        if (g_grad_up) {
+          gg[0] += g_grad_up[n * 3 + 0];
+          gg[1] += g_grad_up[n * 3 + 1];
+          gg[2] += g_grad_up[n * 3 + 2];
+        }
+        // normal composite: n = g / max(|g|, eps)
+        const float gn = fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-12f);
+        const float m0 = wk * u[3], m1 = wk * u[4], m2 = wk * u[5];
+        const float nd = n0 * m0 + n1 * m1 + n2 * m2;
+        gg[0] += (m0 - n0 * nd) / gn + wk * u[0];
+        gg[1] += (m1 - n1 * nd) / gn + wk * u[1];
+        gg[2] += (m2 - n2 * nd) / gn + wk * u[2];
+        // colour head
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gyv[c] = wk * u[6 + c] * rgb[c] * (1.f - rgb[c]);
+          const float* ar = P.A + c * kNA;
+          gg[0] += gyv[c] * ar[0];
+          gg[1] += gyv[c] * ar[1];
+          gg[2] += gyv[c] * ar[2];
+        }
+        gvec[n * 4 + 0] = gg[0];
+        gvec[n * 4 + 1] = gg[1];
+        gvec[n * 4 + 2] = gg[2];
+        gvec[n * 4 + 3] = 0.f;
+        gy_out[n * 4 + 0] = gyv[0];
+        gy_out[n * 4 + 1] = gyv[1];
+        gy_out[n * 4 + 2] = gyv[2];
+        gy_out[n * 4 + 3] = 0.f;
+        gh[n * kGH + 0] = gs;
+        gh[n * kGH + 1 + kG + 0] = 0.f;
+        gh[n * kGH + 1 + kG + 1] = 0.f;
+        gh[n * kGH + 1 + kG + 2] = 0.f;
+      }
+      s_pt[lane * 4 + 0] = p[0];
+      s_pt[lane * 4 + 1] = p[1];
+      s_pt[lane * 4 + 2] = p[2];
+      s_pt[lane * 4 + 3] = scene;
+      s_gg[lane * 4 + 0] = gg[0];
+      s_gg[lane * 4 + 1] = gg[1];
+      s_gg[lane * 4 + 2] = gg[2];
+      s_coef[lane * 4 + 0] = wk;
+      s_coef[lane * 4 + 1] = gyv[0];
+      s_coef[lane * 4 + 2] = gyv[1];
+      s_coef[lane * 4 + 3] = gyv[2];
+      s_gs[lane] = gs;
+      s_ray[lane] = ray;
+    }
+    // column sums of this tile: inv_s, b_rgb, b1[0]
+    float r0 = inv_part, r1 = gyv[0], r2 = gyv[1], r3 = gyv[2], r4 = gs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      r0 += __shfl_xor(r0, o);
+      r1 += __shfl_xor(r1, o);
+      r2 += __shfl_xor(r2, o);
+      r3 += __shfl_xor(r3, o);
+      r4 += __shfl_xor(r4, o);
+    }
+    if (lane == 0) {
+      unsafeAtomicAdd(sums + kSumInvS, r0);
+      unsafeAtomicAdd(sums + kSumRgb + 0, r1);
+      unsafeAtomicAdd(sums + kSumRgb + 1, r2);
+      unsafeAtomicAdd(sums + kSumRgb + 2, r3);
+      unsafeAtomicAdd(sums + kSumB1, r4);
+    }
+  }
+  __syncthreads();
+
+  // ---- d f' and d geo: w_k u_ray + sum_c gy_c A[c, .]; lane j owns column j of both
+  {
+    const float af[3] = {P.A[0 * kNA + 3 + lane], P.A[1 * kNA + 3 + lane], P.A[2 * kNA + 3 + lane]};
+    const float ag[3] = {P.A[0 * kNA + 3 + kF2 + lane], P.A[1 * kNA + 3 + kF2 + lane],
+                         P.A[2 * kNA + 3 + kF2 + lane]};
+    float geo_sum = 0.f;
+    for (int s = 0; s < 32; ++s) {
+      const int64_t n = base + s;
+      const float wk = s_coef[s * 4 + 0], y0 = s_coef[s * 4 + 1], y1 = s_coef[s * 4 + 2],
+                  y2 = s_coef[s * 4 + 3];
+      const float* u = g_comp + (int64_t)s_ray[s] * kNV;
+      float gf2 = 0.f, ggeo = 0.f;
+      if (n < n_total) {
+        gf2 = wk * u[lane] + y0 * af[0] + y1 * af[1] + y2 * af[2];
+        ggeo = wk * u[kF2 + lane] + y0 * ag[0] + y1 * ag[1] + y2 * ag[2];
+        gfeat[n * kC + kF + lane] = gf2;
+        gh[n * kGH + 1 + lane] = ggeo;
+      }
+      bufA[s * kLd + lane] = ggeo;
+      geo_sum += ggeo;
+    }
+    unsafeAtomicAdd(sums + kSumB1 + 1 + lane, geo_sum);
+  }
+
+  // ---- gq = J gg : 64-channel gather with the weights D_c = sum_a gg_a d_a w_c
+  {
+    const int cq = lane & 15, sub = lane >> 4;
+    float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int s = pass * 4 + sub;
+      const int64_t n = base + s;
+      const Axes ax = make_axes(s_pt[s * 4 + 0], s_pt[s * 4 + 1], s_pt[s * 4 + 2], vol);
+      const int scene = (int)s_pt[s * 4 + 3];
+      const float a0 = s_gg[s * 4 + 0], a1 = s_gg[s * 4 + 1], a2 = s_gg[s * 4 + 2];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < n_total) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int64_t off;
+          float w, dx, dy, dz;
+          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
+            const float D = a0 * dx + a1 * dy + a2 * dz;
+            const float4 v = ldg4(vol.p + off + 4 * cq);
+            acc.x += D * v.x;
+            acc.y += D * v.y;
+            acc.z += D * v.z;
+            acc.w += D * v.w;
+          }
+        }
+        *reinterpret_cast<float4*>(gq + n * kF + 4 * cq) = acc;
+      }
+      *reinterpret_cast<float4*>(&bufB[s * kLd + 4 * cq]) = acc;
+      qsum.x += acc.x;
+      qsum.y += acc.y;
+      qsum.z += acc.z;
+      qsum.w += acc.w;
+    }
+    qsum.x += __shfl_xor(qsum.x, 16);
+    qsum.y += __shfl_xor(qsum.y, 16);
+    qsum.z += __shfl_xor(qsum.z, 16);
+    qsum.w += __shfl_xor(qsum.w, 16);
+    qsum.x += __shfl_xor(qsum.x, 32);
+    qsum.y += __shfl_xor(qsum.y, 32);
+    qsum.z += __shfl_xor(qsum.z, 32);
+    qsum.w += __shfl_xor(qsum.w, 32);
+    if (sub == 0) {
+      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 0, qsum.x);
+      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 1, qsum.y);
+      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 2, qsum.z);
+      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 3, qsum.w);
+    }
+  }
+  __syncthreads();
+
+  // ---- gt = gq . M^T (K = F), ga1 = ggeo . W1[1:] (K = G) + gsdf (x) W1[0]
+  f32x16 gt[4], ga1[4];
+  zero_acc(gt);
+  zero_acc(ga1);
+  tile_gemm<4>(bufB, kLd, P.MW, kF, kF, gt, lane);
+  tile_gemm<4>(bufA, kLd, P.W1gt, kG, kG, ga1, lane);
+  __syncthreads();  // both tiles consumed: bufA / bufB are free again
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int col = nb * 32 + i;
+    const float v1 = P.W1[col];
+    float s_c0 = 0.f, s_bc1 = 0.f, s_v1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, h);
+      const int64_t n = base + row;
+      const bool valid = n < n_total;
+      const float a = ga1[nb][r] + s_gs[row] * v1;
+      float sp, d1 = 0.f, d2 = 0.f;
+      if (valid) softplus100(save_h0[n * kH + col], &sp, &d1, &d2);
+      const float g0 = a * d1 + gt[nb][r] * v1 * d2;
+      s_c0 += g0;
+      s_bc1 += valid ? a : 0.f;
+      s_v1 += gt[nb][r] * d1;
+      bufB[row * kLd + col] = g0;
+      bufA[row * kLd + col] = valid ? a : 0.f;
+      if (valid) {
+        gz[n * (2 * kH) + col] = g0;
+        gz[n * (2 * kH) + kH + col] = a;
+        tmat[n * kH + col] = v1 * d1;
+      }
+    }
+    s_c0 += __shfl_xor(s_c0, 32);
+    s_bc1 += __shfl_xor(s_bc1, 32);
+    s_v1 += __shfl_xor(s_v1, 32);
+    if (h == 0) {
+      unsafeAtomicAdd(sums + kSumC0 + col, s_c0);
+      unsafeAtomicAdd(sums + kSumBc1 + col, s_bc1);
+      unsafeAtomicAdd(sums + kSumV1 + col, s_v1);
+    }
+  }
+  __syncthreads();
+
+  // ---- gf = gh0 . M + ga1 . Wc1  (K = H each)
+  {
+    f32x16 gf[2];
+    zero_acc(gf);
+    tile_gemm<2>(bufB, kLd, P.Mt, kH, kH, gf, lane);
+    tile_gemm<2>(bufA, kLd, P.Wc1t, kH, kH, gf, lane);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t n = base + acc_row(r, h);
+        if (n < n_total) gfeat[n * kC + nb * 32 + i] = gf[nb][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Volume-gradient scatter: gV[corner c] += w_c gfeat + D_c [q ; 0].  One wave per sample, lane =
+// channel (128-byte contiguous atomic runs), samples visited in a scrambled order so that the
+// waves in flight do not hold consecutive samples of one ray (which share corner voxels).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void volume_scatter_kernel(
+    Vol vol, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ starts, int64_t n_total, int S, int norm_pts, float norm_div,
+    const float* __restrict__ gfeat, const float* __restrict__ gvec, const float* __restrict__ q,
+    float* __restrict__ gvol, uint32_t perm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_total; it += nw) {
+    const int64_t n = perm ? (int64_t)((uint64_t)it * perm % (uint64_t)n_total) : it;
+    float p[3];
+    sample_point(n, S, origins, dirs, starts, norm_pts, norm_div, p);
+    const int scene = (int)((n / S) / vol.rays_per_scene);
+    const Axes ax = make_axes(p[0], p[1], p[2], vol);
+    const float a0 = gvec[n * 4 + 0], a1 = gvec[n * 4 + 1], a2 = gvec[n * 4 + 2];
+    const float glo = gfeat[n * kC + lane], ghi = gfeat[n * kC + 64 + lane];
+    const float qv = q[n * kF + lane];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int64_t off;
+      float w, dx, dy, dz;
+      if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
+        const float D = a0 * dx + a1 * dy + a2 * dz;
+        unsafeAtomicAdd(gvol + off + lane, w * glo + D * qv);
+        unsafeAtomicAdd(gvol + off + 64 + lane, w * ghi);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Coarse pass + importance sampling: one workgroup per ray, one wave per 32 coarse samples.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxS0 = 128;
+constexpr int kMaxImp = 63;
+constexpr int kLdF = kF + 4;
+
+__device__ __forceinline__ float lerp_rn(float lo, float hi, float t) {
+  return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t));
+}
+__device__ __forceinline__ float to_euclid(float x, float nearv, float farv) {
+  return __fadd_rn(__fmul_rn(x, farv), __fmul_rn(__fsub_rn(1.f, x), nearv));
+}
+
+__global__ __launch_bounds__(256) void coarse_sample_kernel(
+    Vol vol, Head P, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ nears, const float* __restrict__ fars, int S0, int n_imp,
+    const float* __restrict__ lin_bins, const float* __restrict__ t_rand, int t_rand_cols,
+    const float* __restrict__ lin_u, const float* __restrict__ u_rand, int u_rand_cols,
+    float base_inv_s, float* __restrict__ bins_out, float* __restrict__ starts_out,
+    float* __restrict__ deltas_out, int32_t* __restrict__ dbg_idx, float* __restrict__ dbg_sdf,
+    float* __restrict__ dbg_w) {
+  __shared__ __attribute__((aligned(16))) float s_f[4][32 * kLdF];
+  __shared__ float s_bins[kMaxS0 + 1], s_e[kMaxS0 + 1], s_sdf[kMaxS0], s_cos[kMaxS0],
+      s_alpha[kMaxS0], s_w[kMaxS0], s_cdf[kMaxS0 + 1], s_new[kMaxImp + 1],
+      s_out[kMaxS0 + kMaxImp + 2];
+  __shared__ float s_scalar[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t ray = blockIdx.x;
+  const float nearv = nears[ray], farv = fars[ray];
+  const int nthreads = blockDim.x;
+
+  // spacing bin edges (ray_samplers.py:70-88) and their ray distances
+  for (int j = tid; j <= S0; j += nthreads) {
+    float b = lin_bins[j];
+    if (t_rand) {
+      const float lo = j == 0 ? lin_bins[0] : __fmul_rn(__fadd_rn(lin_bins[j], lin_bins[j - 1]), 0.5f);
+      const float hi = j == S0 ? lin_bins[S0] : __fmul_rn(__fadd_rn(lin_bins[j + 1], lin_bins[j]), 0.5f);
+      const float t = t_rand[ray * t_rand_cols + (t_rand_cols == 1 ? 0 : j)];
+      b = lerp_rn(lo, hi, t);
+    }
+    s_bins[j] = b;
+    s_e[j] = to_euclid(b, nearv, farv);
+  }
+  __syncthreads();
+
+  // SDF at the start positions (NOT normalised: neus.py:17-21 / SURVEY Q1)
+  if (wave * 32 < S0) {
+    const int scene = (int)(ray / vol.rays_per_scene);
+    const float o0 = origins[ray * 3 + 0], o1 = origins[ray * 3 + 1], o2 = origins[ray * 3 + 2];
+    const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
+    float* sF = s_f[wave];
+    const int cq = lane & 15, sub = lane >> 4;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int s = pass * 4 + sub;
+      const int k = wave * 32 + s;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < S0) {
+        const float t = s_e[k];
+        const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          int64_t off;
+          float w, dx, dy, dz;
+          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
+            const float4 v = ldg4(vol.p + off + 4 * cq);
+            acc.x += w * v.x;
+            acc.y += w * v.y;
+            acc.z += w * v.z;
+            acc.w += w * v.w;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&sF[s * kLdF + 4 * cq]) = acc;
+    }
+  }
+  __syncthreads();
+  if (wave * 32 < S0) {
+    f32x16 a1[4], tt[4];
+    mlp_hidden(s_f[wave], kLdF, P, lane, a1, tt, nullptr, 0, 0);
+    // (s_sdf rows beyond S0 land in the padding of the kMaxS0 array)
+    sdf_rows(a1, P, lane, s_sdf + wave * 32);
+  }
+  __syncthreads();
+
+  // fixed-inv_s section alphas (ray_samplers.py:426-463)
+  const int n1 = S0 - 1;
+  for (int j = tid; j < n1; j += nthreads) {
+    const float dist = __fsub_rn(s_e[j + 1], s_e[j]);
+    s_cos[j] = (s_sdf[j + 1] - s_sdf[j]) / (dist + 1e-5f);
+  }
+  __syncthreads();
+  for (int j = tid; j < n1; j += nthreads) {
+    const float dist = __fsub_rn(s_e[j + 1], s_e[j]);
+    const float prev = j > 0 ? s_cos[j - 1] : 0.f;
+    const float cv = fminf(fmaxf(fminf(prev, s_cos[j]), -1e3f), 0.f);
+    const float mid = (s_sdf[j] + s_sdf[j + 1]) * 0.5f;
+    const float pc = sigmoidf_((mid - cv * dist * 0.5f) * base_inv_s);
+    const float nc = sigmoidf_((mid + cv * dist * 0.5f) * base_inv_s);
+    s_alpha[j] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+  }
+  __syncthreads();
+
+  // weights (rays.py:83-105) and the padded pdf / cdf of PDFSampler (ray_samplers.py:243-262)
+  if (wave == 0) {
+    float a[2], x[2];
+    float prod = 1.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane * 2 + u;
+      a[u] = j < n1 ? s_alpha[j] : 0.f;
+      x[u] = j < n1 ? 1.f - a[u] + 1e-7f : 1.f;
+      prod *= x[u];
+    }
+    float incl = prod;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(incl, o);
+      if (lane >= o) incl *= up;
+    }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.f;
+    float w[2], wsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      w[u] = a[u] * T;   // 0 for j >= n1 (a = 0): the appended zero weight of sample S0-1
+      T *= x[u];
+      wsum += w[u];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) wsum += __shfl_xor(wsum, o);
+    const float pad = fmaxf(1e-5f - wsum, 0.f);
+    const float den = wsum + pad;
+    float pdf[2], run = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane * 2 + u;
+      if (j < S0) s_w[j] = w[u];
+      pdf[u] = j < S0 ? (w[u] + pad / (float)S0) / den : 0.f;
+      run += pdf[u];
+    }
+    float incs = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(incs, o);
+      if (lane >= o) incs += up;
+    }
+    float before = incs - run;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane * 2 + u;
+      before += pdf[u];
+      if (j < S0) s_cdf[j + 1] = fminf(1.f, before);
+    }
+    if (lane == 0) s_cdf[0] = 0.f;
+  }
+  __syncthreads();
+
+  // inverse-CDF samples (ray_samplers.py:263-313)
+  const int nb = n_imp + 1;
+  for (int m = tid; m < nb; m += nthreads) {
+    float u = lin_u[m];
+    if (u_rand) u = __fadd_rn(u, u_rand[ray * u_rand_cols + (u_rand_cols == 1 ? 0 : m)] / (float)nb);
+    else u = __fadd_rn(u, 1.f / (float)(2 * nb));
+    int idx = 0;  // searchsorted(cdf, u, right=True): number of entries <= u
+    for (int j = 0; j <= S0; ++j) idx += s_cdf[j] <= u ? 1 : 0;
+    const int below = min(max(idx - 1, 0), S0), above = min(max(idx, 0), S0);
+    const float c0 = s_cdf[below], c1 = s_cdf[above], b0 = s_bins[below], b1 = s_bins[above];
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.f;
+    const float t = fminf(fmaxf(__fsub_rn(u, c0) / den, 0.f), 1.f);
+    s_new[m] = lerp_rn(b0, b1, t);
+    if (dbg_idx) dbg_idx[ray * nb + m] = idx;
+  }
+  __syncthreads();
+
+  // sorted merge of the S0 coarse and n_imp new spacing starts (rays.py:118-153); both lists are
+  // non-decreasing, so every element's output slot is its own index plus a count in the other list
+  for (int j = tid; j < S0; j += nthreads) {
+    const float v = s_bins[j];
+    int pos = j;
+    for (int m = 0; m < n_imp; ++m) pos += s_new[m] < v ? 1 : 0;
+    s_out[pos] = v;
+  }
+  for (int m = tid; m < n_imp; m += nthreads) {
+    const float v = s_new[m];
+    int pos = m;
+    for (int j = 0; j < S0; ++j) pos += s_bins[j] <= v ? 1 : 0;
+    s_out[pos] = v;
+  }
+  const int S = S0 + n_imp;
+  if (tid == 0) s_out[S] = fmaxf(s_bins[S0], s_new[n_imp]);
+  __syncthreads();
+  for (int j = tid; j <= S; j += nthreads) {
+    bins_out[ray * (S + 1) + j] = s_out[j];
+    if (j < S) {
+      const float e0 = to_euclid(s_out[j], nearv, farv), e1 = to_euclid(s_out[j + 1], nearv, farv);
+      starts_out[ray * S + j] = e0;
+      deltas_out[ray * S + j] = __fsub_rn(e1, e0);
+    }
+  }
+  if (dbg_sdf)
+    for (int j = tid; j < S0; j += nthreads) {
+      dbg_sdf[ray * S0 + j] = s_sdf[j];
+      dbg_w[ray * S0 + j] = s_w[j];
+    }
+  (void)s_scalar;
+}
+
+inline uint32_t scramble_for(int64_t n) {
+  if (n < 64 || n >= 0x7fffffffLL) return 0;
+  for (uint32_t a : {7919u, 7907u, 7901u, 7883u})
+    if (n % a != 0) return a;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_neus_head_dims(int* hidden, int* f_sdf, int* f_rest, int* geo, int* value_row, int* sums_len) {
+  *hidden = kH;
+  *f_sdf = kF;
+  *f_rest = kF2;
+  *geo = kG;
+  *value_row = kNV;
+  *sums_len = kSumTotal;
+  return PV2_OK;
+}
+
+#define PV2_VOL_CHECK(name)                                                                      \
+  PV2_REQUIRE(vol_b >= 1 && vol_z >= 2 && vol_y >= 2 && vol_x >= 2, name ": bad volume shape");  \
+  PV2_REQUIRE(vol_c == kC, name ": the volume must have 128 channels (channels-last)");          \
+  PV2_REQUIRE(n_rays >= 0 && (n_rays % vol_b) == 0, name ": rays must split evenly over scenes")
+
+int pv2_neus_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                           int vol_c, const float* origins, const float* dirs, const float* nears,
+                           const float* fars, int64_t n_rays, int n_coarse, int n_importance,
+                           const float* lin_bins, const float* t_rand, int t_rand_cols,
+                           const float* lin_u, const float* u_rand, int u_rand_cols,
+                           const float* mw, const float* c0, const float* bc1, const float* w1,
+                           const float* b1, float base_inv_s, float* bins_out, float* starts_out,
+                           float* deltas_out, int32_t* dbg_idx, float* dbg_sdf, float* dbg_w,
+                           pv2_stream_t stream) {
+  PV2_VOL_CHECK("pv2_neus_coarse_sample");
+  PV2_REQUIRE(n_coarse >= 2 && n_coarse <= kMaxS0, "pv2_neus_coarse_sample: 2 <= n_coarse <= 128");
+  PV2_REQUIRE(n_importance >= 1 && n_importance <= kMaxImp,
+              "pv2_neus_coarse_sample: 1 <= n_importance <= 63");
+  PV2_REQUIRE(t_rand == nullptr || t_rand_cols == 1 || t_rand_cols == n_coarse + 1,
+              "pv2_neus_coarse_sample: t_rand must have 1 or n_coarse+1 columns");
+  PV2_REQUIRE(u_rand == nullptr || u_rand_cols == 1 || u_rand_cols == n_importance + 1,
+              "pv2_neus_coarse_sample: u_rand must have 1 or n_importance+1 columns");
+  PV2_REQUIRE((dbg_sdf == nullptr) == (dbg_w == nullptr), "pv2_neus_coarse_sample: debug outputs");
+  if (n_rays == 0) return PV2_OK;
+  PV2_REQUIRE(n_rays < 0x7fffffffLL, "pv2_neus_coarse_sample: too many rays");
+  Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
+  Head P{};
+  P.MW = mw;
+  P.c0 = c0;
+  P.bc1 = bc1;
+  P.W1 = w1;
+  P.b1 = b1;
+  const int waves = (n_coarse + 31) / 32;
+  hipLaunchKernelGGL(coarse_sample_kernel, dim3((unsigned)n_rays), dim3(64 * waves), 0,
+                     (hipStream_t)stream, v, P, origins, dirs, nears, fars, n_coarse, n_importance,
+                     lin_bins, t_rand, t_rand_cols, lin_u, u_rand, u_rand_cols, base_inv_s, bins_out,
+                     starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w);
+  return pv2::check_launch("neus_coarse_sample");
+}
+
+int pv2_neus_field_forward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                           int vol_c, const float* origins, const float* dirs, const float* starts,
+                           const float* deltas, int64_t n_rays, int n_samples, const float* mw,
+                           const float* c0, const float* bc1, const float* w1, const float* b1,
+                           const float* m_t, const float* q0, const float* a_rgb,
+                           const float* b_rgb, const float* inv_s, int norm_pts, float norm_div,
+                           float* sdf, float* alpha, float* values, float* save_f, float* save_h0,
+                           float* save_a1, float* save_q, pv2_stream_t stream) {
+  PV2_VOL_CHECK("pv2_neus_field_forward");
+  PV2_REQUIRE(n_samples >= 1, "pv2_neus_field_forward: n_samples");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_field_forward: too many samples");
+  Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
+  Head P{mw, c0, bc1, w1, b1, m_t, q0, a_rgb, b_rgb, inv_s, nullptr, nullptr};
+  hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0,
+                     (hipStream_t)stream, v, P, origins, dirs, starts, deltas, n_total, n_samples,
+                     norm_pts, norm_div, sdf, alpha, values, save_f, save_h0, save_a1, save_q);
+  return pv2::check_launch("neus_field_forward");
+}
+
+int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                            int vol_c, const float* origins, const float* dirs, const float* starts,
+                            const float* deltas, int64_t n_rays, int n_samples, const float* mw,
+                            const float* w1, const float* m_t, const float* w1g_t,
+                            const float* wc1_t, const float* a_rgb, const float* inv_s,
+                            int norm_pts, float norm_div, const float* sdf, const float* values,
+                            const float* save_h0, const float* save_q, const float* weights,
+                            const float* g_alpha, const float* g_sdf, const float* g_grad,
+                            const float* g_comp, float* gfeat, float* gvec, float* gz, float* tmat,
+                            float* gq, float* gh, float* gy, float* sums, float* grad_volume,
+                            pv2_stream_t stream) {
+  PV2_VOL_CHECK("pv2_neus_field_backward");
+  PV2_REQUIRE(n_samples >= 1, "pv2_neus_field_backward: n_samples");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_field_backward: too many samples");
+  hipStream_t s = (hipStream_t)stream;
+  Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
+  Head P{mw, nullptr, nullptr, w1, nullptr, m_t, nullptr, a_rgb, nullptr, inv_s, w1g_t, wc1_t};
+  int st = pv2::zero_words(sums, kSumTotal, s);
+  if (st != PV2_OK) return st;
+  hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
+                     origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
+                     values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
+                     gq, gh, gy, sums);
+  st = pv2::check_launch("neus_field_backward");
+  if (st != PV2_OK || grad_volume == nullptr) return st;
+  // grad_volume must be zero-initialised by the caller (it may already hold other contributions)
+  const int64_t waves = n_total < 256 * 8 * 4 ? n_total : 256 * 8 * 4;
+  hipLaunchKernelGGL(volume_scatter_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, v,
+                     origins, dirs, starts, n_total, n_samples, norm_pts, norm_div, gfeat, gvec,
+                     save_q, grad_volume, scramble_for(n_total));
+  return pv2::check_launch("neus_volume_scatter");
+}
+
+}  // extern "C"

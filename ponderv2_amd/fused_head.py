@@ -1,0 +1,332 @@
+"""The NeuS render head on the fused ray-march kernels of csrc/raymarch_fused.hip.
+
+Per render pass the per-sample work of the reference's head (paths relative to the reference
+checkout: render_utils/models/neus.py:16-36, ray_samplers.py:55-107,227-322,355-463,
+rays.py:83-153, fields/sdf_field.py:122-284, decoders.py:6-109, renderers.py:5-75) becomes
+
+    forward : coarse_sample (1 launch: stratified bins, coarse SDF, fixed-inv_s weights, inverse-CDF
+              samples, merge)  ->  field forward (1 launch: feature gather, SDF MLP on MFMA, grad sdf,
+              colour head, alpha)  ->  weights (1)  ->  composite of the 140-wide value row (1)
+    backward: composite bwd (1) -> weights bwd (1) -> field backward (1) -> volume scatter (1)
+              -> 4 weight-gradient GEMMs
+
+``render_outputs`` is what ``SurfaceModel.get_outputs`` calls when ``usable`` says the model has the
+head shape the kernels are compiled for; anything else keeps the modular path.  Layers without an
+activation between them are collapsed HERE with torch ops so autograd carries the kernels'
+gradients back to the nn.Linear parameters.  Device fp32 only; there is no CPU path in this module
+(tests install host doubles from oracle/ over ``coarse_sample`` / ``field_render``).
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .kernels import _ptr, _require_device, _stream, zeros_by_kernel
+
+ENABLED = os.environ.get("PV2_FUSED_HEAD", "1") != "0"
+
+_DIMS = None
+
+
+def dims():
+    """(hidden, f_sdf, f_rest, geo, value_row, sums_len) compiled into the kernels."""
+    global _DIMS
+    if _DIMS is None:
+        vals = [ctypes.c_int() for _ in range(6)]
+        _lib.check(_lib.lib().pv2_neus_head_dims(*[ctypes.byref(v) for v in vals]), "pv2_neus_head_dims")
+        _DIMS = tuple(v.value for v in vals)
+    return _DIMS
+
+
+H, FS, F2, G, NV, NSUM = 128, 64, 64, 64, 140, 524  # checked against dims() on first device use
+# value row columns
+COL_F2, COL_GEO, COL_G, COL_N, COL_RGB, COL_T, COL_ONE = 0, 64, 128, 131, 134, 137, 138
+# column-sum layout of the backward (csrc/raymarch_fused.hip kSum*)
+SUM_C0, SUM_BC1, SUM_V1, SUM_B1, SUM_Q, SUM_RGB, SUM_INVS = 0, 128, 256, 384, 452, 516, 520
+
+
+def device_ok(t):
+    """Tensors the kernels take (overridden by the host doubles in tests)."""
+    return t.is_cuda and t.dtype == torch.float32
+
+
+def _vol5(volume_feature, num_scenes):
+    """The (B,Z,Y,X,C) channels-last view of the projected volume, or None."""
+    if len(volume_feature) != 1:
+        return None
+    v = volume_feature[0]
+    if v.dim() == 4:
+        v = v.unsqueeze(0)
+    if v.dim() != 5 or v.shape[0] != num_scenes:
+        return None
+    v = v.permute(0, 2, 3, 4, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def usable(model, ray_bundle, volume_feature):
+    """True when ``model`` (a NeuSModel) has exactly the head the fused kernels implement."""
+    from .ponder.models.ponder.render_utils.ray_samplers import NeuSSampler, UniformSampler
+
+    if not ENABLED or torch.is_autocast_enabled():
+        return False
+    f = model.field
+    smp = model.sampler
+    sd, rd, md = f.sdf_decoder, f.rgb_decoder, f.semantic_decoder
+    if not (isinstance(smp, NeuSSampler) and isinstance(smp.initial_sampler, UniformSampler)
+            and smp.num_upsample_steps == 1 and 2 <= smp.num_samples <= 128
+            and 1 <= smp.num_samples_importance <= 63):
+        return False
+    if not (f.volume_type == "default" and f.padding_mode == "zeros" and not f.share_volume
+            and f.use_gradient and f._cos_anneal_ratio == 1.0 and rd is not None):
+        return False
+    if model.loss.weights.get("sparse_points_sdf_loss", 0.0) > 0:
+        return False
+    if not (sd.num_layers == 3 and rd.num_layers == 2 and sd.points_factor == 0.0
+            and rd.points_factor == 0.0 and sd.fc_c[0].in_features == FS
+            and sd.lin0.out_features == H and sd.lin1.out_features == 1 + G
+            and rd.fc_c[0].in_features == 3 + F2 + G + 3 and rd.lin0.out_features == 3):
+        return False
+    if md is not None and not (md.num_layers == 2 and md.points_factor == 0.0
+                               and md.out_activation is None and f.hoist_semantic
+                               and md.fc_c[0].in_features == 3 + F2 + G):
+        return False
+    if len(volume_feature) != 1:
+        return False
+    v = volume_feature[0]
+    c = v.shape[1] if v.dim() == 5 else v.shape[0]
+    n_scenes = getattr(ray_bundle, "num_scenes", 1)
+    rays = ray_bundle.origins.shape[0]
+    return bool(c == FS + F2 and device_ok(v) and device_ok(ray_bundle.origins)
+                and rays % max(n_scenes, 1) == 0 and rays > 0)
+
+
+# --------------------------------------------------------------------------------------------
+# the two operations
+# --------------------------------------------------------------------------------------------
+def _check_dims():
+    assert dims() == (H, FS, F2, G, NV, NSUM), dims()
+
+
+def coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_rand, n_importance,
+                  MW, c0, bc1, W1, b1, base_inv_s, debug=False):
+    """-> (bins (R,S+1), starts (R,S), deltas (R,S)[, debug dict]); nothing is differentiable."""
+    _require_device(vol5, origins, dirs, nears, fars)
+    _check_dims()
+    B, Z, Y, X, C = vol5.shape
+    R = origins.shape[0]
+    S0 = lin_bins.numel() - 1
+    S = S0 + n_importance
+    dev = vol5.device
+    with torch.no_grad():
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        vol5, origins, dirs, nears, fars = map(f32, (vol5, origins, dirs, nears, fars))
+        t_rand, u_rand = f32(t_rand), f32(u_rand)
+        MW, c0, bc1, W1, b1 = map(f32, (MW, c0, bc1, W1, b1))
+        bins = torch.empty((R, S + 1), dtype=torch.float32, device=dev)
+        starts = torch.empty((R, S), dtype=torch.float32, device=dev)
+        deltas = torch.empty((R, S), dtype=torch.float32, device=dev)
+        dbg = None
+        if debug:
+            dbg = dict(idx=torch.empty((R, n_importance + 1), dtype=torch.int32, device=dev),
+                       sdf=torch.empty((R, S0), dtype=torch.float32, device=dev),
+                       weights=torch.empty((R, S0), dtype=torch.float32, device=dev))
+        _lib.check(_lib.lib().pv2_neus_coarse_sample(
+            _ptr(vol5), B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(nears.reshape(-1)),
+            _ptr(fars.reshape(-1)), R, S0, n_importance, _ptr(f32(lin_bins)), _ptr(t_rand),
+            0 if t_rand is None else t_rand.shape[-1], _ptr(f32(lin_u)), _ptr(u_rand),
+            0 if u_rand is None else u_rand.shape[-1], _ptr(MW), _ptr(c0), _ptr(bc1), _ptr(W1),
+            _ptr(b1), float(base_inv_s), _ptr(bins), _ptr(starts), _ptr(deltas),
+            _ptr(dbg["idx"]) if debug else None, _ptr(dbg["sdf"]) if debug else None,
+            _ptr(dbg["weights"]) if debug else None, _stream(vol5)), "pv2_neus_coarse_sample")
+    return (bins, starts, deltas, dbg) if debug else (bins, starts, deltas)
+
+
+def _gemm_tn_into(a, b, out):
+    """out[I,J] += a[M,I]^T b[M,J]  (csrc/sparse_conv.hip, atomically accumulated)."""
+    m, i = a.shape
+    j = b.shape[1]
+    assert out.shape == (i, j) and out.is_contiguous() and a.is_contiguous() and b.is_contiguous()
+    _lib.check(_lib.lib().pv2_gemm_tn(_ptr(a), _ptr(b), m, i, j, _ptr(out), _stream(a)), "pv2_gemm_tn")
+
+
+class _FieldRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
+                norm_pts, norm_div):
+        _require_device(vol5, origins, dirs, starts, deltas, MW, W1, A)
+        _check_dims()
+        L = _lib.lib()
+        B, Z, Y, X, C = vol5.shape
+        R, S = starts.shape
+        N = R * S
+        dev = vol5.device
+        c = lambda t: t.detach().contiguous()
+        vol5, origins, dirs, starts, deltas = map(c, (vol5, origins, dirs, starts, deltas))
+        MW, c0, bc1, W1, b1, A, b_rgb = map(c, (MW, c0, bc1, W1, b1, A, b_rgb))
+        inv_s_c = c(inv_s).reshape(1)
+        Mt = MW[:H].t().contiguous()
+        q0 = MW[H:].t().mv(W1[0]).contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        sdf, alpha, vals = new(R, S), new(R, S), new(R, S, NV)
+        sf, sh0, sa1, sq = new(N, FS), new(N, H), new(N, H), new(N, FS)
+        st = _stream(vol5)
+        _lib.check(L.pv2_neus_field_forward(
+            _ptr(vol5), B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S,
+            _ptr(MW), _ptr(c0), _ptr(bc1), _ptr(W1), _ptr(b1), _ptr(Mt), _ptr(q0), _ptr(A),
+            _ptr(b_rgb), _ptr(inv_s_c), int(norm_pts), float(norm_div), _ptr(sdf), _ptr(alpha),
+            _ptr(vals), _ptr(sf), _ptr(sh0), _ptr(sa1), _ptr(sq), st), "pv2_neus_field_forward")
+        weights = new(R, S)
+        _lib.check(L.pv2_raymarch_weights_forward(_ptr(alpha), R, S, _ptr(weights), None, st),
+                   "pv2_raymarch_weights_forward")
+        comp = new(R, NV)
+        _lib.check(L.pv2_raymarch_accumulate_forward(_ptr(weights), _ptr(vals), R, S, NV, _ptr(comp),
+                                                     st), "pv2_raymarch_accumulate_forward")
+        ctx.save_for_backward(vol5, origins, dirs, starts, deltas, MW, W1, A, inv_s_c, sdf, alpha,
+                              vals, sf, sh0, sa1, sq, weights, Mt)
+        ctx.norm = (int(norm_pts), float(norm_div))
+        ctx.inv_s_shape = inv_s.shape
+        grad = vals[:, :, COL_G:COL_G + 3].contiguous()
+        ctx.mark_non_differentiable(weights)
+        return sdf, grad, weights, comp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_grad, _g_weights, g_comp):
+        (vol5, origins, dirs, starts, deltas, MW, W1, A, inv_s, sdf, alpha, vals, sf, sh0, sa1, sq,
+         weights, Mt) = ctx.saved_tensors
+        L = _lib.lib()
+        B, Z, Y, X, C = vol5.shape
+        R, S = starts.shape
+        N = R * S
+        dev = vol5.device
+        st = _stream(vol5)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_comp = (torch.zeros((R, NV), dtype=torch.float32, device=dev) if g_comp is None
+                  else g_comp.contiguous())
+        g_sdf = None if g_sdf is None else g_sdf.contiguous()
+        g_grad = None if g_grad is None else g_grad.contiguous()
+        gw = new(R, S)
+        _lib.check(L.pv2_raymarch_accumulate_backward(_ptr(weights), _ptr(vals), _ptr(g_comp), R, S,
+                                                      NV, _ptr(gw), None, st),
+                   "pv2_raymarch_accumulate_backward")
+        g_alpha = new(R, S)
+        _lib.check(L.pv2_raymarch_weights_backward(_ptr(alpha), _ptr(gw), R, S, _ptr(g_alpha), st),
+                   "pv2_raymarch_weights_backward")
+        gfeat, gvec, gz, tmat = new(N, C), new(N, 4), new(N, 2 * H), new(N, H)
+        gq, gh, gy, sums = new(N, FS), new(N, 68), new(N, 4), new(NSUM)
+        need_vol = ctx.needs_input_grad[0]
+        gvol = zeros_by_kernel(tuple(vol5.shape), torch.float32, dev) if need_vol else None
+        W1gt = W1[1:].t().contiguous()
+        Wc1t = MW[H:].t().contiguous()
+        _lib.check(L.pv2_neus_field_backward(
+            _ptr(vol5), B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S,
+            _ptr(MW), _ptr(W1), _ptr(Mt), _ptr(W1gt), _ptr(Wc1t), _ptr(A), _ptr(inv_s), ctx.norm[0],
+            ctx.norm[1], _ptr(sdf), _ptr(vals), _ptr(sh0), _ptr(sq), _ptr(weights), _ptr(g_alpha),
+            _ptr(g_sdf), _ptr(g_grad), _ptr(g_comp), _ptr(gfeat), _ptr(gvec), _ptr(gz), _ptr(tmat),
+            _ptr(gq), _ptr(gh), _ptr(gy), _ptr(sums), _ptr(gvol), st), "pv2_neus_field_backward")
+        # weight gradients: sums over all samples of outer products = four A^T B reductions
+        g_MW = zeros_by_kernel((2 * H, FS), torch.float32, dev)
+        _gemm_tn_into(gz, sf, g_MW)                 # [gh0 | ga1]^T f
+        _gemm_tn_into(tmat, gq, g_MW[:H])           # + t^T gq on the M rows
+        g_W1p = zeros_by_kernel((68, H), torch.float32, dev)
+        _gemm_tn_into(gh, sa1, g_W1p)
+        g_Ap = zeros_by_kernel((4, NV), torch.float32, dev)
+        _gemm_tn_into(gy, vals.reshape(N, NV), g_Ap)
+        qsum = sums[SUM_Q:SUM_Q + FS]
+        v1 = W1[0]
+        g_MW[H:] += torch.outer(v1, qsum)
+        g_W1 = g_W1p[:1 + G].clone()
+        g_W1[0] += sums[SUM_V1:SUM_V1 + H] + MW[H:].mv(qsum)
+        g_A = torch.cat([g_Ap[:3, COL_G:COL_G + 3], g_Ap[:3, COL_F2:COL_F2 + F2],
+                         g_Ap[:3, COL_GEO:COL_GEO + G],
+                         gy.reshape(R, S, 4).sum(1)[:, :3].t().mm(dirs)], dim=1)
+        return (gvol, None, None, None, None, g_MW, sums[SUM_C0:SUM_C0 + H].clone(),
+                sums[SUM_BC1:SUM_BC1 + H].clone(), g_W1, sums[SUM_B1:SUM_B1 + 1 + G].clone(), g_A,
+                sums[SUM_RGB:SUM_RGB + 3].clone(), sums[SUM_INVS].reshape(ctx.inv_s_shape), None,
+                None)
+
+
+def field_render(vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
+                 norm_pts, norm_div):
+    """-> sdf (R,S), grad (R,S,3), weights (R,S) [no gradient], comp (R,140).  Differentiable (once)
+    in the volume, the collapsed parameters and inv_s."""
+    return _FieldRender.apply(vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb,
+                              inv_s, norm_pts, norm_div)
+
+
+# --------------------------------------------------------------------------------------------
+# model glue
+# --------------------------------------------------------------------------------------------
+def collapse(field):
+    """Collapsed parameters of the SDF and colour heads (differentiable torch ops)."""
+    sd, rd = field.sdf_decoder, field.rgb_decoder
+    zero = 0.0
+    for dec in (sd, rd):  # fc_p(points) * 0.0 of the reference: an exact zero with a graph
+        zero = zero + (dec.fc_p.weight.sum() + dec.fc_p.bias.sum()) * 0.0
+    W0, b0 = sd.lin0.weight, sd.lin0.bias
+    Wc0, bc0 = sd.fc_c[0].weight, sd.fc_c[0].bias
+    Wc1, bc1 = sd.fc_c[1].weight, sd.fc_c[1].bias
+    MW = torch.cat([W0.mm(Wc0), Wc1], dim=0)
+    c0 = W0.mv(bc0) + b0 + zero
+    Wr1, br1 = rd.lin0.weight, rd.lin0.bias
+    Wrc, brc = rd.fc_c[0].weight, rd.fc_c[0].bias
+    return dict(MW=MW, c0=c0, bc1=bc1, W1=sd.lin1.weight, b1=sd.lin1.bias, A=Wr1.mm(Wrc),
+                b_rgb=Wr1.mv(brc) + br1)
+
+
+def render_outputs(model, ray_bundle, volume_feature):
+    """``SurfaceModel.get_outputs`` on the fused kernels (same keys and values, except that the
+    coarse pass's diagnostic point sets are not materialised)."""
+    from .ponder.models.ponder.render_utils.rays import device_constant, device_linspace
+
+    field, smp = model.field, model.sampler
+    B = getattr(ray_bundle, "num_scenes", 1)
+    vol5 = _vol5(volume_feature, B)
+    o, d = ray_bundle.origins, ray_bundle.directions
+    R = o.shape[0]
+    dev = o.device
+    cp = collapse(field)
+    S0, n_imp = smp.num_samples, smp.num_samples_importance
+    ini, pdf = smp.initial_sampler, smp.pdf_sampler
+    t_rand = u_rand = None
+    if ini.train_stratified and ini.training:
+        t_rand = ini.rand((R, 1 if ini.single_jitter else S0 + 1), dtype=o.dtype, device=dev)
+    if pdf.train_stratified and pdf.training:
+        u_rand = pdf.rand((R, 1 if pdf.single_jitter else n_imp + 1), device=dev)
+    nb = n_imp + 1
+    lin_bins = device_linspace(0.0, 1.0, S0 + 1, dev)
+    lin_u = device_linspace(0.0, 1.0 - 1.0 / nb, nb, dev)
+    bins, starts, deltas = coarse_sample(
+        vol5, o, d, ray_bundle.nears.reshape(-1), ray_bundle.fars.reshape(-1), lin_bins, t_rand,
+        lin_u, u_rand, n_imp, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], smp.base_variance)
+    inv_s = field.deviation_network.get_variance()
+    sdf, grad, weights, comp = field_render(
+        vol5, o, d, starts, deltas, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], cp["A"],
+        cp["b_rgb"], inv_s, field.norm_pts, 1.0 + field.norm_padding + 10e-4)
+    wsum = comp[:, COL_ONE:COL_ONE + 1]
+    out = {}
+    rgb = comp[:, COL_RGB:COL_RGB + 3]
+    bg = device_constant(model.rgb_renderer.background_color, dev, rgb.dtype)
+    rgb = rgb + bg * (1.0 - wsum)
+    out["rgb"] = rgb if model.training else rgb.clamp(0.0, 1.0)
+    md = field.semantic_decoder
+    if md is not None:
+        xbar = torch.cat([comp[:, COL_G:COL_G + 3], comp[:, COL_F2:COL_F2 + F2],
+                          comp[:, COL_GEO:COL_GEO + G]], dim=1)
+        zero = (md.fc_p.weight.sum() + md.fc_p.bias.sum()) * 0.0
+        hidden = F.linear(xbar, md.fc_c[0].weight) + (md.fc_c[0].bias + zero) * wsum
+        lin = md.last_linear
+        out["semantic"] = F.linear(hidden, lin.weight) + lin.bias * wsum
+    depth = comp[:, COL_T:COL_T + 1] / (wsum + 1e-10)
+    per_scene = starts.reshape(B, -1)
+    lo = per_scene.amin(1).repeat_interleave(R // B).reshape(-1, 1)
+    hi = per_scene.amax(1).repeat_interleave(R // B).reshape(-1, 1)
+    out["depth"] = torch.maximum(torch.minimum(depth, hi), lo)
+    out["normal"] = comp[:, COL_N:COL_N + 3]
+    out.update(weights=weights.unsqueeze(-1), sdf=sdf.unsqueeze(-1), gradients=grad,
+               z_vals=starts.unsqueeze(-1))
+    if not model.training:
+        out["sampled_points"] = o[:, None, :] + d[:, None, :] * starts[..., None]
+    return out

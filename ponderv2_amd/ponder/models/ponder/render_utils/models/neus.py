@@ -2,6 +2,7 @@
 field's SDF as the proposal, then field evaluation with alphas and compositing weights."""
 from functools import partial
 
+from ponderv2_amd import fused_head
 from ..builder import RENDERERS
 from .base_surface_model import SurfaceModel
 
@@ -11,6 +12,13 @@ class NeuSModel(SurfaceModel):
     def __init__(self, field, collider, sampler, loss, **kwargs):
         super().__init__(field=field, collider=collider, sampler=sampler, loss=loss)
         self.anneal_end = 50000
+
+    def get_outputs(self, ray_bundle, volume_feature, **kwargs):
+        # the shipped head shape runs on the fused ray-march kernels (csrc/raymarch_fused.hip);
+        # every other configuration keeps the modular path below
+        if fused_head.usable(self, ray_bundle, volume_feature):
+            return fused_head.render_outputs(self, ray_bundle, volume_feature)
+        return super().get_outputs(ray_bundle, volume_feature, **kwargs)
 
     def sample_and_forward_field(self, ray_bundle, volume_feature):
         sampled = self.sampler(ray_bundle, occupancy_fn=self.field.get_occupancy,

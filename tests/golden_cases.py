@@ -113,7 +113,8 @@ def run_spunet(device, dtype):
     return errs, cos
 
 
-def run_neus(device):
+def run_neus(device, return_values=False):
+    from ponderv2_amd import fused_head as fhd
     from ponderv2_amd.ponder.models.ponder.render_utils import RayBundle, build_renderer
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
@@ -131,9 +132,28 @@ def run_neus(device):
     o = torch.from_numpy(g["origins"]).to(device)
     d = torch.from_numpy(g["directions"]).to(device)
     targets = {k: torch.from_numpy(g[f"tgt_{k}"]).to(device) for k in ("depth", "rgb", "semantic")}
-    out = renderer(RayBundle(origins=o, directions=d), [volume])
+    fused_calls = {"n": 0}
+    orig_render = fhd.field_render
+
+    def counted(*a):
+        fused_calls["n"] += 1
+        return orig_render(*a)
+
+    fhd.field_render = counted
+    try:
+        out = renderer(RayBundle(origins=o, directions=d), [volume])
+    finally:
+        fhd.field_render = orig_render
     losses = renderer.get_loss(out, targets)
     sum(v for k, v in losses.items() if "loss" in k).backward()
+    if return_values:
+        vals = {"out_" + k: out[k].detach().cpu() for k in ("rgb", "semantic", "depth", "normal", "weights",
+                                                              "sdf", "gradients", "z_vals")}
+        vals.update({"loss_" + k: v.detach().cpu().reshape(1) for k, v in losses.items()})
+        vals["dvolume"] = volume.grad.detach().cpu()
+        vals.update({"grad_" + k: p.grad.detach().cpu() for k, p in renderer.named_parameters()
+                     if p.grad is not None})
+        return dict(values=vals, fused_calls=fused_calls["n"])
     errs = {}
     for k in ("rgb", "semantic", "depth", "normal", "weights", "sdf", "gradients", "z_vals"):
         errs["out_" + k] = rel_err(out[k], g["out_" + k])

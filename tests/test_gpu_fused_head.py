@@ -1,0 +1,95 @@
+"""GPU parity of the fused ray-march kernels (csrc/raymarch_fused.hip, through the C ABI) against the
+fp64 restatement oracle/fused_head.py - which tests/test_fused_head_cpu.py pins to autograd and
+tests/test_golden_cpu.py to the reference's own golden vectors."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 2e-4   # fp32 kernels against the fp64 oracle, relative to the largest reference entry
+
+
+def _assert_rows(rows):
+    by = {name: (err, mag) for name, err, mag in rows}
+    flips = by.pop("coarse.idx flips (count)")[0]
+    assert flips <= 2, rows   # searchsorted is integer work: bit-exact up to a cdf tie
+    for name, (err, mag) in by.items():
+        if flips and name in ("coarse.bins", "coarse.starts", "coarse.deltas"):
+            continue
+        assert err <= REL_TOL * mag + 1e-7, (name, err, mag)
+
+
+def test_fused_head_stages_vs_oracle(device):
+    """Every intermediate and every gradient of the coarse pass, the main pass and its backward at
+    the ScanNet sample counts (96 + 36), two scenes."""
+    import check_fused_head as chk
+
+    _assert_rows(chk.run(device, seed=0, verbose=True))
+
+
+def test_fused_head_ragged_sizes_vs_oracle(device):
+    """One scene, 45 samples per ray (tiles straddle rays, the last tile is partial), odd volume
+    extents, coarse count not a multiple of 32."""
+    import check_fused_head as chk
+
+    _assert_rows(chk.run(device, seed=1, verbose=True, B=1, R=5, S=45, S0=40, n_imp=7, Z=5, Y=9, X=11))
+
+
+def test_fused_head_points_outside_the_volume(device):
+    """Rays that leave the unit cube: the coarse pass reads zero padding (reference quirk Q1) and the
+    main pass clamps - results still equal the oracle's."""
+    import check_fused_head as chk
+    from oracle import fused_head as fh
+    from ponderv2_amd import fused_head as fhd
+
+    p = chk.make_problem(seed=3, R=8)
+    p["origins"] = p["origins"] * 4.0          # most samples outside [0,1]^3 in the coarse pass
+    d = {k: (v.to(device=device, dtype=torch.float32).contiguous() if torch.is_tensor(v) else v)
+         for k, v in p.items()}
+    ref = fh.coarse_sample(p["vol"], p["origins"], p["dirs"], p["nears"], p["fars"], p["lin_bins"],
+                           p["t_rand"], p["u_rand"], p["n_imp"], p["MW"], p["c0"], p["bc1"], p["W1"][0],
+                           p["b1"][0], 64.0)
+    bins, _, _ = fhd.coarse_sample(d["vol"], d["origins"], d["dirs"], d["nears"], d["fars"],
+                                   d["lin_bins"], d["t_rand"], d["lin_u"], d["u_rand"], p["n_imp"],
+                                   d["MW"], d["c0"], d["bc1"], d["W1"], d["b1"], 64.0)
+    bad = ((bins.double().cpu() - ref).abs().amax(1) > 1e-5).sum().item()
+    assert bad <= 1, bad
+    a64 = [p[k] for k in ("vol", "origins", "dirs", "starts", "deltas", "MW", "c0", "bc1", "W1", "b1", "A",
+                          "b_rgb", "inv_s")]
+    a32 = [d[k] for k in ("vol", "origins", "dirs", "starts", "deltas", "MW", "c0", "bc1", "W1", "b1", "A",
+                          "b_rgb", "inv_s")]
+    r = fh.field_render(*a64)
+    sdf, grad, w, comp = fhd.field_render(*a32, True, 1.0 + 0.1 + 10e-4)
+    for got, want in ((sdf, r["sdf"]), (grad, r["grad"]), (w, r["weights"]), (comp, r["comp"])):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= REL_TOL * want.abs().max().item() + 1e-7
+
+
+def test_fused_head_is_the_default_render_path(device, monkeypatch):
+    """The NeuS golden runs through the fused kernels unless switched off, and both paths give the
+    reference's numbers."""
+    import golden_cases as gc
+    from ponderv2_amd import fused_head as fhd
+
+    calls = {"n": 0}
+    orig = fhd.field_render
+
+    def counted(*a):
+        calls["n"] += 1
+        return orig(*a)
+
+    monkeypatch.setattr(fhd, "field_render", counted)
+    errs = gc.run_neus(device)
+    assert calls["n"] == 1
+    outs = {k: v for k, v in errs.items() if k.startswith(("out_", "loss_"))}
+    assert max(outs.values()) < 1e-4, errs
+    assert max(errs.values()) < 1e-3, errs
+    monkeypatch.setattr(fhd, "ENABLED", False)
+    errs = gc.run_neus(device)
+    assert calls["n"] == 1
+    assert max(v for k, v in errs.items() if k.startswith(("out_", "loss_"))) < 1e-4, errs
