@@ -73,12 +73,6 @@ def parse():
                          "parity configuration, everything on the path in fp32; bfloat16 runs only "
                          "those dense convs under autocast (the reference config trains with "
                          "enable_amp=True)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the render head (forward + backward) as one hipGraph per step.  Not "
-                         "the default: on full-size runs some loss terms were observed to turn into "
-                         "garbage on some replays (DESIGN.md section 6), so the measured default is "
-                         "the eager head")
-    ap.add_argument("--no-graph", action="store_true", help="(default) eager render head")
     ap.add_argument("--print-losses", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     args = ap.parse_args()
@@ -312,6 +306,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
+    from ponderv2_amd import fused_head
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
@@ -327,7 +322,6 @@ def main():
         cfg = ppt_model_cfg(args.rays_per_view, args.dense_dtype)
     else:
         cfg = model_cfg(args.rays_per_view, args.dense_dtype)
-    cfg["graph_render_head"] = bool(args.graph) and not args.no_graph
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
     if world > 1:
@@ -448,7 +442,8 @@ def main():
                        "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
-            "render_head": "hipGraph replay" if cfg["graph_render_head"] else "eager",
+            "render_head": ("fused ray-march kernels (csrc/raymarch_fused.hip)"
+                            if fused_head.ENABLED and not outdoor else "modular (torch ops + kernels)"),
         }
         if kernels:
             dom = kernels[0]

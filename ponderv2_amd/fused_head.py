@@ -48,8 +48,9 @@ SUM_C0, SUM_BC1, SUM_V1, SUM_B1, SUM_Q, SUM_RGB, SUM_INVS = 0, 128, 256, 384, 45
 
 
 def device_ok(t):
-    """Tensors the kernels take (overridden by the host doubles in tests)."""
-    return t.is_cuda and t.dtype == torch.float32
+    """Tensors the kernels take (overridden by the host doubles in tests).  Reduced-precision
+    volumes (the projection network under autocast) are widened to fp32 on the way in."""
+    return t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.float16)
 
 
 def _vol5(volume_feature, num_scenes):
@@ -69,7 +70,7 @@ def usable(model, ray_bundle, volume_feature):
     """True when ``model`` (a NeuSModel) has exactly the head the fused kernels implement."""
     from .ponder.models.ponder.render_utils.ray_samplers import NeuSSampler, UniformSampler
 
-    if not ENABLED or torch.is_autocast_enabled():
+    if not ENABLED:
         return False
     f = model.field
     smp = model.sampler
@@ -279,12 +280,19 @@ def collapse(field):
 def render_outputs(model, ray_bundle, volume_feature):
     """``SurfaceModel.get_outputs`` on the fused kernels (same keys and values, except that the
     coarse pass's diagnostic point sets are not materialised)."""
+    # the kernels are fp32 launches that autocast never touches; the small torch ops around them
+    # (parameter collapse, per-ray epilogue) stay fp32 as well
+    with torch.autocast(ray_bundle.origins.device.type, enabled=False):
+        return _render_outputs(model, ray_bundle, volume_feature)
+
+
+def _render_outputs(model, ray_bundle, volume_feature):
     from .ponder.models.ponder.render_utils.rays import device_constant, device_linspace
 
     field, smp = model.field, model.sampler
     B = getattr(ray_bundle, "num_scenes", 1)
-    vol5 = _vol5(volume_feature, B)
-    o, d = ray_bundle.origins, ray_bundle.directions
+    vol5 = _vol5(volume_feature, B).float()
+    o, d = ray_bundle.origins.float(), ray_bundle.directions.float()
     R = o.shape[0]
     dev = o.device
     cp = collapse(field)

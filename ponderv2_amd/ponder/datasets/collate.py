@@ -10,6 +10,7 @@ neighbouring pairs of samples into one scene (Mix3D) by keeping every second off
 """
 import random
 from collections.abc import Mapping, Sequence
+from functools import partial
 
 import torch
 from torch.utils.data.dataloader import default_collate
@@ -62,8 +63,33 @@ def collate_fn(batch, max_point=-1):
 
 def point_collate_fn(batch, mix_prob=0, max_point=-1):
     assert isinstance(batch[0], Mapping), "only dict samples are supported"
-    batch = collate_fn(batch, max_point=max_point)
+    return _mix_offsets(collate_fn(batch, max_point=max_point), mix_prob)
+
+
+def _mix_offsets(batch, mix_prob):
+    """Mix3D: with probability ``mix_prob`` neighbouring pairs of samples become one scene."""
     if "offset" in batch and random.random() < mix_prob:
         offset = batch["offset"]
         batch["offset"] = torch.cat([offset[1:-1:2], offset[-1:]], dim=0)
+        if "offset_host" in batch:
+            batch["offset_host"] = [int(v) for v in batch["offset"]]
     return batch
+
+
+def _own_collate(samples, inner, mix_prob, max_point):
+    if max_point > 0:
+        samples = _within_budget(samples, max_point)
+    return _mix_offsets(inner(samples), mix_prob)
+
+
+def loader_collate(dataset, mix_prob=0, max_point=-1):
+    """The collate callable of a training loader.  The reference wires
+    ``partial(point_collate_fn, mix_prob=cfg.mix_prob, max_point=cfg.max_point)`` into every loader
+    (ponder/engines/train.py:243-258, ponder/datasets/dataloader.py:67-80) - the point budget is
+    the out-of-memory guard of its pre-training configs.  Datasets whose samples need their own
+    batch assembly (the synthetic scenes and lidar sweeps of this repository) declare ``collate_fn``
+    and get the same budget and Mix3D handling around it."""
+    own = getattr(dataset, "collate_fn", None)
+    if own is None or own is point_collate_fn:
+        return partial(point_collate_fn, mix_prob=mix_prob, max_point=max_point)
+    return partial(_own_collate, inner=own, mix_prob=mix_prob, max_point=max_point)

@@ -14,6 +14,7 @@ import torch
 import torch.utils.data
 
 from ..utils import comm
+from .collate import loader_collate
 
 
 class ConcatDataset(torch.utils.data.Dataset):
@@ -37,7 +38,11 @@ class ConcatDataset(torch.utils.data.Dataset):
 
 
 def _seed_worker(worker_id, base):
+    """ponder/datasets/dataloader.py:108-117: python, numpy and torch streams of one worker."""
+    import random
+
     seed = base + worker_id
+    random.seed(seed)
     np.random.seed(seed % (2 ** 32))
     torch.manual_seed(seed)
 
@@ -57,7 +62,6 @@ class _EpochSampler:
 class MultiDatasetDataloader:
     def __init__(self, concat_dataset, batch_size_per_gpu, num_worker_per_gpu, mix_prob=0,
                  seed=None, max_point=-1, default_collate=None):
-        assert mix_prob == 0 and max_point == -1, "mix_prob / max_point are not used in pre-training"
         self.datasets = concat_dataset.datasets
         self.ratios = [int(getattr(d, "loop", 1)) for d in self.datasets]
         for d in self.datasets:  # the original loops served as ratios
@@ -67,11 +71,14 @@ class MultiDatasetDataloader:
         self.dataloaders = []
         for k, d in enumerate(self.datasets):
             sampler = torch.utils.data.distributed.DistributedSampler(d) if world > 1 else None
-            collate = getattr(d, "collate_fn", None) or default_collate
+            # every sub-loader collates with the point budget / Mix3D settings of the config
+            # (reference :67-80)
+            collate = loader_collate(d, mix_prob=mix_prob, max_point=max_point)
             init = None
-            if seed is not None:  # distinct stream per (rank, dataset, worker)
+            if seed is not None:  # distinct stream per (rank, dataset, worker), reference :108-117
+                nw = num_worker_per_gpu // len(self.datasets)
                 init = partial(_seed_worker,
-                               base=seed + num_worker_per_gpu * (len(self.datasets) * rank + k))
+                               base=nw * len(self.datasets) * rank + nw * k + seed)
             self.dataloaders.append(torch.utils.data.DataLoader(
                 d, batch_size=batch_size_per_gpu, shuffle=sampler is None,
                 num_workers=num_worker_per_gpu, sampler=sampler, collate_fn=collate,

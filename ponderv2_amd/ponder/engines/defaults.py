@@ -50,6 +50,12 @@ def set_seed(seed=None):
     return seed
 
 
+def worker_init_fn(worker_id, num_workers, rank, seed):
+    """DataLoader workers get the seed num_workers * rank + worker_id + seed
+    (ponder/engines/defaults.py:46-59), so a fixed ``cfg.seed`` reproduces the augmentation stream."""
+    set_seed(num_workers * rank + worker_id + seed)
+
+
 def default_config_parser(file_path, options):
     cfg = Config.fromfile(file_path)
     if options is not None:

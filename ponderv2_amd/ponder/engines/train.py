@@ -17,7 +17,8 @@ from ..models import build_model
 from ..utils import comm
 from ..utils.optimizer import build_optimizer, build_scheduler
 from ..utils.registry import Registry
-from .defaults import create_ddp_model
+from ..datasets.collate import loader_collate
+from .defaults import create_ddp_model, worker_init_fn
 from .hooks import HOOKS, HookBase
 
 TRAINERS = Registry("trainers")
@@ -137,11 +138,16 @@ class Trainer(TrainerBase):
         sampler = (torch.utils.data.distributed.DistributedSampler(data)
                    if comm.get_world_size() > 1 else None)
         workers = self.cfg.num_worker_per_gpu
+        init = None
+        if self.cfg.get("seed") is not None:  # reference engines/defaults.py:46-59
+            init = partial(worker_init_fn, num_workers=workers, rank=comm.get_rank(),
+                           seed=self.cfg.seed)
         return torch.utils.data.DataLoader(
             data, batch_size=self.cfg.batch_size_per_gpu, shuffle=sampler is None,
             num_workers=workers, sampler=sampler,
-            collate_fn=getattr(data, "collate_fn", None) or collate_fn,
-            pin_memory=torch.cuda.is_available(), drop_last=True,
+            collate_fn=loader_collate(data, mix_prob=self.cfg.get("mix_prob", 0),
+                                      max_point=self.cfg.get("max_point", -1)),
+            pin_memory=torch.cuda.is_available(), worker_init_fn=init, drop_last=True,
             persistent_workers=workers > 0)
 
     def before_epoch(self):

@@ -46,7 +46,7 @@ class PonderIndoor(nn.Module):
                  context_channels=256, pool_type="mean", render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True,
-                 proj_autocast=None, batched_render=True, graph_render_head=False,
+                 proj_autocast=None, batched_render=True,
                  sparse_dense_input=True):
         super().__init__()
         self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
@@ -61,13 +61,6 @@ class PonderIndoor(nn.Module):
         # evaluate the projection network's first conv from the occupied cells only (the dense
         # 96-channel grid is never built, sparse_input.py); False = the reference's dense path
         self.sparse_dense_input = sparse_dense_input
-        # replay the (static-shape) render head + its backward as one hipGraph during training.
-        # OFF by default: single replays match the eager head (tests), but in full-size training
-        # runs with an optimizer step between replays the sdf / free-space / eikonal loss terms
-        # were observed to turn into garbage on some steps (profiles/r01_graph_head_loss_trace.txt;
-        # the eager head trains smoothly) - unresolved, see DESIGN.md section 6
-        self.graph_render_head = graph_render_head
-        self._graphed = None
         h = 0.5 + padding / 2
         self.bounds = [[-h, -h, -h], [h, h, h]]
         if mask is not None:
@@ -435,19 +428,8 @@ class PonderIndoor(nn.Module):
         data_dict = self.extract_feature(data_dict)
         ray_dict, data_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
-        res = None
-        if (self.training and self.graph_render_head and self.batched_render
-                and volume_feature[0].is_cuda and torch.is_grad_enabled()):
-            if self._graphed is None:
-                from .graphed_render import GraphedRenderHead
-
-                self._graphed = GraphedRenderHead(self)
-            if not self._graphed.failed:
-                res = self._graphed(volume_feature[0], ray_dict)
-        if res is None:
-            render_out = self.render_func(ray_dict, volume_feature)
-            res = self.render_loss(render_out, ray_dict)
-        loss, loss_dict = res
+        render_out = self.render_func(ray_dict, volume_feature)
+        loss, loss_dict = self.render_loss(render_out, ray_dict)
         out = dict(loss=loss, **loss_dict)
         if self.ppt_loss_weight > 0:
             out["ppt_loss"] = self.ppt_loss(data_dict)  # reported only (reference :699-704)

@@ -13,8 +13,7 @@ GPU organisation (vs the reference's per-scene Python loops):
     (B,Z,Y,X,C) grid - the layout both MIOpen's NDHWC conv and the trilinear sampler want;
   * ``render_func`` (:217-252): when every scene of the batch carries the same number of rays
     (the normal case: ``RaySample(point_nsample=512)`` x 6 cameras) all scenes are rendered in one
-    batched pass and, in training, replayed as a hipGraph together with their backward
-    (graphed_render.py); ragged batches fall back to one pass per scene;
+    batched pass; ragged batches fall back to one pass per scene;
   * block masking (:93-137) ranks all scenes' blocks in one device pass (masking.py).
 """
 from collections.abc import Sequence
@@ -47,7 +46,7 @@ class PonderOutdoor(nn.Module):
                  pool_type="mean", share_volume=True, render_semantic=False, conditions=None,
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  dense_channels_last=True, proj_autocast=None, batched_render=True,
-                 graph_render_head=False, sparse_dense_input=True):
+                 sparse_dense_input=True):
         super().__init__()
         self.grid_shape = _per_condition(grid_shape)
         self.grid_size = _per_condition(grid_size)
@@ -56,9 +55,8 @@ class PonderOutdoor(nn.Module):
         self.share_volume, self.mask = share_volume, mask
         self.dense_channels_last = dense_channels_last
         self.proj_autocast = proj_autocast
-        self.batched_render, self.graph_render_head = batched_render, graph_render_head
+        self.batched_render = batched_render
         self.sparse_dense_input = sparse_dense_input  # first conv from occupied cells only
-        self._graphed = None
         if mask is not None:
             p = nn.Parameter(torch.zeros(1, mask.channel))
             nn.init.trunc_normal_(p, mean=0, std=0.02, a=-0.02, b=0.02)
@@ -225,22 +223,6 @@ class PonderOutdoor(nn.Module):
         data_dict = self.extract_feature(data_dict)
         ray_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
-        res = None
-        if (self.training and self.graph_render_head and self.batched_render
-                and volume_feature[0].is_cuda and torch.is_grad_enabled()
-                and self._uniform_rays(ray_dict)):
-            if self._graphed is None:
-                from .graphed_render import GraphedRenderHead
-
-                self._graphed = GraphedRenderHead(self)
-            if not self._graphed.failed:
-                B = volume_feature[0].shape[0]
-                static = {k: v.reshape(B, -1, v.shape[-1]) if k in ("ray_o", "ray_d") else v
-                          for k, v in ray_dict.items()
-                          if torch.is_tensor(v) and k != "ray_offset"}
-                res = self._graphed(volume_feature[0], static)
-        if res is None:
-            render_out = self.render_func(ray_dict, volume_feature)
-            res = self.render_loss(render_out, ray_dict)
-        loss, loss_dict = res
+        render_out = self.render_func(ray_dict, volume_feature)
+        loss, loss_dict = self.render_loss(render_out, ray_dict)
         return dict(loss=loss, **loss_dict)

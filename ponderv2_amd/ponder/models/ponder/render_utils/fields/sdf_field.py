@@ -13,7 +13,6 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ponderv2_amd.capture_safe import scale_by_scalar
 from ponderv2_amd.smooth_sampler import SmoothSampler
 from ..builder import FIELDS
 from ..decoders import RGBDecoder, SDFDecoder, SemanticDecoder
@@ -87,9 +86,8 @@ class SDFField(nn.Module):
         r = self._cos_anneal_ratio
         iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - r) + F.relu(-true_cos) * r)
         half = iter_cos * ray_samples.deltas * 0.5
-        # inv_s is a one-element function of a parameter: its gradient is a sum over every sample
-        prev_cdf = torch.sigmoid(scale_by_scalar(sdf - half, inv_s))
-        next_cdf = torch.sigmoid(scale_by_scalar(sdf + half, inv_s))
+        prev_cdf = torch.sigmoid((sdf - half) * inv_s)
+        next_cdf = torch.sigmoid((sdf + half) * inv_s)
         return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
 
     def feature_sampling(self, pts_norm, volume_feature):

@@ -9,7 +9,6 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ponderv2_amd.capture_safe import mean_all, sum_all
 from ..builder import build_collider, build_field, build_sampler
 from ..renderers import DepthRenderer, NormalRenderer, RGBRenderer, SemanticRenderer
 
@@ -65,12 +64,12 @@ class SurfaceModel(nn.Module):
         depth_gt = targets["depth"]
         valid = depth_gt > 0.0
         if lw.get("depth_loss", 0.0) > 0:
-            l1 = sum_all(valid * torch.abs(depth_gt - preds_dict["depth"]))
-            out["depth_loss"] = l1 / torch.clamp(sum_all(valid), min=1.0) * lw.depth_loss
+            l1 = torch.sum(valid * torch.abs(depth_gt - preds_dict["depth"]))
+            out["depth_loss"] = l1 / torch.clamp(torch.sum(valid), min=1.0) * lw.depth_loss
         if lw.get("rgb_loss", 0.0) > 0:
             rgb_pred, rgb_gt = preds_dict["rgb"], targets["rgb"]
-            out["rgb_loss"] = mean_all(torch.abs(rgb_pred - rgb_gt)) * lw.rgb_loss
-            out["psnr"] = 20.0 * torch.log10(1.0 / mean_all((rgb_pred - rgb_gt).pow(2)).sqrt())
+            out["rgb_loss"] = torch.mean(torch.abs(rgb_pred - rgb_gt)) * lw.rgb_loss
+            out["psnr"] = 20.0 * torch.log10(1.0 / torch.mean((rgb_pred - rgb_gt).pow(2)).sqrt())
         if lw.get("semantic_loss", 0.0) > 0:
             if not self.training:
                 raise NotImplementedError("semantic loss is only defined for training (SURVEY Q2)")
@@ -90,15 +89,15 @@ class SurfaceModel(nn.Module):
         back = valid & (z_vals > (depth_gt + trunc))
         near = valid & (~front) & (~back)
         if lw.get("free_space_loss", 0.0) > 0:
-            fs = sum_all(F.relu(trunc - pred_sdf) * front) / torch.clamp(sum_all(front), min=1.0)
+            fs = torch.sum(F.relu(trunc - pred_sdf) * front) / torch.clamp(torch.sum(front), min=1.0)
             out["free_space_loss"] = fs * lw.free_space_loss
         if lw.get("sdf_loss", 0.0) > 0:
-            sl = sum_all(torch.abs(z_vals + pred_sdf - depth_gt) * near) / torch.clamp(sum_all(near), min=1.0)
+            sl = torch.sum(torch.abs(z_vals + pred_sdf - depth_gt) * near) / torch.clamp(torch.sum(near), min=1.0)
             out["sdf_loss"] = sl * lw.sdf_loss
         if lw.get("eikonal_loss", 0.0) > 0:
             g = preds_dict["gradients"]
-            out["eikonal_loss"] = mean_all((g.norm(2, dim=-1) - 1) ** 2) * lw.eikonal_loss
+            out["eikonal_loss"] = torch.mean((g.norm(2, dim=-1) - 1) ** 2) * lw.eikonal_loss
         if lw.get("sparse_points_sdf_loss", 0.0) > 0:
-            out["sparse_points_sdf_loss"] = mean_all(torch.abs(preds_dict["sparse_points_sdf"])) \
+            out["sparse_points_sdf_loss"] = torch.mean(torch.abs(preds_dict["sparse_points_sdf"])) \
                 * lw.sparse_points_sdf_loss
         return out

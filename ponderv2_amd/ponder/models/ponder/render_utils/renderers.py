@@ -4,7 +4,6 @@ semantic :66-75)."""
 import torch
 
 from ponderv2_amd import raymarch
-from ponderv2_amd.capture_safe import rowwise_min_max
 from torch import nn
 
 from .rays import device_constant
@@ -39,7 +38,7 @@ class DepthRenderer(nn.Module):
         if B == 1:
             return torch.clip(depth, steps.min(), steps.max())
         per_scene = steps.reshape(B, -1)  # the clip range is per rendered scene (reference :50)
-        lo, hi = rowwise_min_max(per_scene, group=steps.shape[-2])
+        lo, hi = per_scene.amin(1), per_scene.amax(1)
         lo = lo.repeat_interleave(depth.shape[0] // B).reshape(-1, 1)
         hi = hi.repeat_interleave(depth.shape[0] // B).reshape(-1, 1)
         return torch.maximum(torch.minimum(depth, hi), lo)

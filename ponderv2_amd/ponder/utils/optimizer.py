@@ -1,5 +1,7 @@
 """OPTIMIZERS / SCHEDULERS registries (ponder/utils/optimizer.py:13-56, scheduler.py:12-148):
 the entries the pre-training configs name - SGD, Adam, AdamW; OneCycleLR, MultiStepLR, CosineAnnealingLR."""
+import logging
+
 import torch
 
 from .registry import Registry
@@ -11,21 +13,39 @@ for _o in (torch.optim.SGD, torch.optim.Adam, torch.optim.AdamW):
 
 
 def build_optimizer(cfg, model, param_dicts=None):
-    """``param_dicts=[dict(keyword=..., lr_scale=...)]`` gives matching parameters a scaled lr."""
-    if not param_dicts:
-        params = model.parameters()
-    else:
-        groups = [dict(params=[])] + [dict(params=[], lr=cfg["lr"] * d["lr_scale"]) for d in param_dicts]
-        for name, p in model.named_parameters():
-            for i, d in enumerate(param_dicts):
-                if d["keyword"] in name:
-                    groups[i + 1]["params"].append(p)
-                    break
-            else:
-                groups[0]["params"].append(p)
-        params = groups
+    """``param_dicts=[dict(keyword=..., lr=..., momentum=..., weight_decay=...)]`` puts the
+    parameters whose name contains ``keyword`` into their own group with those ABSOLUTE settings
+    (ponder/utils/optimizer.py:21-56; e.g. ``dict(keyword="modulation", lr=0.005)`` in the reference's
+    multi-dataset configs); group 0 keeps ``cfg.lr``.  ``lr_scale`` (a multiple of ``cfg.lr``) is
+    accepted as an extra spelling."""
     cfg = dict(cfg)
-    cfg["params"] = params
+    if param_dicts is None:
+        cfg["params"] = model.parameters()
+        return OPTIMIZERS.build(cfg=cfg)
+    groups, names = [dict(params=[], lr=cfg["lr"])], [[]]
+    for d in param_dicts:
+        g = dict(params=[])
+        for key in ("lr", "momentum", "weight_decay"):
+            if key in d:
+                g[key] = d[key]
+        if "lr_scale" in d and "lr" not in d:
+            g["lr"] = cfg["lr"] * d["lr_scale"]
+        groups.append(g)
+        names.append([])
+    for name, p in model.named_parameters():
+        for i, d in enumerate(param_dicts):
+            if d["keyword"] in name:
+                groups[i + 1]["params"].append(p)
+                names[i + 1].append(name)
+                break
+        else:
+            groups[0]["params"].append(p)
+            names[0].append(name)
+    log = logging.getLogger("ponder")
+    for i, g in enumerate(groups):
+        settings = "".join(f" {k}: {v};" for k, v in g.items() if k != "params")
+        log.info(f"Params Group {i + 1} -{settings} Params: {names[i]}.")
+    cfg["params"] = groups
     return OPTIMIZERS.build(cfg=cfg)
 
 

@@ -15,9 +15,9 @@ from . import _lib
 from .kernels import _ptr, _require_device, _stream
 
 
-# Opt-in until the kernels have been through a hardware run (PV2_FUSED_COMPOSITE=1): the head's
-# compositing (rays.alphas_to_weights, renderers.*) then goes through them where `supported`.
-ENABLED = os.environ.get("PV2_FUSED_COMPOSITE", "0") == "1"
+# The modular head's compositing (rays.alphas_to_weights, renderers.*) goes through these kernels
+# where `supported` (validated on MI355X in round 2); PV2_FUSED_COMPOSITE=0 restores the torch ops.
+ENABLED = os.environ.get("PV2_FUSED_COMPOSITE", "1") != "0"
 
 
 class _CompositeWeights(torch.autograd.Function):

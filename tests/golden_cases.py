@@ -175,7 +175,6 @@ def run_ponder_indoor(device):
     cfg = indoor_model_cfg(dict(SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
                            grid_shape=(32, 32, 8), ray_nsample=20)
     cfg["template"] = ("a", "b")  # any template list: the stub embeddings do not depend on it
-    cfg["graph_render_head"] = False  # the recorded random draws are injected from the host
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()
@@ -241,7 +240,6 @@ def run_ponder_outdoor(device):
     g = np.load(os.path.join(GOLDEN, "ponder_outdoor_small.npz"))
     cfg = outdoor_model_cfg(dict(SMALL_BACKBONE, in_channels=4,
                                  channels=(16, 32, 48, 64, 64, 48, 32, 96)), **OUTDOOR_SMALL)
-    cfg["graph_render_head"] = False  # the recorded random draws are injected from the host
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()
@@ -316,7 +314,7 @@ def run_ponder_ppt(device):
                                 channels=(16, 32, 48, 64, 64, 48, 32, 96)),
                            grid_shape=(32, 32, 8), ray_nsample=20)
     cfg.update(conditions=PPT_CONDITIONS, class_name=tuple(f"class {i}" for i in range(36)),
-               valid_index=PPT_VALID, template=("a", "b"), graph_render_head=False)
+               valid_index=PPT_VALID, template=("a", "b"))
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()

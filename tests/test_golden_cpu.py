@@ -54,44 +54,14 @@ def test_ponder_ppt_forward_matches_reference(cpu_kernels):
     gc.check_model_errors(gc.run_ponder_ppt(torch.device("cpu")))
 
 
-def test_capture_mode_reductions_give_the_same_model_results(cpu_kernels, monkeypatch):
-    """The code paths capture_safe takes WHILE A GRAPH IS BEING CAPTURED (column-sum kernel for
-    the large loss reductions, custom scalar-scale Function, two-step min/max), forced on here on
-    the host with a stand-in for the kernel: the end-to-end indoor golden must still hold, i.e.
-    shapes, dtypes and the first/second-order autograd wiring of those paths are right."""
-    from ponderv2_amd import capture_safe
-
-    class HostColSum(torch.autograd.Function):  # same contract as rownorm._ColSum: (M,1) -> (1,)
-        @staticmethod
-        def forward(ctx, x):
-            assert x.dim() == 2 and x.shape[1] == 1 and x.dtype == torch.float32
-            ctx.rows = x.shape[0]
-            return x.sum(0)
-
-        @staticmethod
-        def backward(ctx, g):
-            return g.unsqueeze(0).expand(ctx.rows, -1)
-
-    used = {"n": 0}
-
-    def capturing(t):
-        used["n"] += 1
-        return True
-
-    monkeypatch.setattr(capture_safe, "capturing", capturing)
-    monkeypatch.setattr(capture_safe, "_ColSum", HostColSum)
-    errs = gc.run_ponder_indoor(torch.device("cpu"))
-    assert used["n"] > 10
-    gc.check_model_errors(errs)
-    gc.check_model_errors(gc.run_ponder_outdoor(torch.device("cpu")), flip_tol=2e-3)
-
-
 def test_fused_compositing_path_reproduces_the_goldens(cpu_kernels, monkeypatch):
-    """With the opt-in compositing ops switched on (host doubles built from the closed-form
-    gradients the kernels implement), the NeuS head and the full indoor model still reproduce the
-    reference's numbers: the wiring in rays.alphas_to_weights / renderers is right."""
+    """The MODULAR head (what non-shipped head shapes and PV2_FUSED_HEAD=0 run) with its compositing
+    ops on the kernels' host doubles (closed-form gradients): the NeuS head and the full indoor
+    model reproduce the reference's numbers, i.e. rays.alphas_to_weights / renderers are wired right."""
     import ponderv2_amd.raymarch as rm
+    from ponderv2_amd import fused_head
 
+    monkeypatch.setattr(fused_head, "ENABLED", False)  # modular head + the compositing ops
     monkeypatch.setattr(rm, "ENABLED", True)
     calls = {"n": 0}
     orig = rm.weighted_sum

@@ -19,9 +19,13 @@ def _assert_rows(rows):
     flips = by.pop("coarse.idx flips (count)")[0]
     assert flips <= 2, rows   # searchsorted is integer work: bit-exact up to a cdf tie
     for name, (err, mag) in by.items():
-        if flips and name in ("coarse.bins", "coarse.starts", "coarse.deltas"):
+        if name in ("coarse.bins", "coarse.starts", "coarse.deltas"):
+            # positions along the ray: inverting a steep cdf amplifies fp32 round-off (measured
+            # 3e-5 of the unit interval); a flipped bin moves a sample by a whole bin
+            assert flips or err <= 1e-4, (name, err, mag)
             continue
-        assert err <= REL_TOL * mag + 1e-7, (name, err, mag)
+        tol = 5e-4 if name.endswith("inv_s") else REL_TOL   # inv_s: a sum with heavy cancellation
+        assert err <= tol * mag + 1e-7, (name, err, mag)
 
 
 def test_fused_head_stages_vs_oracle(device):

@@ -371,47 +371,7 @@ def test_sparse_first_layer_equals_dense_layer_gpu(device, with_bn):
     assert max(errs.values()) < 2e-5, errs
 
 
-# ------------------------------------------------------------------ reductions under graph capture
-def _replay_sums(fn, device, n=200000, replays=4):
-    """Capture y = fn(static_x) once, replay it with fresh inputs, return [(got, expected)]."""
-    static_x = torch.zeros(n, device=device)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        fn(static_x)
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        static_y = fn(static_x)
-    rows = []
-    for i in range(replays):
-        x = torch.randn(n, device=device) + i
-        static_x.copy_(x)
-        graph.replay()
-        rows.append((float(static_y), float(x.double().sum())))
-    return rows
-
-
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first run is the "
-                   "round-end driver's; validates capture_safe.sum_all for the graphed render head")
-def test_capture_safe_sum_survives_graph_replay(device):
-    from ponderv2_amd.capture_safe import sum_all
-
-    for got, want in _replay_sums(sum_all, device):
-        assert abs(got - want) <= 1e-3 * max(abs(want), 1.0) + 0.5, (got, want)
-
-
-@pytest.mark.xfail(strict=False, reason="canary for the suspected ROCm issue: ATen's split reduction clears "
-                   "its semaphores with hipMemsetAsync, which is not reliably replayed inside a hipGraph; if "
-                   "this XPASSes on a newer ROCm the capture_safe detour can go")
-def test_aten_large_sum_under_graph_replay_canary(device):
-    for got, want in _replay_sums(lambda t: t.sum(), device):
-        assert abs(got - want) <= 1e-3 * max(abs(want), 1.0) + 0.5, (got, want)
-
-
 # ------------------------------------------------------------------ compositing (raymarch.hip)
-@pytest.mark.xfail(strict=False, reason="kernels written after the round's GPU budget was spent; first "
-                   "hardware run is the round-end driver's.  Not on the default path yet.")
 @pytest.mark.parametrize("rays,samples", [(1, 1), (5, 64), (1030, 132), (300, 96), (17, 256)])
 def test_raymarch_weights_vs_oracle(device, rays, samples):
     from oracle import raymarch as orm
@@ -433,8 +393,6 @@ def test_raymarch_weights_vs_oracle(device, rays, samples):
         assert err < 1e-5, (name, err)
 
 
-@pytest.mark.xfail(strict=False, reason="kernels written after the round's GPU budget was spent; first "
-                   "hardware run is the round-end driver's.  Not on the default path yet.")
 @pytest.mark.parametrize("features", [1, 3, 31, 32, 128, 131, 512])
 def test_raymarch_weighted_sum_vs_oracle(device, features):
     from oracle import raymarch as orm

@@ -227,28 +227,6 @@ def test_block_masking_keeps_the_reference_set():
     assert torch.allclose(token.grad, torch.full((1, 4), float(masked.sum())))
 
 
-def test_capture_safe_reductions_are_the_plain_ops_outside_capture():
-    """capture_safe.* must be numerically the ordinary torch reductions whenever no graph is being
-    captured (CPU here), including their gradients."""
-    from ponderv2_amd import capture_safe as cs
-
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(5000, 3, generator=g, dtype=torch.double, requires_grad=True)
-    s = torch.tensor([1.7], dtype=torch.double, requires_grad=True)
-    mask = torch.rand(5000, 3, generator=g) > 0.5
-    assert cs.sum_all(mask).item() == mask.sum().item()
-    a = cs.mean_all(cs.scale_by_scalar(x, s) ** 2) + cs.sum_all(x * mask)
-    b = ((x * s) ** 2).mean() + (x * mask).sum()
-    ga, gb = torch.autograd.grad(a, [x, s]), torch.autograd.grad(b, [x, s])
-    assert torch.equal(a, b) and all(torch.equal(p, q) for p, q in zip(ga, gb))
-    y = torch.randn(3, 8 * 11, generator=g)
-    lo, hi = cs.rowwise_min_max(y, group=11)
-    assert torch.equal(lo, y.amin(1)) and torch.equal(hi, y.amax(1))
-    # the custom Function behind scale_by_scalar, exercised directly (it only engages during capture)
-    torch.autograd.gradcheck(cs._ScaleByScalar.apply, (x[:50], s))
-    torch.autograd.gradgradcheck(cs._ScaleByScalar.apply, (x[:20], s))
-
-
 @pytest.mark.parametrize("hash_type", ["fnv", "ravel"])
 def test_device_grid_sample_same_voxels_as_host_transform(hash_type):
     """grid_sample_torch (runs on any device) against the host GridSample: identical hash bit
@@ -309,3 +287,70 @@ def test_whole_model_autocast_runs_through_the_host_code(monkeypatch):
         assert torch.isfinite(out["loss"])
         grads = [p.grad for p in model.backbone.parameters() if p.grad is not None]
         assert grads and all(g.dtype == torch.float32 and torch.isfinite(g).all() for g in grads)
+
+
+def test_loaders_apply_the_point_budget_of_the_config():
+    """mix_prob / max_point reach every loader's collate as in the reference (engines/train.py:
+    243-258, datasets/dataloader.py:67-80): the reference's pre-training configs set
+    max_point = 2000000, which must build and must drop samples over the budget."""
+    from ponderv2_amd.ponder.datasets import ConcatDataset, MultiDatasetDataloader
+    from ponderv2_amd.ponder.datasets.collate import loader_collate, point_collate_fn
+
+    class Scenes(torch.utils.data.Dataset):
+        loop = 1
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            n = 10 * (i + 1)
+            return dict(coord=torch.zeros(n, 3), offset=torch.tensor([n]))
+
+    # reader-style dataset (no collate of its own): the reference's partial(point_collate_fn, ...)
+    col = loader_collate(Scenes(), mix_prob=0, max_point=35)
+    assert col.func is point_collate_fn and col.keywords == dict(mix_prob=0, max_point=35)
+    batch = col([Scenes()[0], Scenes()[1], Scenes()[2]])       # 10 + 20 fit, 30 does not
+    assert batch["offset"].tolist() == [10, 30] and batch["coord"].shape[0] == 30
+    # dataset with its own batch assembly: same budget around it
+    from ponderv2_amd.ponder.datasets import SyntheticRGBDDataset, make_scene
+
+    ds = SyntheticRGBDDataset(length=2, num_views=1, image_hw=(12, 16), n_raw=2000)
+    samples = [ds[0], ds[1]]
+    n0 = len(samples[0]["coord"])
+    assert loader_collate(ds, max_point=n0 + 1)(samples)["offset"].tolist() == [n0]
+    mixed = loader_collate(ds, mix_prob=1.0)(samples)          # Mix3D: two scenes become one
+    assert mixed["offset"].tolist() == [n0 + len(samples[1]["coord"])] == mixed["offset_host"]
+    # the multi-dataset loader no longer refuses the reference's settings
+    loader = MultiDatasetDataloader(ConcatDataset([Scenes(), Scenes()], loop=1), 2, 0, mix_prob=0,
+                                    seed=3, max_point=2000000)
+    first = next(iter(loader))
+    assert first["offset"].numel() == 2
+
+
+def test_build_optimizer_takes_the_reference_param_dicts():
+    """Absolute per-group lr / momentum / weight_decay keyed by name substring
+    (ponder/utils/optimizer.py:21-56), group 0 at cfg.lr."""
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+    from ponderv2_amd.ponder.utils.optimizer import build_optimizer
+
+    model = torch.nn.Sequential()
+    model.add_module("backbone", torch.nn.Linear(3, 3))
+    model.add_module("modulation", torch.nn.Linear(3, 3))
+    model.add_module("head", torch.nn.Linear(3, 3))
+    cfg = ConfigDict(dict(type="SGD", lr=0.05, momentum=0.9, weight_decay=1e-4))
+    opt = build_optimizer(cfg, model, [ConfigDict(dict(keyword="modulation", lr=0.005)),
+                                       ConfigDict(dict(keyword="head", momentum=0.5, weight_decay=0.0))])
+    g0, g1, g2 = opt.param_groups
+    assert (g0["lr"], g0["momentum"], g0["weight_decay"]) == (0.05, 0.9, 1e-4) and len(g0["params"]) == 2
+    assert (g1["lr"], g1["momentum"]) == (0.005, 0.9) and len(g1["params"]) == 2
+    assert (g2["lr"], g2["momentum"], g2["weight_decay"]) == (0.05, 0.5, 0.0)
+    assert len(build_optimizer(cfg, model, None).param_groups) == 1
+
+
+def test_worker_seeds_follow_the_reference_formula(monkeypatch):
+    from ponderv2_amd.ponder.engines import defaults
+
+    seen = []
+    monkeypatch.setattr(defaults, "set_seed", seen.append)
+    defaults.worker_init_fn(3, num_workers=8, rank=2, seed=100)
+    assert seen == [8 * 2 + 3 + 100]

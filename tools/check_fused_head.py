@@ -128,11 +128,13 @@ def run(device, seed=0, verbose=True, **shape):
     gfeat, gvec, gz, tmat = new(N, C), new(N, 4), new(N, 2 * fhd.H), new(N, fhd.H)
     gq, gh, gy, sums = new(N, fhd.FS), new(N, 68), new(N, 4), new(fhd.NSUM)
     MWd, W1d = d["MW"], d["W1"]
+    # (named, so the transposed copies stay alive until the launch has been enqueued)
+    Mt, W1gt, Wc1t = (MWd[:fhd.H].t().contiguous(), W1d[1:].t().contiguous(),
+                      MWd[fhd.H:].t().contiguous())
     B, Z, Y, X, _ = p["vol"].shape
     _lib.check(L.pv2_neus_field_backward(
         _ptr(d["vol"]), B, Z, Y, X, C, _ptr(d["origins"]), _ptr(d["dirs"]), _ptr(d["starts"]),
-        _ptr(d["deltas"]), R, S, _ptr(MWd), _ptr(W1d), _ptr(MWd[:fhd.H].t().contiguous()),
-        _ptr(W1d[1:].t().contiguous()), _ptr(MWd[fhd.H:].t().contiguous()), _ptr(d["A"]),
+        _ptr(d["deltas"]), R, S, _ptr(MWd), _ptr(W1d), _ptr(Mt), _ptr(W1gt), _ptr(Wc1t), _ptr(d["A"]),
         _ptr(d["inv_s"].reshape(1)), 1, 1.0 + 0.1 + 10e-4, _ptr(saved["sdf"]), _ptr(saved["vals"]),
         _ptr(saved["sh0"]), _ptr(saved["sq"]), _ptr(saved["weights"]), _ptr(g_alpha), _ptr(d["g_sdf"]),
         _ptr(d["g_grad"]), _ptr(d["g_comp"]), _ptr(gfeat), _ptr(gvec), _ptr(gz), _ptr(tmat), _ptr(gq),

@@ -36,11 +36,12 @@ def sect():
     else:
         ray, d = model.prepare_ray(d); t.append(time.perf_counter())
         vol = model.prepare_volume(d); t.append(time.perf_counter())
-    res = model._graphed(vol[0], ray); t.append(time.perf_counter())
+    out = model.render_func(ray, vol); t.append(time.perf_counter())
+    res = model.render_loss(out, ray); t.append(time.perf_counter())
     opt.zero_grad(set_to_none=True); res[0].backward(); t.append(time.perf_counter())
     opt.step(); t.append(time.perf_counter())
     torch.cuda.synchronize(); t.append(time.perf_counter())
-    names = ["backbone_fwd", "prepare_ray", "prepare_volume", "render(graph)", "backward", "opt", "drain"]
+    names = ["backbone_fwd", "prepare_ray", "prepare_volume", "render", "losses", "backward", "opt", "drain"]
     print(" | ".join("%s %.2f" % (n, 1e3 * (b - a)) for n, a, b in zip(names, t[:-1], t[1:])), flush=True)
 for _ in range(3): sect()
 pr = cProfile.Profile(); pr.enable()
