@@ -97,6 +97,18 @@ int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_row
                       const int32_t* block_sums, int32_t* pair_other, int32_t* pair_row,
                       pv2_stream_t stream);
 
+/* Table helpers for the output-stationary conv below.
+ * invert: out[k*n_out_cols + tbl[k*stride_in + j]] = j for valid entries (out is filled with -1
+ *   first); n_cols_dev (device int32, may be NULL) caps the columns read.  Every (k, value) pair may
+ *   occur at most once (true for the strided-conv tables: a child has one parent per offset).
+ * masks: mask[i] = bit k set iff tbl[k*stride_in + i] >= 0 (K <= 63); columns >= *n_cols_dev get
+ *   the all-ones mask so they sort last. */
+int pv2_table_invert(const int32_t* tbl, int K, int64_t n_cols, int64_t stride_in,
+                     const int32_t* n_cols_dev, int32_t* out, int64_t n_out_cols,
+                     pv2_stream_t stream);
+int pv2_table_masks(const int32_t* tbl, int K, int64_t n_cols, int64_t stride_in,
+                    const int32_t* n_cols_dev, int64_t* mask, pv2_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sparse convolution arithmetic (gather -> MFMA f32 GEMM -> scatter-add, one launch per conv).
  * Replaces spconv 2.x's ops.indice_conv / indice_conv_backward (same call sites as above).
@@ -123,6 +135,20 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
                        const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
                        int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
                        float* out_feat, int64_t n_out, pv2_stream_t stream);
+
+/* Output-stationary form of the same convolution (same reference call sites): every output row is
+ * computed by ONE workgroup from the gather table and written once - no atomics, no zero-fill,
+ * bitwise reproducible.
+ *   out[o, n] = bias[n] + sum_k sum_c in[nbr[k*nbr_stride + o], c] * weight[n, kw(k), c]
+ * with kw(k) = kflip ? K-1-k : k, entries nbr < 0 skipped.  perm (int32 [n_out], may be NULL) is
+ * the order in which rows are grouped into 32-row tiles (rows sorted by pv2_table_masks keep the
+ * gathered tiles dense); results do not depend on it beyond fp32 summation order per row - which
+ * is fixed for a given perm.  bias may be NULL.  Grad-input of a submanifold conv = the same call
+ * on grad_out with the transposed weights [c_in, K, c_out] and kflip = 1 (coordinates unique). */
+int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                          int c_out, const int32_t* nbr, int64_t nbr_stride, const int32_t* perm,
+                          int kflip, const float* bias, float* out_feat, int64_t n_out,
+                          pv2_stream_t stream);
 
 /* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
  * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count chunks of

@@ -249,9 +249,66 @@ __global__ void down_table_kernel(const int4* __restrict__ coords, int64_t n, in
   }
 }
 
+// out[k][tbl[k][j]] = j for every valid entry: turns "which input feeds output o under offset k"
+// into "which output does input j feed under offset k" (and back).  Every (k, value) pair occurs
+// at most once in the tables of this file, so the scatter is race-free and deterministic.
+__global__ void table_invert_kernel(const int32_t* __restrict__ tbl, int K, int64_t n_cols,
+                                    int64_t stride_in, const int32_t* __restrict__ n_cols_dev,
+                                    int32_t* __restrict__ out, int64_t stride_out) {
+  const int64_t cols = n_cols_dev ? min((int64_t)*n_cols_dev, n_cols) : n_cols;
+  const int64_t total = (int64_t)K * cols;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t k = e / cols, j = e % cols;
+    const int32_t v = tbl[k * stride_in + j];
+    if (v >= 0) out[k * stride_out + v] = (int32_t)j;
+  }
+}
+
+// mask[i] = bit k set when tbl[k][i] >= 0 (K <= 64): the key the output-stationary conv sorts its
+// rows by, so that the rows of one tile use the same few kernel offsets.
+__global__ void table_masks_kernel(const int32_t* __restrict__ tbl, int K, int64_t n_cols,
+                                   int64_t stride_in, const int32_t* __restrict__ n_cols_dev,
+                                   int64_t* __restrict__ mask) {
+  const int64_t cols = n_cols_dev ? min((int64_t)*n_cols_dev, n_cols) : n_cols;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cols; i += stride) {
+    uint64_t m = 0;
+    if (i < cols)
+      for (int k = 0; k < K; ++k) m |= (uint64_t)(tbl[(int64_t)k * stride_in + i] >= 0) << k;
+    else
+      m = ~0ull >> 1;  // columns past the valid count sort last
+    mask[i] = (int64_t)m;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pv2_table_invert(const int32_t* tbl, int K, int64_t n_cols, int64_t stride_in,
+                     const int32_t* n_cols_dev, int32_t* out, int64_t n_out_cols,
+                     pv2_stream_t stream) {
+  PV2_REQUIRE(K >= 1 && n_cols >= 0 && n_out_cols >= 0 && stride_in >= n_cols,
+              "pv2_table_invert: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out_cols > 0)
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(pv2::grid_for(K * n_out_cols, 256)), dim3(256), 0, s,
+                       out, (int64_t)K * n_out_cols, -1);
+  if (n_cols > 0)
+    hipLaunchKernelGGL(table_invert_kernel, dim3(pv2::grid_for(K * n_cols, 256)), dim3(256), 0, s,
+                       tbl, K, n_cols, stride_in, n_cols_dev, out, n_out_cols);
+  return pv2::check_launch("table_invert");
+}
+
+int pv2_table_masks(const int32_t* tbl, int K, int64_t n_cols, int64_t stride_in,
+                    const int32_t* n_cols_dev, int64_t* mask, pv2_stream_t stream) {
+  PV2_REQUIRE(K >= 1 && K <= 63, "pv2_table_masks: 1 <= K <= 63");
+  if (n_cols == 0) return PV2_OK;
+  hipLaunchKernelGGL(table_masks_kernel, dim3(pv2::grid_for(n_cols, 256)), dim3(256), 0,
+                     (hipStream_t)stream, tbl, K, n_cols, stride_in, n_cols_dev, mask);
+  return pv2::check_launch("table_masks");
+}
 
 int pv2_hash_build(const int32_t* coords, int64_t n, uint64_t* table_keys, int32_t* table_vals,
                    int64_t table_size, pv2_stream_t stream) {

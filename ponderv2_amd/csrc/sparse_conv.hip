@@ -567,6 +567,100 @@ __global__ __launch_bounds__(256) void skinny_gemm_tn_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Output-stationary sparse conv: no atomics, no zero-fill, bitwise run-to-run reproducible.
+//
+//   Y[o, n] = bias[n] + sum_k sum_c X[nbr[k][o], c] * W[n, kmap(k), c]        (nbr < 0: no term)
+//
+// `nbr` is the [K, n_out] gather table of the rulebook (rulebook.hip): for a submanifold conv the
+// neighbour table itself serves the forward pass and - read with kmap(k) = K-1-k and the
+// transposed weights - the grad-input pass (the pair (j -> i, k) is the pair (i -> j, K-1-k)); a
+// strided conv uses its child table forwards and the inverted (parent) table backwards.
+//
+// A workgroup owns 32 output rows x 32*NB output channels.  Rows are taken in the order `perm`
+// (rows sorted by their bit mask of present offsets, so that a tile's rows share offsets and few
+// gathered rows are empty).  The four waves split the tile's PRESENT offsets round-robin; each
+// accumulates its share in registers (A = gathered rows, global -> registers, 32-byte runs; B =
+// weight rows of its offset from L2), then the partial tiles meet in LDS and wave 0 adds them in a
+// FIXED order and writes every output element exactly once.
+template <int NB, bool VEC>
+__global__ __launch_bounds__(256) void spconv_os_kernel(
+    const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
+    const int32_t* __restrict__ nbr, int64_t nbr_stride, const int32_t* __restrict__ perm,
+    int kflip, const float* __restrict__ bias, int64_t n_out, float* __restrict__ Y) {
+  __shared__ float red[3][NB * 16 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t r = (int64_t)blockIdx.x * 32 + i;
+  const bool rv = r < n_out;
+  const int orow = rv ? (perm ? perm[r] : (int)r) : 0;
+  const int n0 = blockIdx.y * NB * 32;
+
+  const float* wrow[NB];
+  bool wok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + nb * 32 + i;
+    wok[nb] = n < c_out;
+    wrow[nb] = W + (int64_t)(wok[nb] ? n : 0) * K * c_in + 4 * h;
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
+
+  int present = 0;
+  int idx_next = rv ? nbr[orow] : -1;
+  for (int k = 0; k < K; ++k) {
+    const int idx = idx_next;
+    if (k + 1 < K) idx_next = rv ? nbr[(int64_t)(k + 1) * nbr_stride + orow] : -1;
+    if (__ballot(idx >= 0) == 0ull) continue;     // no row of the tile has this offset
+    if ((present++ & 3) != wave) continue;        // another wave's share
+    const bool pv = idx >= 0;
+    const float* xrow = X + (int64_t)(pv ? idx : 0) * c_in + 4 * h;
+    const int kw = kflip ? K - 1 - k : k;
+#pragma unroll 2
+    for (int kk = 0; kk < c_in; kk += 8) {
+      const float4 a = load4<VEC>(xrow, kk, c_in - 4 * h, pv);
+      float4 b[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        b[nb] = load4<VEC>(wrow[nb] + (int64_t)kw * c_in, kk, c_in - 4 * h, wok[nb]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nb].x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nb].y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nb].z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nb].w, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+
+  if (wave > 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[wave - 1][(nb * 16 + q) * 64 + lane] = acc[nb][q];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  int out_row[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out_row[q] = __shfl(rv ? orow : -1, (q & 3) + 8 * (q >> 2) + 4 * h);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + nb * 32 + i;
+    const float bv = (bias && n < c_out) ? bias[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = (nb * 16 + q) * 64 + lane;
+      const float v = ((acc[nb][q] + red[0][e]) + red[1][e]) + red[2][e];
+      if (out_row[q] >= 0 && n < c_out) Y[(int64_t)out_row[q] * c_out + n] = v + bv;
+    }
+  }
+}
+
 template <int NB>
 int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -684,6 +778,44 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
     default: return launch_fwd<4>(PV2_FWD_ARGS);
   }
 #undef PV2_FWD_ARGS
+}
+
+int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                          int c_out, const int32_t* nbr, int64_t nbr_stride, const int32_t* perm,
+                          int kflip, const float* bias, float* out_feat, int64_t n_out,
+                          pv2_stream_t stream) {
+  PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_os_forward: bad channel/offset count");
+  PV2_REQUIRE(nbr_stride >= n_out && n_out < 0x7fffffffLL, "pv2_spconv_os_forward: bad row count");
+  (void)n_in;
+  if (n_out == 0) return PV2_OK;
+  const int nblk = (c_out + 31) / 32;
+  // wide tiles amortise the gathered rows; narrow ones give small layers enough workgroups
+  const int64_t row_tiles = (n_out + 31) / 32;
+  int nb = nblk >= 4 ? 4 : nblk;
+  if (nb == 4 && row_tiles * ((nblk + 3) / 4) < 512) nb = 2;
+  if (nb == 2 && row_tiles * ((nblk + 1) / 2) < 512) nb = 1;
+  const int groups = (nblk + nb - 1) / nb;
+  PV2_REQUIRE(row_tiles < 0x7fffffffLL && groups < 65536, "pv2_spconv_os_forward: grid too large");
+  const bool vec = (c_in % 8) == 0;
+  const dim3 grid((unsigned)row_tiles, (unsigned)groups);
+  hipStream_t s = (hipStream_t)stream;
+#define PV2_LAUNCH_OS(NB)                                                                          \
+  do {                                                                                             \
+    if (vec)                                                                                       \
+      hipLaunchKernelGGL((spconv_os_kernel<NB, true>), grid, dim3(256), 0, s, in_feat, c_in,       \
+                         weight, K, c_out, nbr, nbr_stride, perm, kflip, bias, n_out, out_feat);   \
+    else                                                                                           \
+      hipLaunchKernelGGL((spconv_os_kernel<NB, false>), grid, dim3(256), 0, s, in_feat, c_in,      \
+                         weight, K, c_out, nbr, nbr_stride, perm, kflip, bias, n_out, out_feat);   \
+  } while (0)
+  switch (nb) {
+    case 1: PV2_LAUNCH_OS(1); break;
+    case 2: PV2_LAUNCH_OS(2); break;
+    case 3: PV2_LAUNCH_OS(3); break;
+    default: PV2_LAUNCH_OS(4); break;
+  }
+#undef PV2_LAUNCH_OS
+  return pv2::check_launch("spconv_os_forward");
 }
 
 int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,

@@ -12,7 +12,25 @@ import torch
 from . import _lib
 from ._lib import PAIR_TILE, SCAN_CHUNK, WGRAD_TILE, PointsDesc, VolumeDesc
 
+import os
+
 FWD_LDS_TILE = 128  # tile of the LDS-staged forward kernel (pv2_spconv_forward_tile)
+# Which forward / grad-input kernel a conv with a gather table on its rulebook runs on:
+#   "auto" (default)  the output-stationary kernel (no atomics, no zero-fill, bitwise reproducible)
+#                     where it is the faster one on MI355X - strided and inverse convs, 1.0-1.7x
+#                     (profiles/r02_spconv_os_ab.txt) - and the pair-major scatter-add kernel for
+#                     the 27-offset submanifold convs, whose weight slabs it shares between 128 pairs;
+#   True  / PV2_SPCONV_OS=1   output-stationary everywhere: the DETERMINISTIC mode (bitwise
+#                     identical forward passes; used by the parity tests that bound gradients);
+#   False / PV2_SPCONV_OS=0   scatter-add everywhere.
+_OS_ENV = os.environ.get("PV2_SPCONV_OS", "auto")
+USE_OS = True if _OS_ENV == "1" else False if _OS_ENV == "0" else "auto"
+
+
+def _use_os(rb) -> bool:
+    if rb.nbr is None or USE_OS is False:
+        return False
+    return True if USE_OS is True else rb.K <= 8
 # Run the centre offset of submanifold convs as a separate plain-store pass (no zero-fill, fewer
 # atomics).  Measured neutral on MI355X at the ScanNet batch (the second launch and its smaller
 # grids cost what the saved fill and atomics gain), so the single-launch path is the default.
@@ -61,6 +79,14 @@ class Rulebook:
     # single offset of a 1x1 conv); -1 when there is none (strided / inverse convs)
     center_k: int = -1
     _tiles: dict = field(default_factory=dict)
+    # output-stationary view: gather table [K, nbr_stride] (input row feeding output row o under
+    # offset k, or -1), the row order `perm` that groups rows with equal offset masks, and whether
+    # the weight offsets are read mirrored (grad-input of a submanifold conv)
+    nbr: Optional[torch.Tensor] = None
+    nbr_stride: int = 0
+    perm: Optional[torch.Tensor] = None
+    kflip: int = 0
+    _transposed_os: Optional[tuple] = None   # (nbr, stride, perm, kflip) of the transposed rulebook
 
     @property
     def n_pairs(self) -> int:
@@ -85,6 +111,9 @@ class Rulebook:
         rb = Rulebook(self.K, self.n_out, self.n_in, self.pair_out, self.pair_in, self.kstart,
                       self.kstart_host, self.center_k if self.n_in == self.n_out else -1)
         rb._tiles = self._tiles
+        if self._transposed_os is not None:
+            rb.nbr, rb.nbr_stride, rb.perm, rb.kflip = self._transposed_os
+            rb._transposed_os = (self.nbr, self.nbr_stride, self.perm, self.kflip)
         return rb
 
 
@@ -107,6 +136,17 @@ def _compact(tbl: torch.Tensor, K: int, n: int, n_rows_dev: Optional[torch.Tenso
     return pair_other, pair_row, kstart, kstart_host
 
 
+def _mask_order(tbl: torch.Tensor, K: int, n_cols: int, stride: int) -> Optional[torch.Tensor]:
+    """Row order for the output-stationary kernel: rows sorted (stably) by the bit mask of their
+    present offsets.  None (natural order) for windows wider than 63 offsets and tiny tables."""
+    if K > 63 or n_cols < 64:
+        return None
+    mask = torch.empty(n_cols, dtype=torch.int64, device=tbl.device)
+    _lib.check(_lib.lib().pv2_table_masks(_ptr(tbl), K, n_cols, stride, None, _ptr(mask),
+                                          _stream(tbl)), "pv2_table_masks")
+    return torch.argsort(mask, stable=True).to(torch.int32)
+
+
 def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     """coords int32 [N,4] (b,x,y,z) -> rulebook of a submanifold conv with an odd cubic kernel."""
     _require_device(coords)
@@ -118,8 +158,11 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if ksize == 1:
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         kh = np.array([0, n], dtype=np.int64)
-        return Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh,
-                        center_k=0)
+        rb = Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh,
+                      center_k=0)
+        rb.nbr, rb.nbr_stride = ar, n
+        rb._transposed_os = (ar, n, None, 0)
+        return rb
     L = _lib.lib()
     tsize = 1 << max(4, int(2 * max(n, 1) - 1).bit_length())
     keys = torch.empty(tsize, dtype=torch.int64, device=dev)
@@ -130,7 +173,13 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     _lib.check(L.pv2_subm_neighbor_table(_ptr(coords), n, ksize, _ptr(keys), _ptr(vals), tsize,
                                          _ptr(nbr), _stream(coords)), "pv2_subm_neighbor_table")
     pair_in, pair_out, kstart, kstart_host = _compact(nbr, K, n, None)
-    return Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host, center_k=K // 2)
+    rb = Rulebook(K, n, n, pair_in, pair_out, kstart, kstart_host, center_k=K // 2)
+    if n > 0:
+        # the neighbour table is its own transpose up to mirroring the offsets (coordinates are
+        # unique): grad-input reads the same table with the weight offsets flipped
+        rb.nbr, rb.nbr_stride, rb.perm = nbr, n, _mask_order(nbr, K, n, n)
+        rb._transposed_os = (nbr, n, rb.perm, 1)
+    return rb
 
 
 def rulebook_from_table(tbl: torch.Tensor, K: int, n_in: int, n_out: int) -> Rulebook:
@@ -170,6 +219,14 @@ def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List
     pair_in, pair_out, kstart, kstart_host = _compact(tbl, K, n, n_out_dev)
     n_out = int(n_out_dev.item())
     rb = Rulebook(K, n, n_out, pair_in, pair_out, kstart, kstart_host)
+    if n > 0 and n_out > 0:
+        # forward gathers the children of every output voxel (tbl, row stride n); the transposed
+        # use (grad-input, inverse conv) gathers the one parent of every input voxel
+        parent = torch.empty(K * n, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_table_invert(_ptr(tbl), K, n_out, n, None, _ptr(parent), n, st),
+                   "pv2_table_invert")
+        rb.nbr, rb.nbr_stride, rb.perm = tbl, n, _mask_order(tbl, K, n_out, n)
+        rb._transposed_os = (parent, n, _mask_order(parent, K, n, n), 0)
     return rb, out_coords[:n_out]
 
 
@@ -177,8 +234,10 @@ def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List
 # Sparse conv arithmetic
 # --------------------------------------------------------------------------------------------
 def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[pair_out] += W[k] . feats[pair_in].  weight_okc: fp32 [c_out, K, c_in] contiguous."""
+                   out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[pair_out] += W[k] . feats[pair_in].  weight_okc: fp32 [c_out, K, c_in] contiguous.
+    With a gather table on the rulebook (and no tensor to accumulate onto) the output-stationary
+    kernel computes ``bias + conv`` and writes every element once."""
     _require_device(feats, weight_okc)
     assert feats.dtype == torch.float32 and weight_okc.dtype == torch.float32
     feats = feats.contiguous()
@@ -186,6 +245,14 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     c_out, K, c_in = weight_okc.shape
     assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
     L = _lib.lib()
+    if out is None and _use_os(rb):
+        out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
+        _lib.check(L.pv2_spconv_os_forward(
+            _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.nbr), rb.nbr_stride,
+            _ptr(rb.perm), rb.kflip, _ptr(bias), _ptr(out), rb.n_out, _stream(feats)),
+            "pv2_spconv_os_forward")
+        return out
+    assert bias is None or out is None, "bias is fused only by the output-stationary path"
     tile = L.pv2_spconv_forward_tile(c_in, c_out)
     tile_start, n_tiles, tile_host = rb.tiles(tile)
     c_lo = c_hi = 0
@@ -200,7 +267,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
         _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
         _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, c_lo, c_hi, _ptr(out),
         rb.n_out, _stream(feats)), "pv2_spconv_forward")
-    return out
+    return out if bias is None else out + bias
 
 
 def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rulebook,

@@ -410,3 +410,80 @@ def test_raymarch_weighted_sum_vs_oracle(device, features):
     for name, got, r in (("out", out, ref), ("gw", gw, gw_ref), ("gx", gx, gx_ref)):
         err = (got.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
         assert err < 1e-5, (name, err)
+
+
+# ------------------------------------------------------------------ output-stationary conv
+@pytest.mark.parametrize("c_in,c_out,ksize", [(6, 32, 5), (32, 64, 3), (128, 128, 3), (256, 96, 3)])
+def test_output_stationary_conv_is_bitwise_reproducible_and_equals_scatter_kernel(
+        device, c_in, c_out, ksize, monkeypatch):
+    """Forward and grad-input on the output-stationary kernel: identical bits on every call, and
+    the same numbers (fp32 re-association only) as the pair-major scatter-add kernels."""
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(c_in + c_out)
+    coords = random_voxels(8, batch=2, n_per_batch=900)
+    n = len(coords)
+    monkeypatch.setattr(K, "USE_OS", True)
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), ksize)
+    assert rb.nbr is not None
+    x = torch.randn(n, c_in, device=device)
+    w = torch.randn(c_out, ksize ** 3, c_in, device=device) * 0.1
+    g = torch.randn(n, c_out, device=device)
+    w_t = w.permute(2, 1, 0).contiguous()
+    runs = [(K.spconv_forward(x, w, rb), K.spconv_forward(g, w_t, rb.transposed())) for _ in range(3)]
+    for y, dx in runs[1:]:
+        assert torch.equal(y, runs[0][0]) and torch.equal(dx, runs[0][1])
+    monkeypatch.setattr(K, "USE_OS", False)
+    y_ref, dx_ref = K.spconv_forward(x, w, rb), K.spconv_forward(g, w_t, rb.transposed())
+    assert (runs[0][0] - y_ref).abs().max() <= 2e-5 * y_ref.abs().max()
+    assert (runs[0][1] - dx_ref).abs().max() <= 2e-5 * dx_ref.abs().max()
+
+
+def test_output_stationary_strided_and_inverse_conv(device, monkeypatch):
+    """Strided conv (children gathered per output voxel), its grad-input / the inverse conv (one
+    parent per input voxel) and a fused bias, against the scatter-add kernels; bitwise repeatable."""
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(11)
+    coords = random_voxels(9, batch=2, n_per_batch=2500)
+    shape = [68, 66, 58]
+    rb, oc = K.build_downsample_rulebook(torch.from_numpy(coords).to(device), 2, shape)
+    n, m = len(coords), rb.n_out
+    x = torch.randn(n, 32, device=device)
+    w = torch.randn(64, 8, 32, device=device) * 0.1
+    w_inv = torch.randn(48, 8, 64, device=device) * 0.1
+    bias = torch.randn(64, device=device)
+    down = K.spconv_forward(x, w, rb, bias=bias)
+    up = K.spconv_forward(down, w_inv, rb.transposed())
+    assert down.shape == (m, 64) and up.shape == (n, 48)
+    assert torch.equal(down, K.spconv_forward(x, w, rb, bias=bias))
+    assert torch.equal(up, K.spconv_forward(down, w_inv, rb.transposed()))
+    monkeypatch.setattr(K, "USE_OS", False)
+    down_ref = K.spconv_forward(x, w, rb) + bias
+    up_ref = K.spconv_forward(down_ref, w_inv, rb.transposed())
+    assert (down - down_ref).abs().max() <= 2e-5 * down_ref.abs().max()
+    assert (up - up_ref).abs().max() <= 2e-5 * up_ref.abs().max()
+
+
+def test_spunet_forward_is_bitwise_reproducible(device, monkeypatch):
+    """Deterministic mode (output-stationary convs everywhere): forward passes of the backbone on
+    the same input give identical bits - no atomics on the forward path."""
+    import golden_cases as gc
+    from ponderv2_amd import kernels as K
+
+    monkeypatch.setattr(K, "USE_OS", True)
+    from oracle.detweights import fill_deterministic, formula_tensor
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(gc.os.path.join(gc.GOLDEN, "spunet_small.npz"))
+    coords = g["coords"]
+    counts = np.bincount(coords[:, 0])
+    model = build_model(ConfigDict(gc.SMALL_BACKBONE))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    feat = formula_tensor("spunet.feat", (len(coords), 6), 1.0).to(device)
+    batch = dict(grid_coord=torch.from_numpy(coords[:, 1:].astype(np.int64)).to(device), feat=feat,
+                 offset=torch.from_numpy(np.cumsum(counts)).long().to(device))
+    outs = [model(dict(batch)).clone() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
