@@ -97,6 +97,11 @@ int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_row
                       const int32_t* block_sums, int32_t* pair_other, int32_t* pair_row,
                       pv2_stream_t stream);
 
+/* out[s*(K+1) + k] = sum_{j<k} ceil((kstart[j+1]-kstart[j]) / tile_sizes[s]) for up to 4 tile sizes
+ * (host array): the tile prefixes (`tile_start`) the conv entry points below take. */
+int pv2_tile_prefix(const int32_t* kstart, int K, const int32_t* tile_sizes, int n_sizes,
+                    int32_t* out, pv2_stream_t stream);
+
 /* Table helpers for the output-stationary conv below.
  * invert: out[k*n_out_cols + tbl[k*stride_in + j]] = j for valid entries (out is filled with -1
  *   first); n_cols_dev (device int32, may be NULL) caps the columns read.  Every (k, value) pair may
@@ -187,18 +192,19 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
  *   backward: g = dy * (y > 0) when y is given (fused ReLU), else dy;
  *             dx = weight*invstd*(g - mean(g) - xhat*mean(g*xhat)); dresidual = g (optional);
  *             gsum[0..c) = sum g (= dbias), gsum[c..2c) = sum g*xhat (= dweight).
- * zeroed_ws: device scratch of 2*c + 1 doubles that MUST BE ALL ZERO on entry; both calls leave it
- * all zero again (the statistics kernel's last block consumes and clears it), so one buffer,
- * cleared once at allocation, serves every layer issued on the same stream.
- * weight / bias may be NULL (affine=False).
+ * workspace: device scratch of pv2_bn_workspace_floats(c) floats, contents irrelevant on entry (the
+ * statistics kernel writes per-block partial sums into it, the apply kernel adds them in a fixed
+ * order: no atomics, bitwise reproducible); one buffer serves every layer issued on one stream.
+ * c <= 1024.  weight / bias may be NULL (affine=False).
  * ------------------------------------------------------------------------------------------ */
+int64_t pv2_bn_workspace_floats(int c);
 int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const float* bias,
                    const float* residual, int relu, float eps, float momentum,
-                   float* running_mean, float* running_var, double* zeroed_ws,
+                   float* running_mean, float* running_var, float* workspace,
                    float* mean_invstd, float* y, pv2_stream_t stream);
 int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     const float* mean_invstd, const float* weight, int64_t n, int c,
-                    double* zeroed_ws, float* gsum, float* dx, float* dresidual_or_null,
+                    float* workspace, float* gsum, float* dx, float* dresidual_or_null,
                     pv2_stream_t stream);
 /* out[c] = sum_r x[r, c] */
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);

@@ -27,7 +27,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "pv2_spconv_forward": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, c_int64,
                 c_int64, _P, c_int64, _P]),
+    "pv2_tile_prefix": (c_int, [_P, c_int, POINTER(c_int32), c_int, _P, _P]),
     "pv2_table_invert": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_int64, _P]),
     "pv2_table_masks": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "pv2_spconv_os_forward": (
@@ -57,6 +58,7 @@ SIGNATURES = {
                 _P]),
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
+    "pv2_bn_workspace_floats": (c_int64, [c_int]),
     "pv2_bn_forward": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P,
                                _P, _P, _P]),
     "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),

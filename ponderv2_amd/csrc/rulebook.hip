@@ -155,6 +155,22 @@ __global__ void table_scan_kernel(int32_t* __restrict__ block_sums, int K, int n
   if (tid == 0) kstart[K] = carry_s;
 }
 
+// out[s][k] = sum_{j<k} ceil((kstart[j+1]-kstart[j]) / tile[s]): the workgroup-tile prefixes the
+// conv kernels search, for up to 4 tile sizes at once (one thread each; K is tiny).
+__global__ void tile_prefix_kernel(const int32_t* __restrict__ kstart, int K, int4 tiles, int n,
+                                   int32_t* __restrict__ out) {
+  const int s = threadIdx.x;
+  if (s >= n) return;
+  const int tile = s == 0 ? tiles.x : s == 1 ? tiles.y : s == 2 ? tiles.z : tiles.w;
+  int acc = 0;
+  int32_t* o = out + (int64_t)s * (K + 1);
+  for (int k = 0; k < K; ++k) {
+    o[k] = acc;
+    acc += (kstart[k + 1] - kstart[k] + tile - 1) / tile;
+  }
+  o[K] = acc;
+}
+
 __global__ void table_compact_kernel(const int32_t* __restrict__ tbl, int64_t n,
                                      const int32_t* __restrict__ n_rows_dev,
                                      const int32_t* __restrict__ block_excl,
@@ -410,6 +426,20 @@ int pv2_table_count(const int32_t* tbl, int K, int64_t n, const int32_t* n_rows_
   hipLaunchKernelGGL(table_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, K, nchunks,
                      kstart);
   return pv2::check_launch("table_count");
+}
+
+int pv2_tile_prefix(const int32_t* kstart, int K, const int32_t* tile_sizes, int n_sizes,
+                    int32_t* out, pv2_stream_t stream) {
+  PV2_REQUIRE(K >= 1 && n_sizes >= 1 && n_sizes <= 4, "pv2_tile_prefix: 1..4 tile sizes");
+  int4 t = make_int4(1, 1, 1, 1);
+  int* tp = &t.x;
+  for (int i = 0; i < n_sizes; ++i) {
+    PV2_REQUIRE(tile_sizes[i] >= 1, "pv2_tile_prefix: tile sizes must be positive");
+    tp[i] = tile_sizes[i];
+  }
+  hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kstart, K, t,
+                     n_sizes, out);
+  return pv2::check_launch("tile_prefix");
 }
 
 int pv2_table_compact(const int32_t* tbl, int K, int64_t n, const int32_t* n_rows_dev,

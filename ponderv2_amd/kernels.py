@@ -92,18 +92,23 @@ class Rulebook:
     def n_pairs(self) -> int:
         return int(self.kstart_host[-1])
 
+    TILE_SIZES = (PAIR_TILE, FWD_LDS_TILE, WGRAD_TILE, 2048)
+
     def tiles(self, tile: int):
-        """(device prefix int32[K+1], total) of ceil(count_k / tile).  The prefix is computed ON
-        THE DEVICE from ``kstart`` (no host->device copy whose source could be freed early); the
-        total comes from the host copy of ``kstart``."""
-        if tile not in self._tiles:
-            counts = self.kstart[1:] - self.kstart[:-1]
-            per_k = torch.div(counts + (tile - 1), tile, rounding_mode="floor")
-            dev = torch.zeros(self.K + 1, dtype=torch.int32, device=self.kstart.device)
-            dev[1:] = torch.cumsum(per_k, 0).to(torch.int32)
-            host = np.zeros(self.K + 1, dtype=np.int64)
-            np.cumsum((np.diff(self.kstart_host) + tile - 1) // tile, out=host[1:])
-            self._tiles[tile] = (dev, int(host[-1]), host)
+        """(device prefix int32[K+1], total, host prefix) of ceil(count_k / tile).  The device
+        prefixes of all four tile sizes the kernels use come from ONE small launch per rulebook
+        (pv2_tile_prefix on the device copy of ``kstart`` - no host->device copy, which would
+        stall the host behind the queue); the totals come from the host copy of ``kstart``."""
+        if not self._tiles:
+            sizes = self.TILE_SIZES
+            dev = torch.empty((len(sizes), self.K + 1), dtype=torch.int32, device=self.kstart.device)
+            arr = (ctypes.c_int32 * len(sizes))(*sizes)
+            _lib.check(_lib.lib().pv2_tile_prefix(_ptr(self.kstart), self.K, arr, len(sizes),
+                                                  _ptr(dev), _stream(self.kstart)), "pv2_tile_prefix")
+            for i, t in enumerate(sizes):
+                host = np.zeros(self.K + 1, dtype=np.int64)
+                np.cumsum((np.diff(self.kstart_host) + t - 1) // t, out=host[1:])
+                self._tiles[t] = (dev[i], int(host[-1]), host)
         return self._tiles[tile]
 
     def transposed(self) -> "Rulebook":
@@ -158,8 +163,9 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if ksize == 1:
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         kh = np.array([0, n], dtype=np.int64)
-        rb = Rulebook(1, n, n, ar, ar, torch.tensor([0, n], dtype=torch.int32, device=dev), kh,
-                      center_k=0)
+        kstart = torch.zeros(2, dtype=torch.int32, device=dev)
+        kstart[1:] = n  # (a fill kernel, not a host->device copy)
+        rb = Rulebook(1, n, n, ar, ar, kstart, kh, center_k=0)
         rb.nbr, rb.nbr_stride = ar, n
         rb._transposed_os = (ar, n, None, 0)
         return rb
@@ -177,7 +183,9 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if n > 0:
         # the neighbour table is its own transpose up to mirroring the offsets (coordinates are
         # unique): grad-input reads the same table with the weight offsets flipped
-        rb.nbr, rb.nbr_stride, rb.perm = nbr, n, _mask_order(nbr, K, n, n)
+        # (the mask sort is only worth its launches when the submanifold convs run output-stationary)
+        rb.nbr, rb.nbr_stride = nbr, n
+        rb.perm = _mask_order(nbr, K, n, n) if USE_OS is True else None
         rb._transposed_os = (nbr, n, rb.perm, 1)
     return rb
 

@@ -98,11 +98,13 @@ def reduce_gemm_tn(a, b):
 
 
 def linear(x, weight, bias=None):
-    """``F.linear`` on the MFMA kernels for large fp32 device batches; anything else (small
-    batches, other dtypes, autocast regions, host tensors under the test doubles) goes to torch."""
+    """``F.linear`` on the MFMA kernels for large device batches (fp32 arithmetic also inside
+    autocast regions: the kernels are launches autocast never touches, reduced-precision inputs are
+    widened on the way in); small batches and host tensors under the test doubles go to torch."""
     rows = x.numel() // max(x.shape[-1], 1)
-    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32
-            or rows < MIN_ROWS or torch.is_autocast_enabled()):
+    if (not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16, torch.float16)
+            or weight.dtype != torch.float32 or rows < MIN_ROWS):
         return F.linear(x, weight, bias)
+    x = x.float()
     y = tall_gemm_nt(x.reshape(rows, x.shape[-1]), weight, bias)
     return y.reshape(*x.shape[:-1], weight.shape[0])

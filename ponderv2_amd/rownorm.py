@@ -3,8 +3,8 @@ a column-sum, on the gfx950 kernels of csrc/rownorm.hip.
 
 ``fused_bn(bn_module, x, residual=None, relu=False)`` uses the parameters and running buffers of a
 stock ``nn.BatchNorm1d`` (so state_dicts stay reference-compatible) and computes
-``[relu](bn(x) [+ residual])`` in two short launches, and two for the backward (the statistics
-kernel's last block finalises them and clears the shared workspace, csrc/rownorm.hip).  Anything the kernels
+``[relu](bn(x) [+ residual])`` in two short launches, and two for the backward (per-block partial
+statistics, then an apply kernel that adds them in a fixed order: no atomics, csrc/rownorm.hip).  Anything the kernels
 do not cover (eval mode, other dtypes, host tensors under the test doubles) takes the module path.
 """
 import torch
@@ -17,16 +17,32 @@ from .kernels import _ptr, _require_device, _stream
 _WORKSPACES = {}
 
 
-def _zeroed_workspace(device, channels):
-    """The statistics kernels' scratch: 2C doubles + a ticket word, all zero between launches (the
-    kernels clean up after themselves, csrc/rownorm.hip), so ONE buffer per stream - cleared when
-    it is allocated - serves every layer.  Grown (re-allocated, re-zeroed) on demand."""
+def _workspace(device, channels):
+    """The statistics kernels' scratch (per-block partial sums, csrc/rownorm.hip): launches on one
+    stream are ordered, so ONE buffer per stream serves every layer.  Grown on demand."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    need = int(_lib.lib().pv2_bn_workspace_floats(channels))
     ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() < 2 * channels + 1:
-        ws = torch.zeros(max(2 * channels + 1, 1025), dtype=torch.float64, device=device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 64 * 2 * 256), dtype=torch.float32, device=device)
         _WORKSPACES[key] = ws
     return ws
+
+
+def _bump_batches_tracked(bn):
+    """``num_batches_tracked += 1`` without a kernel launch per layer per step: counted on the host
+    and written back whenever the module's state is read (state_dict) - the value only matters for
+    checkpoints here (momentum is not None)."""
+    if not hasattr(bn, "_pv2_pending_batches"):
+        bn._pv2_pending_batches = 0
+
+        def flush(module, *args):
+            if module._pv2_pending_batches and module.num_batches_tracked is not None:
+                module.num_batches_tracked.add_(module._pv2_pending_batches)
+            module._pv2_pending_batches = 0
+
+        bn.register_state_dict_pre_hook(flush)
+    bn._pv2_pending_batches += 1
 
 
 class _FusedBNFunction(torch.autograd.Function):
@@ -38,7 +54,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         y = torch.empty_like(x)
-        sums = _zeroed_workspace(x.device, c)
+        sums = _workspace(x.device, c)
         mean_invstd = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().pv2_bn_forward(
             _ptr(x), n, c, _ptr(weight), _ptr(bias), _ptr(residual), int(relu), float(eps),
@@ -59,7 +75,7 @@ class _FusedBNFunction(torch.autograd.Function):
         gsum = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().pv2_bn_backward(
             _ptr(dy), _ptr(x), _ptr(y), _ptr(mean_invstd), _ptr(weight), n, c,
-            _ptr(_zeroed_workspace(x.device, c)), _ptr(gsum), _ptr(dx), _ptr(dres), _stream(x)),
+            _ptr(_workspace(x.device, c)), _ptr(gsum), _ptr(dx), _ptr(dres), _stream(x)),
             "pv2_bn_backward")
         dweight = gsum[c:] if weight is not None else None
         dbias = gsum[:c] if ctx.has_bias else None
@@ -67,9 +83,12 @@ class _FusedBNFunction(torch.autograd.Function):
 
 
 def can_fuse(bn, x):
-    """True when the rownorm.hip kernels cover this call (training-mode fp32 device matrix)."""
-    return (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() == 2
-            and x.shape[0] > 1 and bn.momentum is not None and not torch.is_autocast_enabled()
+    """True when the rownorm.hip kernels cover this call: a training-mode device matrix.  Autocast
+    does not change the answer - the kernels are fp32 launches it never touches; reduced-precision
+    inputs are widened on the way in and the result is fp32."""
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and bn.training
+            and x.dim() == 2 and x.shape[0] > 1 and bn.momentum is not None
+            and bn.weight.dtype == torch.float32
             and not isinstance(bn, torch.nn.SyncBatchNorm))  # SyncBN reduces across ranks itself
 
 
@@ -87,12 +106,13 @@ def fused_bn(bn, x, residual=None, relu=False, weight=None, bias=None):
             y = y + residual
         return F.relu(y) if relu else y
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        _bump_batches_tracked(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    w = bn.weight if weight is None else weight.contiguous()
-    b = bn.bias if bias is None else bias.contiguous()
-    return _FusedBNFunction.apply(x, w, b, residual, rm, rv, relu, bn.eps, bn.momentum)
+    w = bn.weight if weight is None else weight.float().contiguous()
+    b = bn.bias if bias is None else bias.float().contiguous()
+    residual = None if residual is None else residual.float()
+    return _FusedBNFunction.apply(x.float(), w, b, residual, rm, rv, relu, bn.eps, bn.momentum)
 
 
 class _ColSum(torch.autograd.Function):

@@ -85,6 +85,9 @@ class _SparseConvBase(SparseModule):
 
     def _apply_conv(self, features, rb):
         w = self.weight.reshape(self.out_channels, -1, self.in_channels)
+        # fp32 kernels also inside autocast regions (widen whatever the region produced)
+        if features.dtype in (torch.bfloat16, torch.float16):
+            features = features.float()
         out = K.SparseConvFunction.apply(features, w, rb)
         if self.bias is not None:
             out = out + self.bias

@@ -233,7 +233,8 @@ def test_fused_bn_matches_torch(device, n, c, relu, with_res):
         outs = [y.detach(), xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var]
         if with_res:
             outs.append(ri.grad)
-        return [o.double().cpu() for o in outs], int(bn.num_batches_tracked)
+        # (the fused path counts batches on the host and writes them back when the state is read)
+        return [o.double().cpu() for o in outs], int(bn.state_dict()["num_batches_tracked"])
 
     ref, _ = run(torch.device("cpu"), torch.float64)
     got, nbt = run(device, torch.float32)
@@ -245,6 +246,27 @@ def test_fused_bn_matches_torch(device, n, c, relu, with_res):
         floor = float(gout.abs().max()) * 1.5 / (float(x.std()) * 0.2 + 1e-3) if name == "dx" else 0.05
         err = (a - b).abs().max().item() / max(b.abs().max().item(), floor)
         assert err < 2e-5, (name, err)
+
+
+def test_fused_bn_large_mean_to_std_ratio(device):
+    """Columns whose mean is 1e3..1e4 times their spread: the shifted accumulation keeps the batch
+    variance (E[(x-s)^2] - (E[x-s])^2 with s = the first row) accurate where E[x^2] - mean^2 in fp32
+    would lose every digit."""
+    import torch.nn as nn
+    from ponderv2_amd.rownorm import fused_bn
+
+    torch.manual_seed(3)
+    n, c = 5000, 48
+    base = torch.linspace(50.0, 4000.0, c)
+    x = base + 0.3 * torch.randn(n, c)
+    bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(device).train()
+    y = fused_bn(bn, x.to(device))
+    xd = x.double()
+    ref = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-3)
+    # fp32 inputs at |x| ~ 4000 carry ~2.4e-4 absolute noise, i.e. ~1e-3 of the 0.3 spread
+    assert (y.double().cpu() - ref).abs().max() < 5e-3
+    sd = bn.state_dict()
+    assert (sd["running_var"].double().cpu() - (0.99 + 0.01 * xd.var(0))).abs().max() < 1e-4
 
 
 def test_col_sum(device):
