@@ -37,18 +37,25 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def pmc_traffic_bytes(kernel_key="spconv_fwd_lds_kernel<4>"):
-    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes of THIS command
-    (profiles/r01_pmc_fetch_write_per_kernel.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB
-    per launch).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane
-    streaming reads.  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+PMC_FILE = "profiles/r02_pmc_fetch_write_per_kernel.json"
+
+
+def pmc_traffic(kernel_key):
+    """(HBM-side bytes per launch, source) of a kernel from the rocprofv3 PMC passes committed with
+    this round (tools/gpu_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench command;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streaming reads).
+    A STATIC read of that file - the counters cannot be collected inside a timed run - so the
+    commit it was measured at travels with it.  (None, reason) when absent."""
+    path = os.path.join(ROOT, PMC_FILE)
     try:
         with open(path) as f:
-            rec = json.load(f)[kernel_key]
-        return 1024.0 * (2.0 * rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"])
-    except Exception:
-        return None
+            doc = json.load(f)
+        rec = doc["kernels"][kernel_key]
+        return (1024.0 * (2.0 * rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]),
+                f"{PMC_FILE} (static; measured at commit {doc.get('commit', '?')}, "
+                f"{rec.get('launches', '?')} launches)")
+    except Exception as e:  # noqa: BLE001
+        return None, f"{PMC_FILE} unavailable ({type(e).__name__})"
 
 
 def parse():
@@ -73,6 +80,10 @@ def parse():
                          "parity configuration, everything on the path in fp32; bfloat16 runs only "
                          "those dense convs under autocast (the reference config trains with "
                          "enable_amp=True)")
+    ap.add_argument("--config", default=None,
+                    help="config file to take the model / optimizer / scheduler sections from "
+                         "(default: the repository's synthetic-data config of the workload; the "
+                         "reference's own config file works unchanged)")
     ap.add_argument("--print-losses", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     args = ap.parse_args()
@@ -81,54 +92,52 @@ def parse():
     return args
 
 
-def model_cfg(rays_per_view, dense_dtype="float32"):
-    import golden_cases as gc  # the ScanNet model section, restated (reference tree absent here)
-
-    backbone = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0,
-                    channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
-    cfg = gc.indoor_model_cfg(backbone, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
-    cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
-    return cfg
-
-
-PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
-PPT_VALID = (tuple(range(25)), tuple(range(20)), tuple(range(13)))  # class counts of the reference
+CONFIGS = {  # the configs/ files whose model / optimizer / scheduler sections the bench builds from
+    "indoor": "configs/scannet/pretrain-ponder-spunet-v1m1-synthetic.py",
+    "ppt": "configs/scannet/pretrain-ponder-ppt-v1m1-synthetic.py",
+    "outdoor": "configs/nuscenes/pretrain-ponder-spunet-v1m1-synthetic.py",
+}
 PPT_SCHEDULE = (0, 0, 0, 0, 1, 1, 2)                                 # sampling ratio 4:2:1
 
 
-def ppt_model_cfg(rays_per_view, dense_dtype="float32"):
-    """configs/scannet/pretrain-ponder-ppt-v1m1-0-sc-s3-st-spunet.py:22-228, restated."""
-    cfg = model_cfg(rays_per_view, dense_dtype)
-    cfg["backbone"] = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_channels=32,
-                           context_channels=256, channels=(32, 64, 128, 256, 256, 128, 96, 96),
-                           layers=(2, 3, 4, 6, 2, 2, 2, 2), cls_mode=False,
-                           conditions=("ScanNet", "S3DIS", "Structured3D"), zero_init=False,
-                           norm_decouple=True, norm_adaptive=True, norm_affine=True)
-    names = tuple(f"class {i}" for i in range(36))
-    cfg.update(conditions=PPT_CONDITIONS, class_name=names, valid_index=PPT_VALID)
+def load_config(workload, path=None):
+    """Config.fromfile on the repository's config for the workload (model / optimizer / scheduler
+    sections identical to the reference's; only the data section is synthetic) or on ``path`` -
+    e.g. the reference's own configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py, which loads
+    unchanged."""
+    from ponderv2_amd.ponder.utils.config import Config
+
+    return Config.fromfile(path or os.path.join(ROOT, CONFIGS[workload]))
+
+
+def model_cfg(rays_per_view, dense_dtype="float32", workload="indoor", path=None):
+    cfg = load_config(workload, path).model.to_dict()
+    if workload != "outdoor":
+        cfg["ray_nsample"] = rays_per_view
+    if isinstance(cfg.get("template"), (list, tuple)):
+        cfg["template"] = cfg["template"][0]   # the stub text encoder ignores the template
+    cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
     return cfg
 
 
-def make_ppt_batches(rank, scenes, views, device):
-    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
-
-    out = []
-    for k, cond in enumerate(PPT_CONDITIONS):
-        samples = [make_scene(1000 * rank + 100 * k + i, num_views=views, image_hw=(480, 640),
-                              condition=cond, num_classes=len(PPT_VALID[k])) for i in range(scenes)]
-        batch = collate_fn(samples)
-        out.append({k2: (v.to(device) if torch.is_tensor(v) else v) for k2, v in batch.items()})
-    return out
+def ppt_model_cfg(rays_per_view, dense_dtype="float32"):
+    return model_cfg(rays_per_view, dense_dtype, "ppt")
 
 
 def outdoor_model_cfg(dense_dtype="float32"):
-    import golden_cases as gc  # the nuScenes model section, restated
+    return model_cfg(None, dense_dtype, "outdoor")
 
-    backbone = dict(type="SpUNet-v1m1", in_channels=4, num_classes=0,
-                    channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
-    cfg = gc.outdoor_model_cfg(backbone)
-    cfg["proj_autocast"] = None if dense_dtype == "float32" else dense_dtype
-    return cfg
+
+def make_ppt_batches(rank, scenes, views, device, conditions, valid_index):
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    out = []
+    for k, cond in enumerate(conditions):
+        samples = [make_scene(1000 * rank + 100 * k + i, num_views=views, image_hw=(480, 640),
+                              condition=cond, num_classes=len(valid_index[k])) for i in range(scenes)]
+        batch = collate_fn(samples)
+        out.append({k2: (v.to(device) if torch.is_tensor(v) else v) for k2, v in batch.items()})
+    return out
 
 
 def make_outdoor_batch(rank, scenes, rays_per_camera, device):
@@ -145,7 +154,8 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}   # family -> list of (start, end, flops, bytes)
-        self._orig = {}
+        self._orig, self._orig_c, self._handle = {}, {}, None
+        self.l2_bytes = {}
 
     def _add(self, fam, s, e, flops, nbytes, shape=None):
         self.records.setdefault(fam, []).append((s, e, flops, nbytes, shape))
@@ -171,7 +181,7 @@ class KernelTimer:
 
             setattr(K, name, fn)
 
-        def conv_cost(feats, w, rb, out=None):
+        def conv_cost(feats, w, rb, out=None, bias=None):
             c_out, kk, c_in = w.shape
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
@@ -194,6 +204,60 @@ class KernelTimer:
                 return (0.0, pts * 8.0 * c * inp.element_size() * mult)
             return cost
 
+        # fused ray-march entry points (csrc/raymarch_fused.hip): events around the C-ABI calls.
+        # flops: the MLP GEMMs (2H*F + G*H + F*H MACs per sample forward, as many again backward,
+        # weight gradients run in pv2_gemm_tn and are not counted here); bytes: everything the
+        # launch writes plus the volume rows it gathers, each counted once (compulsory - the 8x
+        # corner re-reads are served by L2/MALL and reported separately as l2_gather_gbs)
+        import ponderv2_amd._lib as LIB
+
+        handle = LIB.lib()
+        self._handle = handle
+        H_, F_, G_, C_, NV_ = 128, 64, 64, 128, 140
+
+        def wrap_c(name, fam, cost):
+            orig = getattr(handle, name)
+            self._orig_c[name] = orig
+
+            def fn(*a):
+                s_ = torch.cuda.Event(enable_timing=True)
+                e_ = torch.cuda.Event(enable_timing=True)
+                s_.record()
+                rc = orig(*a)
+                e_.record()
+                c = cost(*a)
+                timer._add(fam, s_, e_, c[0], c[1], None)
+                timer.l2_bytes[fam] = timer.l2_bytes.get(fam, 0.0) + c[2]
+                return rc
+
+            setattr(handle, name, fn)
+
+        def vol_bytes(a):
+            return 4.0 * a[1] * a[2] * a[3] * a[4] * a[5]
+
+        def field_fwd_cost(*a):
+            n = a[10] * a[11]
+            gather = n * 8.0 * (C_ + F_) * 4
+            return (n * 2.0 * (2 * H_ * F_ + G_ * H_ + F_ * H_),
+                    n * 4.0 * (NV_ + F_ + 2 * H_ + F_ + 2) + min(vol_bytes(a), n * 8.0 * C_ * 4),
+                    gather)
+
+        def field_bwd_cost(*a):
+            n = a[10] * a[11]
+            wrote = n * 4.0 * (C_ + 4 + 2 * H_ + H_ + F_ + 68 + 4)
+            read = n * 4.0 * (NV_ + H_ + F_ + C_ + 8)
+            scatter = n * 8.0 * C_ * 4          # read-modify-write of the volume gradient
+            return (n * 2.0 * (F_ * H_ + G_ * H_ + 2 * H_ * F_), wrote + read
+                    + min(2 * vol_bytes(a), 2 * scatter), n * 8.0 * F_ * 4 + 2 * scatter)
+
+        def coarse_cost(*a):
+            n = a[10] * a[11]
+            return (n * 2.0 * (2 * H_ * F_), min(vol_bytes(a) / 2, n * 8.0 * F_ * 4)
+                    + a[10] * 4.0 * 3 * (a[11] + a[12] + 1), n * 8.0 * F_ * 4)
+
+        wrap_c("pv2_neus_field_forward", "field_fwd_kernel", field_fwd_cost)
+        wrap_c("pv2_neus_field_backward", "field_bwd_kernel + volume_scatter_kernel", field_bwd_cost)
+        wrap_c("pv2_neus_coarse_sample", "coarse_sample_kernel", coarse_cost)
         wrap("spconv_forward", "spconv_fwd_kernel (fwd+dgrad)", conv_cost)
         wrap("spconv_backward_weight", "spconv_wgrad_kernel", wgrad_cost)
         wrap("trilinear_forward", "tri_fwd_kernel", tri_cost_factory(1))
@@ -205,9 +269,12 @@ class KernelTimer:
 
         for name, orig in self._orig.items():
             setattr(K, name, orig)
+        for name, orig in self._orig_c.items():
+            setattr(self._handle, name, orig)
 
     def reset(self):
         self.records = {}
+        self.l2_bytes = {}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -222,6 +289,10 @@ class KernelTimer:
                             alg_gbs=nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                             alg_flops_per_launch=flops / max(len(recs), 1),
                             alg_bytes_per_launch=nbytes / max(len(recs), 1)))
+            if fam in self.l2_bytes:
+                out[-1]["l2_gather_gbs"] = self.l2_bytes[fam] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                out[-1]["frac_of_f32_mfma_peak"] = out[-1]["tflops"] / F32_MFMA_PEAK_TFLOPS
+                out[-1]["frac_of_hbm_peak"] = out[-1]["alg_gbs"] / HBM_PEAK_GBS
         return sorted(out, key=lambda r: -r["total_ms"])
 
     def shape_table(self, steps):
@@ -260,9 +331,15 @@ def clone_batch(batch):
 
 
 def cpu_baseline(args):
-    """Same model code, oracle CPU kernels, host cores: one scene (20 000 voxels, 128 rays),
-    one full training step (forward + backward + SGD), fp32."""
-    from oracle import cpu_backend
+    """the same model code on the host cores through the oracle's CPU kernels
+    (kind "port"; spconv itself is absent, so there is no runnable reference CPU backbone),
+    BASELINE configs[0]: one scene of 20 000 voxels, 2 views x 64 = 128 rays, fp32.  One warm-up
+    step, then the MEDIAN of three timed training steps (forward + backward + SGD); the SparseUNet
+    forward alone (the north star's CPU baseline item) and the rulebook build are timed separately,
+    median of three each.  ~30 s of host work on the GPU box's 128 cores."""
+    import statistics
+
+    from oracle import cpu_backend, rulebook as orb
     from ponderv2_amd.ponder.datasets import collate_fn, make_scene
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
@@ -273,23 +350,42 @@ def cpu_baseline(args):
         opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True,
                               weight_decay=1e-4)
         batch = collate_fn([make_scene(0, num_views=2, image_hw=(480, 640), n_voxels=20000)])
-        tb = time.perf_counter()   # the SparseUNet forward on its own (north_star's CPU baseline item)
+
+        def step():
+            t0 = time.perf_counter()
+            out = model(clone_batch(batch))
+            t1 = time.perf_counter()
+            opt.zero_grad()
+            out["loss"].backward()
+            opt.step()
+            return t1 - t0, time.perf_counter() - t0
+
+        step()  # warm-up (allocator, thread pools, oneDNN primitive caches)
+        timed = [step() for _ in range(3)]
+        t_fwd = statistics.median(t[0] for t in timed)
+        t_step = statistics.median(t[1] for t in timed)
+        backbone = []
         with torch.no_grad():
-            model.backbone(clone_batch(batch))
-        t_backbone = time.perf_counter() - tb
-        t0 = time.perf_counter()
-        out = model(clone_batch(batch))
-        t_fwd = time.perf_counter() - t0
-        opt.zero_grad()
-        out["loss"].backward()
-        opt.step()
-        t = time.perf_counter() - t0
-    return dict(value=1.0 / t, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 scene (20000 voxels, 2 views x 64 = 128 rays), ONE train step "
-                       "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels "
-                       f"(SparseUNet forward alone {t_backbone:.2f} s, model forward {t_fwd:.2f} s, "
-                       f"step {t:.2f} s), no warm-up",
-                rays_per_s=128.0 / t, sparse_unet_forward_s=t_backbone, forward_s=t_fwd, step_s=t)
+            for _ in range(3):
+                tb = time.perf_counter()
+                model.backbone(clone_batch(batch))
+                backbone.append(time.perf_counter() - tb)
+        t_backbone = statistics.median(backbone)
+    coords = torch.cat([torch.zeros(len(batch["grid_coord"]), 1, dtype=torch.long),
+                        batch["grid_coord"]], 1).int().numpy()
+    rb = []
+    for _ in range(3):
+        tr = time.perf_counter()
+        orb.subm_rulebook(coords, 3)
+        rb.append(time.perf_counter() - tr)
+    return dict(value=1.0 / t_step, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
+                sample="configs[0]: 1 scene (20000 voxels, 2 views x 64 = 128 rays), train step "
+                       "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels; 1 warm-up + "
+                       f"median of 3 (SparseUNet forward alone {t_backbone:.2f} s, model forward "
+                       f"{t_fwd:.2f} s, step {t_step:.2f} s, level-0 k3 rulebook build "
+                       f"{statistics.median(rb):.2f} s)",
+                rays_per_s=128.0 / t_step, sparse_unet_forward_s=t_backbone, forward_s=t_fwd,
+                step_s=t_step, rulebook_build_s=statistics.median(rb))
 
 
 def main():
@@ -316,37 +412,35 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
     outdoor = args.workload == "outdoor"
     ppt = args.workload == "ppt"
-    if outdoor:
-        cfg = outdoor_model_cfg(args.dense_dtype)
-    elif ppt:
-        cfg = ppt_model_cfg(args.rays_per_view, args.dense_dtype)
-    else:
-        cfg = model_cfg(args.rays_per_view, args.dense_dtype)
+    cfg = model_cfg(args.rays_per_view, args.dense_dtype, args.workload, args.config)
+    full = load_config(args.workload, args.config)
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)
-    # optimiser + OneCycleLR exactly as the reference's run_step drives them every iteration
-    # (engines/train.py:185-203): the schedule starts at max_lr / div_factor
-    if outdoor:  # configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py:95-104
-        opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01)
-        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, total_steps=100000,
-                                                    pct_start=0.4, anneal_strategy="cos",
-                                                    div_factor=10.0, final_div_factor=100.0)
+    # optimiser + scheduler from the config's own sections, stepped every iteration as the
+    # reference's run_step does (engines/train.py:185-203); the lr follows the config's rule
+    # lr = base * total_batch / config_batch
+    from ponderv2_amd.ponder.utils.optimizer import build_optimizer, build_scheduler
+
+    ocfg = full.optimizer.to_dict()
+    ocfg["lr"] = ocfg["lr"] * (args.scenes_per_gpu * world) / float(full.batch_size)
+    opt = build_optimizer(ocfg, model, full.get("param_dicts"))
+    scfg = full.scheduler.to_dict()
+    scfg.update(total_steps=100000)
+    if "max_lr" in scfg:
+        scfg["max_lr"] = ocfg["lr"]
+    sched = build_scheduler(scfg, opt)
+    if outdoor:
         batch = make_outdoor_batch(rank, args.scenes_per_gpu, args.rays_per_camera, device)
-    else:       # configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:156-170 (ppt: lr 1e-4 * bs / 8)
-        lr = (0.0001 if ppt else 0.0005) * (args.scenes_per_gpu * world) / 8
-        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4,
-                              nesterov=True)
-        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=100000,
-                                                    pct_start=0.05, anneal_strategy="cos",
-                                                    div_factor=10.0, final_div_factor=10000.0)
+    else:
         batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
     n_vox = int(batch["offset"][-1])
     batches, counter = [batch], [0]
     if ppt:  # one resident batch per condition, visited in the loader's 4:2:1 order
-        per_cond = make_ppt_batches(rank, args.scenes_per_gpu, args.views, device)
+        per_cond = make_ppt_batches(rank, args.scenes_per_gpu, args.views, device, cfg["conditions"],
+                                    cfg["valid_index"])
         batches = [per_cond[k] for k in PPT_SCHEDULE]
 
     def step():
@@ -451,11 +545,11 @@ def main():
                 result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma",
                                       "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
                                       "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
-                                      "traffic": pmc_traffic_bytes(),
-                                      "traffic_note": "bytes/launch of spconv_fwd_lds_kernel<4> "
-                                                      "(72 of the family's 117 launches/step) from "
-                                                      "separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
-                                                      "passes (profiles/); algorithmic bytes/launch = "
+                                      "traffic": pmc_traffic("spconv_fwd_lds_kernel<4>")[0],
+                                      "traffic_source": pmc_traffic("spconv_fwd_lds_kernel<4>")[1],
+                                      "traffic_note": "HBM-side bytes/launch of "
+                                                      "spconv_fwd_lds_kernel<4> (the family's main "
+                                                      "instantiation); algorithmic bytes/launch = "
                                                       "alg_bytes_per_launch",
                                       "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
                                       "alg_flops_per_launch": dom["alg_flops_per_launch"],

@@ -47,11 +47,18 @@ class Recorder:
             self.perm.append(t.detach().cpu().clone())
             return t
 
-        torch.rand, torch.randperm = rand, randperm
+        self.search, self._search = [], torch.searchsorted
+
+        def searchsorted(*a, **k):
+            t = self._search(*a, **k)
+            self.search.append(t.detach().cpu().clone())
+            return t
+
+        torch.rand, torch.randperm, torch.searchsorted = rand, randperm, searchsorted
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.randperm = self._rand, self._perm
+        torch.rand, torch.randperm, torch.searchsorted = self._rand, self._perm, self._search
 
 
 def spunet_case():
@@ -178,6 +185,82 @@ def ponder_indoor_case(ConfigDict):
         grad_names=np.array(gnames),
         **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
     print("ponder_indoor_small:", {k: round(float(v), 6) for k, v in out.items()},
+          "rand draws", [tuple(r.shape) for r in rec.rand])
+
+
+def ponder_indoor_cfg1_case(ConfigDict):
+    """BASELINE.json configs[1] at FULL size (the bench workload: 2 scenes, 2 views x 256 = 512 rays
+    per scene) - same recipe and fixture layout as configs[0] below."""
+    ponder_indoor_cfg0_case(ConfigDict, scenes=2, rays_per_view=256, n_voxels=None,
+                            name="ponder_indoor_cfg1")
+
+
+def ponder_indoor_cfg0_case(ConfigDict, scenes=1, rays_per_view=64, n_voxels=20000,
+                            name="ponder_indoor_cfg0"):
+    """BASELINE.json configs[0] at FULL size: the reference's PonderIndoor.forward with the shipped
+    model section (SpUNet-v1m1 32..256 channels, (2,3,4,6,2,2,2,2) blocks, 128x128x32 grid,
+    UNet3D-v1m2, NeuS head 96+36 samples) on one synthetic ScanNet-shaped scene of 20 000 voxels and
+    2 views x 64 = 128 rays, fp32, training mode.  Besides the losses and gradient probes the
+    fixture holds what the renderer returned per ray (RGB, depth) and the importance sampler's
+    searchsorted bin indices (integer work: asserted bit-exact by the tests)."""
+    import time
+
+    from ponder.models.builder import MODELS
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    cfg = _render_cfg()
+    mcfg = cfg.model.to_dict()
+    mcfg.update(ray_nsample=rays_per_view, template="a photo of a [x]")
+    torch.manual_seed(0)
+    model = MODELS.build(ConfigDict(mcfg))
+    fill_deterministic(model)
+    model.train()
+    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
+                        for i in range(scenes)])
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    captured = {"rgb": [], "depth": [], "normal": []}
+    orig_render = model.renderer.forward
+
+    def render(*a, **k):
+        out = orig_render(*a, **k)
+        for key in captured:   # the reference renders scene by scene
+            captured[key].append(out[key].detach().clone())
+        return out
+
+    model.renderer.forward = render
+    torch.manual_seed(321)
+    t0 = time.perf_counter()
+    with Recorder() as rec:
+        out = model(inp)
+    out["loss"].backward()
+    print("%s reference step on %d host threads: %.1f s" % (name, torch.get_num_threads(),
+                                                           time.perf_counter() - t0))
+    B, V, H, W = batch["depth"].shape
+    pix = np.zeros((B, V, rays_per_view, 2), dtype=np.int64)
+    it = iter(rec.perm)
+    for b in range(B):
+        for v in range(V):
+            ys, xs = torch.where(batch["depth"][b, v] > 0)
+            sel = next(it)[:rays_per_view]
+            pix[b, v, :, 0], pix[b, v, :, 1] = ys[sel].numpy(), xs[sel].numpy()
+    params = dict(model.named_parameters())
+    gnames = ["backbone.conv_input.1.bias", "backbone.enc.3.block5.bn2.weight",
+              "backbone.dec.0.block1.bn2.bias", "proj_net.final_conv.bias",
+              "renderer.field.sdf_decoder.lin1.bias", "renderer.field.rgb_decoder.lin0.weight",
+              "renderer.field.semantic_decoder.lin0.bias", "renderer.field.deviation_network.variance"]
+    assert len(rec.search) == scenes
+    np.savez_compressed(
+        os.path.join(GOLDEN, name + ".npz"), ray_pixels=pix,
+        rands=np.array(len(rec.rand)),
+        **{f"rand_{i}": r.numpy() for i, r in enumerate(rec.rand)},
+        pdf_bins=torch.cat(rec.search).numpy().astype(np.int32),
+        render_rgb=torch.cat(captured["rgb"]).numpy(), render_depth=torch.cat(captured["depth"]).numpy(),
+        render_normal=torch.cat(captured["normal"]).numpy(),
+        n_voxels=np.array(int(batch["offset"][-1])),
+        out_names=np.array(list(out.keys())), out_values=np.array([float(v) for v in out.values()]),
+        grad_names=np.array(gnames),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    print(name + ":", {k: round(float(v), 6) for k, v in out.items()},
           "rand draws", [tuple(r.shape) for r in rec.rand])
 
 
@@ -367,7 +450,9 @@ def main():
     only = sys.argv[1:]
     cases = dict(spunet=spunet_case, neus=lambda: neus_case_impl(ConfigDict),
                  indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case, transforms=transform_chain_case, ppt=lambda: ponder_ppt_case(ConfigDict),
-                 outdoor=lambda: ponder_outdoor_case(ConfigDict))
+                 outdoor=lambda: ponder_outdoor_case(ConfigDict),
+                 cfg0=lambda: ponder_indoor_cfg0_case(ConfigDict),
+                 cfg1=lambda: ponder_indoor_cfg1_case(ConfigDict))
     for name, fn in cases.items():
         if not only or name in only:
             fn()

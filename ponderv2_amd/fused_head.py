@@ -26,6 +26,9 @@ from . import _lib
 from .kernels import _ptr, _require_device, _stream, zeros_by_kernel
 
 ENABLED = os.environ.get("PV2_FUSED_HEAD", "1") != "0"
+# tests set this to a dict to receive the coarse pass's diagnostics (importance-sampling bin
+# indices, coarse SDF and weights) of the next render
+CAPTURE = None
 
 _DIMS = None
 
@@ -306,9 +309,13 @@ def _render_outputs(model, ray_bundle, volume_feature):
     nb = n_imp + 1
     lin_bins = device_linspace(0.0, 1.0, S0 + 1, dev)
     lin_u = device_linspace(0.0, 1.0 - 1.0 / nb, nb, dev)
-    bins, starts, deltas = coarse_sample(
+    res = coarse_sample(
         vol5, o, d, ray_bundle.nears.reshape(-1), ray_bundle.fars.reshape(-1), lin_bins, t_rand,
-        lin_u, u_rand, n_imp, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], smp.base_variance)
+        lin_u, u_rand, n_imp, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], smp.base_variance,
+        debug=CAPTURE is not None)
+    bins, starts, deltas = res[:3]
+    if CAPTURE is not None:
+        CAPTURE.update(res[3], bins=bins)
     inv_s = field.deviation_network.get_variance()
     sdf, grad, weights, comp = field_render(
         vol5, o, d, starts, deltas, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], cp["A"],

@@ -196,6 +196,71 @@ def run_ponder_indoor(device):
     return errs
 
 
+FULL_BACKBONE = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0,
+                     channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
+
+
+def run_ponder_indoor_cfg1(device):
+    """BASELINE.json configs[1] (the bench workload) at full size: 2 scenes, 512 rays each."""
+    return run_ponder_indoor_cfg0(device, scenes=2, rays_per_view=256, n_voxels=None,
+                                  name="ponder_indoor_cfg1")
+
+
+def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
+                           name="ponder_indoor_cfg0"):
+    """BASELINE.json configs[0] at full size against the reference's own run of it
+    (oracle/make_golden.py::ponder_indoor_cfg0_case): one scene, 20 000 voxels, 128 rays, the
+    shipped backbone / grid / head.  Returns relative errors of every loss term, of the rendered
+    RGB / depth / normal per ray, of the gradient probes, and the number of importance-sampling bin
+    indices that differ from the reference's ``searchsorted`` result."""
+    from ponderv2_amd import fused_head as fhd
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = indoor_model_cfg(FULL_BACKBONE, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
+    model = build_model(ConfigDict(cfg))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
+    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
+                        for i in range(scenes)])
+    assert int(batch["offset"][-1]) == int(g["n_voxels"])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch["ray_pixels"] = torch.from_numpy(g["ray_pixels"])
+    rendered, capture = {"rgb": [], "depth": [], "normal": []}, {}
+    orig = model.renderer.forward
+
+    def render(*a, **k):
+        out = orig(*a, **k)
+        for key in rendered:   # one call for the batched render, one per scene otherwise
+            rendered[key].append(out[key].detach())
+        return out
+
+    model.renderer.forward = render
+    fhd.CAPTURE = capture
+    try:
+        out = model(batch)
+    finally:
+        fhd.CAPTURE = None
+    out["loss"].backward()
+    errs = {}
+    for name, val in zip(g["out_names"], g["out_values"]):
+        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+    for key in ("rgb", "depth", "normal"):
+        errs["render_" + key] = rel_err(torch.cat(rendered[key]), g["render_" + key])
+    params = dict(model.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    flips = -1
+    if "idx" in capture:
+        flips = int((capture["idx"].cpu().numpy() != g["pdf_bins"]).sum())
+    return errs, flips
+
+
 # model section of configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py (reference :20-92)
 OUTDOOR_RENDERER = dict(
     type="NeuSModel",
