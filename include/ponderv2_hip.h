@@ -155,6 +155,24 @@ int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const fl
                           int kflip, const float* bias, float* out_feat, int64_t n_out,
                           pv2_stream_t stream);
 
+/* Output-stationary conv with an LDS accumulator tile, for rulebooks in canonical (k, output row)
+ * order whose output rows are the natural row range (submanifold convs): a workgroup owns 64 or 128
+ * consecutive output rows, walks the K offsets, processes its pairs of each offset COMPACTED (32
+ * per MFMA row block), adds the result blocks into the LDS tile and writes every output element
+ * once.  No atomics to memory, no zero-fill, bitwise reproducible.
+ *   segments: seg[k*(T+1) + t] = first pair of offset k with pair_out >= 64*t, T = ceil(n_out/64);
+ *             seg has K*(T+1) int32 entries.  Build once per rulebook.
+ *   forward : out[o, n] = bias[n] + sum over pairs (i -> o, k) of in[i, :] . weight[n, kw(k), :],
+ *             kw(k) = kflip ? K-1-k : k;  c_in % 32 == 0, c_out % 4 == 0.
+ * Grad-input of a submanifold conv = forward on grad_out with the transposed weights
+ * [c_in, K, c_out] and kflip = 1 on the SAME pair lists. */
+int pv2_spconv_osl_segments(const int32_t* pair_out, const int32_t* kstart, int K, int64_t n_out,
+                            int32_t* seg, pv2_stream_t stream);
+int pv2_spconv_osl_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                           int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                           const int32_t* seg, int kflip, const float* bias, float* out_feat,
+                           int64_t n_out, pv2_stream_t stream);
+
 /* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
  * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count chunks of
  * tile_pairs = pv2_spconv_wgrad_tile(c_in, c_out, n_pairs, K) pairs (PV2_WGRAD_TILE or 2048). */

@@ -52,6 +52,9 @@ SIGNATURES = {
     "pv2_table_masks": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "pv2_spconv_os_forward": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, c_int64, _P, c_int, _P, _P, c_int64, _P]),
+    "pv2_spconv_osl_segments": (c_int, [_P, _P, c_int, c_int64, _P, _P]),
+    "pv2_spconv_osl_forward": (
+        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P]),
     "pv2_spconv_wgrad_tile": (c_int, [c_int, c_int, c_int64, c_int]),
     "pv2_spconv_backward_weight": (
         c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,

@@ -661,6 +661,134 @@ __global__ __launch_bounds__(256) void spconv_os_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Output-stationary conv with an LDS accumulator tile (submanifold convs: K = 27 offsets).
+//
+// A workgroup owns TOUT consecutive output rows x 32*NB output channels, kept as an fp32 tile in
+// LDS for the whole kernel.  For every offset k the tile's pairs are a contiguous run of the
+// canonical (k, output row) pair list - `seg[k * (n_tiles64 + 1) + t64]` marks where 64-row block
+// t64 starts inside offset k - so they are processed COMPACTED, 32 pairs per MFMA row block,
+// without empty rows.  Wave (cb, ph) owns channel block cb and every NPH-th chunk; its weight rows
+// W[n, k, :] go from L2 to registers once per offset, the gathered input rows stream into the A
+// operand, and the 32 x 32 result block is added to the tile's rows with ds_add (within one offset
+// every output row occurs once, and a barrier separates the offsets: no two additions to an
+// element race, so the result is bitwise reproducible).  At the end each element is written once,
+// 16 bytes per lane: no atomics to global memory, no zero-fill.
+// Grad-input runs the same kernel on grad_out with the transposed weights and kflip = 1: the pair
+// (j -> i) of offset k is the pair (i -> j) of offset K-1-k in the same canonical list.
+constexpr int kOslPad = 4;
+
+template <int NB, int TOUT>
+__global__ __launch_bounds__(256) void spconv_osl_kernel(
+    const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
+    const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
+    const int32_t* __restrict__ seg, int n_tiles64, int kflip, const float* __restrict__ bias,
+    int64_t n_out, float* __restrict__ Y) {
+  constexpr int NT = 32 * NB, LD = NT + kOslPad;
+  constexpr int NPH = 4 / NB >= 1 ? 4 / NB : 1;  // waves that share a channel block
+  constexpr int B64 = TOUT / 64;                 // 64-row blocks per tile
+  __shared__ __attribute__((aligned(16))) float acc_s[TOUT * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int cb = wave % NB, ph = wave / NB;
+  const bool active = wave < NB * NPH;
+  const int tile = blockIdx.x;
+  const int64_t row0 = (int64_t)tile * TOUT;
+  const int n0 = blockIdx.y * NT;
+  for (int e = tid; e < TOUT * LD; e += 256) acc_s[e] = 0.f;
+  __syncthreads();
+
+  const int n = n0 + cb * 32 + i;
+  const bool nok = active && n < c_out;
+  const float* wrow = W + (int64_t)(nok ? n : 0) * K * c_in + 4 * h;
+  const int t64 = tile * B64;
+  const int t64e = min(t64 + B64, n_tiles64);
+
+  for (int k = 0; k < K; ++k) {
+    const int32_t* sk = seg + (int64_t)k * (n_tiles64 + 1);
+    const int s = sk[t64], e = sk[t64e];
+    if (e > s && active) {
+      const int kw = kflip ? K - 1 - k : k;
+      const float* wk = wrow + (int64_t)kw * c_in;
+      const int nchunk = (e - s + 31) >> 5;
+      for (int c0 = 0; c0 < c_in; c0 += 128) {      // reduction axis in slabs of <= 128
+        const int cw = min(128, c_in - c0);
+        float4 b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) b[q] = ld4(wk + c0 + 8 * q, nok && 8 * q < cw);
+        for (int j = ph; j < nchunk; j += NPH) {
+          const int p = s + 32 * j + i;
+          const bool pv = p < e;
+          const int rin = pv ? pair_in[p] : 0;
+          const int rout = pv ? (int)(pair_out[p] - row0) : -1;
+          const float* xrow = X + (int64_t)rin * c_in + c0 + 4 * h;
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (8 * q < cw) {
+              const float4 a = ld4(xrow + 8 * q, pv);
+              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[q].x, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[q].y, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[q].z, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[q].w, d, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int orow = __shfl(rout, (r & 3) + 8 * (r >> 2) + 4 * h);
+            if (orow >= 0) atomicAdd(&acc_s[orow * LD + cb * 32 + i], d[r]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // offsets are separated: two additions to one element never overlap
+  }
+
+  // one coalesced write per output element (16 bytes per lane), bias fused
+  constexpr int Q = NT / 4;
+  for (int e4 = tid; e4 < TOUT * Q; e4 += 256) {
+    const int r = e4 / Q, c4 = (e4 % Q) * 4;
+    const int64_t orow = row0 + r;
+    const int nn = n0 + c4;
+    if (orow >= n_out || nn >= c_out) continue;
+    float4 v = *reinterpret_cast<const float4*>(&acc_s[r * LD + c4]);
+    if (nn + 3 < c_out) {
+      if (bias) {
+        v.x += bias[nn];
+        v.y += bias[nn + 1];
+        v.z += bias[nn + 2];
+        v.w += bias[nn + 3];
+      }
+      *reinterpret_cast<float4*>(Y + orow * c_out + nn) = v;
+    } else {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int u = 0; u < 4 && nn + u < c_out; ++u)
+        Y[orow * c_out + nn + u] = vv[u] + (bias ? bias[nn + u] : 0.f);
+    }
+  }
+}
+
+// seg[k * (n_tiles64 + 1) + t] = first pair of offset k whose output row is >= 64 t (t = n_tiles64:
+// the end of the offset).  One thread per entry, binary search in the (k, output row) sorted list.
+__global__ void osl_segments_kernel(const int32_t* __restrict__ pair_out,
+                                    const int32_t* __restrict__ kstart, int K, int n_tiles64,
+                                    int32_t* __restrict__ seg) {
+  const int64_t total = (int64_t)K * (n_tiles64 + 1);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int k = (int)(e / (n_tiles64 + 1)), t = (int)(e % (n_tiles64 + 1));
+    int lo = kstart[k], hi = kstart[k + 1];
+    const int target = t * 64;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (pair_out[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    seg[e] = lo;
+  }
+}
+
 template <int NB>
 int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -816,6 +944,56 @@ int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const fl
   }
 #undef PV2_LAUNCH_OS
   return pv2::check_launch("spconv_os_forward");
+}
+
+int pv2_spconv_osl_segments(const int32_t* pair_out, const int32_t* kstart, int K, int64_t n_out,
+                            int32_t* seg, pv2_stream_t stream) {
+  PV2_REQUIRE(K >= 1 && n_out >= 0 && n_out < 0x7fffffffLL, "pv2_spconv_osl_segments: bad sizes");
+  const int n_tiles64 = (int)((n_out + 63) / 64);
+  hipLaunchKernelGGL(osl_segments_kernel, dim3(pv2::grid_for((int64_t)K * (n_tiles64 + 1), 256)),
+                     dim3(256), 0, (hipStream_t)stream, pair_out, kstart, K, n_tiles64, seg);
+  return pv2::check_launch("spconv_osl_segments");
+}
+
+int pv2_spconv_osl_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                           int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                           const int32_t* seg, int kflip, const float* bias, float* out_feat,
+                           int64_t n_out, pv2_stream_t stream) {
+  PV2_REQUIRE(c_in >= 32 && (c_in % 32) == 0, "pv2_spconv_osl_forward: c_in must be a multiple of 32");
+  PV2_REQUIRE(c_out >= 1 && K >= 1 && (c_out % 4) == 0, "pv2_spconv_osl_forward: bad channel count");
+  PV2_REQUIRE(n_out >= 0 && n_out < 0x7fffffffLL, "pv2_spconv_osl_forward: bad row count");
+  (void)n_in;
+  if (n_out == 0) return PV2_OK;
+  const int n_tiles64 = (int)((n_out + 63) / 64);
+  const int nblk = (c_out + 31) / 32;
+  const int nb = nblk >= 4 ? 4 : nblk;
+  const int groups = (nblk + nb - 1) / nb;
+  // 128-row tiles halve the weight traffic per pair; 64-row tiles keep all CUs busy on the
+  // coarse levels (a few thousand rows)
+  const bool big = (int64_t)((n_tiles64 + 1) / 2) * groups >= 768;
+  const int tiles = big ? (n_tiles64 + 1) / 2 : n_tiles64;
+  const dim3 grid((unsigned)tiles, (unsigned)groups);
+  hipStream_t s = (hipStream_t)stream;
+#define PV2_LAUNCH_OSL(NB, TOUT)                                                                   \
+  hipLaunchKernelGGL((spconv_osl_kernel<NB, TOUT>), grid, dim3(256), 0, s, in_feat, c_in, weight,  \
+                     K, c_out, pair_in, pair_out, seg, n_tiles64, kflip, bias, n_out, out_feat)
+  if (big) {
+    switch (nb) {
+      case 1: PV2_LAUNCH_OSL(1, 128); break;
+      case 2: PV2_LAUNCH_OSL(2, 128); break;
+      case 3: PV2_LAUNCH_OSL(3, 128); break;
+      default: PV2_LAUNCH_OSL(4, 128); break;
+    }
+  } else {
+    switch (nb) {
+      case 1: PV2_LAUNCH_OSL(1, 64); break;
+      case 2: PV2_LAUNCH_OSL(2, 64); break;
+      case 3: PV2_LAUNCH_OSL(3, 64); break;
+      default: PV2_LAUNCH_OSL(4, 64); break;
+    }
+  }
+#undef PV2_LAUNCH_OSL
+  return pv2::check_launch("spconv_osl_forward");
 }
 
 int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,

@@ -27,6 +27,19 @@ _OS_ENV = os.environ.get("PV2_SPCONV_OS", "auto")
 USE_OS = True if _OS_ENV == "1" else False if _OS_ENV == "0" else "auto"
 
 
+# The LDS-accumulator output-stationary kernel (pv2_spconv_osl_forward) for submanifold convs is
+# EXPERIMENTAL and off: it removes the atomics (compacted pair chunks, one store per element) but
+# its per-offset chain of dependent loads (segment -> pair -> row -> MFMA) is not yet pipelined and
+# it measures 3-7x SLOWER than the scatter-add kernel (profiles/r02_spconv_os_ab_v2.txt).
+# PV2_SPCONV_OSL=1 switches it on for A/B runs.
+USE_OSL = os.environ.get("PV2_SPCONV_OSL", "0") == "1"
+
+
+def _use_osl(rb, c_in, c_out) -> bool:
+    return (USE_OSL and USE_OS is not False and rb.osl is not None and c_in % 32 == 0
+            and c_out % 4 == 0)
+
+
 def _use_os(rb) -> bool:
     if rb.nbr is None or USE_OS is False:
         return False
@@ -87,6 +100,9 @@ class Rulebook:
     perm: Optional[torch.Tensor] = None
     kflip: int = 0
     _transposed_os: Optional[tuple] = None   # (nbr, stride, perm, kflip) of the transposed rulebook
+    # LDS-accumulator output-stationary view (submanifold convs): the canonical pair lists, the
+    # per-offset segment starts of every 64-row output block, and the weight-offset mirror flag
+    osl: Optional[tuple] = None              # (pair_in, pair_out, seg, kflip)
 
     @property
     def n_pairs(self) -> int:
@@ -119,6 +135,8 @@ class Rulebook:
         if self._transposed_os is not None:
             rb.nbr, rb.nbr_stride, rb.perm, rb.kflip = self._transposed_os
             rb._transposed_os = (self.nbr, self.nbr_stride, self.perm, self.kflip)
+        if self.osl is not None:  # same canonical lists, weight offsets mirrored
+            rb.osl = self.osl[:3] + (1 - self.osl[3],)
         return rb
 
 
@@ -183,6 +201,10 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if n > 0:
         # the neighbour table is its own transpose up to mirroring the offsets (coordinates are
         # unique): grad-input reads the same table with the weight offsets flipped
+        seg = torch.empty(K * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_spconv_osl_segments(_ptr(pair_out), _ptr(kstart), K, n, _ptr(seg),
+                                             _stream(coords)), "pv2_spconv_osl_segments")
+        rb.osl = (pair_in, pair_out, seg, 0)
         # (the mask sort is only worth its launches when the submanifold convs run output-stationary)
         rb.nbr, rb.nbr_stride = nbr, n
         rb.perm = _mask_order(nbr, K, n, n) if USE_OS is True else None
@@ -253,6 +275,13 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     c_out, K, c_in = weight_okc.shape
     assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
     L = _lib.lib()
+    if out is None and _use_osl(rb, c_in, c_out):
+        pin, pout, seg, kflip = rb.osl
+        out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
+        _lib.check(L.pv2_spconv_osl_forward(
+            _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(pin), _ptr(pout), _ptr(seg),
+            kflip, _ptr(bias), _ptr(out), rb.n_out, _stream(feats)), "pv2_spconv_osl_forward")
+        return out
     if out is None and _use_os(rb):
         out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
         _lib.check(L.pv2_spconv_os_forward(

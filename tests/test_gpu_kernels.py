@@ -446,6 +446,7 @@ def test_output_stationary_conv_is_bitwise_reproducible_and_equals_scatter_kerne
     coords = random_voxels(8, batch=2, n_per_batch=900)
     n = len(coords)
     monkeypatch.setattr(K, "USE_OS", True)
+    monkeypatch.setattr(K, "USE_OSL", False)   # this test is about the gather-table kernel
     rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), ksize)
     assert rb.nbr is not None
     x = torch.randn(n, c_in, device=device)
@@ -457,6 +458,37 @@ def test_output_stationary_conv_is_bitwise_reproducible_and_equals_scatter_kerne
         assert torch.equal(y, runs[0][0]) and torch.equal(dx, runs[0][1])
     monkeypatch.setattr(K, "USE_OS", False)
     y_ref, dx_ref = K.spconv_forward(x, w, rb), K.spconv_forward(g, w_t, rb.transposed())
+    assert (runs[0][0] - y_ref).abs().max() <= 2e-5 * y_ref.abs().max()
+    assert (runs[0][1] - dx_ref).abs().max() <= 2e-5 * dx_ref.abs().max()
+
+
+@pytest.mark.parametrize("c_in,c_out,n_per", [(32, 32, 900), (64, 96, 900), (128, 128, 3000),
+                                              (256, 160, 700), (96, 64, 40)])
+def test_lds_tile_output_stationary_conv(device, c_in, c_out, n_per, monkeypatch):
+    """The LDS-accumulator kernel (compacted pair chunks, one store per element) on submanifold
+    convs: forward and grad-input (same pair lists, mirrored offsets) equal the scatter-add kernels up
+    to fp32 re-association and are bitwise repeatable; also through autograd with a fused bias."""
+    from ponderv2_amd import kernels as K
+
+    torch.manual_seed(c_in + 3 * c_out)
+    coords = random_voxels(12, batch=2, n_per_batch=n_per)
+    n = len(coords)
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), 3)
+    assert rb.osl is not None
+    x = torch.randn(n, c_in, device=device)
+    w = torch.randn(c_out, 27, c_in, device=device) * 0.1
+    g = torch.randn(n, c_out, device=device)
+    bias = torch.randn(c_out, device=device)
+    w_t = w.permute(2, 1, 0).contiguous()
+    monkeypatch.setattr(K, "USE_OSL", True)
+    runs = [(K.spconv_forward(x, w, rb, bias=bias), K.spconv_forward(g, w_t, rb.transposed()))
+            for _ in range(3)]
+    for y, dx in runs[1:]:
+        assert torch.equal(y, runs[0][0]) and torch.equal(dx, runs[0][1])
+    monkeypatch.setattr(K, "USE_OSL", False)
+    monkeypatch.setattr(K, "USE_OS", False)
+    y_ref = K.spconv_forward(x, w, rb) + bias
+    dx_ref = K.spconv_forward(g, w_t, rb.transposed())
     assert (runs[0][0] - y_ref).abs().max() <= 2e-5 * y_ref.abs().max()
     assert (runs[0][1] - dx_ref).abs().max() <= 2e-5 * dx_ref.abs().max()
 

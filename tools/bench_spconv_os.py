@@ -36,14 +36,15 @@ def ab(name, rb, cin, cout, kk):
     x = torch.randn(rb.n_in, cin, device=dev); w = torch.randn(cout, kk, cin, device=dev) * 0.05
     fl = 2.0 * rb.n_pairs * cin * cout
     res = []
-    for use in (False, True):
-        K.USE_OS = use
+    for use, osl in ((False, False), (True, False), (True, True)):
+        K.USE_OS, K.USE_OSL = use, osl
         t = timeit(lambda: K.spconv_forward(x, w, rb))
         res.append(t)
-    K.USE_OS = "auto"
-    print("%-22s %4d->%4d K%3d pairs %7d rows %6d | scatter %7.1f us %6.1f TF | out-stationary %7.1f us %6.1f TF | x%.2f"
+    K.USE_OS, K.USE_OSL = "auto", True
+    print("%-22s %4d->%4d K%3d pairs %7d rows %6d | scatter %7.1f us %6.1f TF | gather-table OS %7.1f us %6.1f TF | "
+          "LDS-tile OS %7.1f us %6.1f TF | x%.2f"
           % (name, cin, cout, kk, rb.n_pairs, rb.n_out, res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6,
-             res[0] / res[1]), flush=True)
+             res[2], fl / res[2] / 1e6, res[0] / res[2]), flush=True)
 
 ab("stem k5", stem, 6, 32, 125)
 for lvl, cin, cout in [(0, 96, 96), (0, 128, 96), (1, 32, 32), (1, 96, 96), (1, 128, 96), (2, 64, 64), (2, 128, 128),
