@@ -97,8 +97,10 @@ def _look_at(eye, target):
 
 
 def make_scene(seed, n_raw=120000, keep=0.2, grid_size=0.02, num_views=2, image_hw=(480, 640),
-               n_voxels=None, condition="ScanNet", num_classes=20):
-    """One synthetic scene as numpy arrays (the per-sample dict a Dataset would return)."""
+               n_voxels=None, condition="ScanNet", num_classes=20, voxelize=True):
+    """One synthetic scene as numpy arrays (the per-sample dict a Dataset would return).
+    ``voxelize=False`` skips the host GridSample and returns the raw (dropout-thinned) points, for
+    runs that voxelise on the device (``datasets.voxelize.device_grid_sample``)."""
     rng = np.random.default_rng(seed)
     boxes = _boxes(rng)
     faces = _faces(boxes)
@@ -110,12 +112,13 @@ def make_scene(seed, n_raw=120000, keep=0.2, grid_size=0.02, num_views=2, image_
                 color=np.clip(plane_rgb[pid[sel]] + rng.uniform(-20, 20, (len(sel), 3)), 0, 255)
                 .astype(np.float32),
                 normal=nrm[sel].astype(np.float32), segment=(pid[sel] % num_classes).astype(np.int64))
-    state = np.random.get_state()
-    np.random.seed(seed)  # GridSample draws from numpy's global generator, as the reference does
-    data = GridSample(grid_size=grid_size, hash_type="fnv", mode="train",
-                      return_grid_coord=True)(data)
-    np.random.set_state(state)
-    if n_voxels is not None:  # trim / pad-by-repeat-free: trim only (config 1 asks for 20 000)
+    if voxelize:
+        state = np.random.get_state()
+        np.random.seed(seed)  # GridSample draws from numpy's global generator, as the reference does
+        data = GridSample(grid_size=grid_size, hash_type="fnv", mode="train",
+                          return_grid_coord=True)(data)
+        np.random.set_state(state)
+    if n_voxels is not None and voxelize:  # trim / pad-by-repeat-free: trim only (config 1 asks for 20 000)
         for k in ("coord", "color", "normal", "segment", "grid_coord"):
             data[k] = data[k][:n_voxels]
         data["grid_coord"] = data["grid_coord"] - data["grid_coord"].min(0)
@@ -156,7 +159,8 @@ def collate_fn(samples):
     stack = lambda k: torch.from_numpy(np.stack([s[k] for s in samples]))  # noqa: E731
     counts = [len(s["coord"]) for s in samples]
     feat = np.concatenate([np.concatenate([s["color"] / 127.5 - 1, s["normal"]], 1) for s in samples])
-    return dict(coord=cat("coord", np.float32), grid_coord=cat("grid_coord", np.int64),
+    grid = dict(grid_coord=cat("grid_coord", np.int64)) if "grid_coord" in samples[0] else {}
+    return dict(coord=cat("coord", np.float32), **grid,
                 feat=torch.from_numpy(feat.astype(np.float32)), segment=cat("segment", np.int64),
                 offset=torch.tensor(np.cumsum(counts), dtype=torch.int64),
                 offset_host=[int(v) for v in np.cumsum(counts)],
@@ -172,11 +176,11 @@ class SyntheticRGBDDataset(torch.utils.data.Dataset):
 
     def __init__(self, length=64, base_seed=0, num_views=2, image_hw=(480, 640), n_raw=120000,
                  keep=0.2, grid_size=0.02, n_voxels=None, loop=1, condition="ScanNet",
-                 num_classes=20, **kwargs):
+                 num_classes=20, voxelize=True, **kwargs):
         self.length, self.base_seed, self.loop = length, base_seed, loop
         self.kw = dict(num_views=num_views, image_hw=tuple(image_hw), n_raw=n_raw, keep=keep,
                        grid_size=grid_size, n_voxels=n_voxels, condition=condition,
-                       num_classes=num_classes)
+                       num_classes=num_classes, voxelize=voxelize)
 
     def __len__(self):
         return self.length * self.loop

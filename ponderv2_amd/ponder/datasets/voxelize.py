@@ -129,3 +129,35 @@ def grid_sample_torch(coord, grid_size, hash_type="fnv", pick=None):
         pick = torch.randint(0, int(count.max()), (count.numel(),), device=coord.device)
     idx_unique = order[start + pick.to(start.device) % count]
     return idx_unique, grid[idx_unique]
+
+
+def device_grid_sample(batch, grid_size=0.02, hash_type="fnv", keys=("coord", "feat", "segment"),
+                       picks=None):
+    """Train-mode GridSample of a collated batch of RAW points on whatever device the batch lives
+    on (the GPU, after the trainer's host->device copy): per scene - the rows between consecutive
+    ``offset`` entries - one representative per occupied voxel, in the host transform's voxel order
+    (``grid_sample_torch``).  Rewrites ``keys`` and ``offset`` and adds ``grid_coord``; every other
+    entry (images, poses, ...) passes through.  This is the device half of SURVEY 8(f) F3: the
+    loader workers then only stream raw points (``voxelize=False`` on the synthetic datasets).
+    ``picks``: optional list of per-scene tensors standing in for the transform's random draws."""
+    import torch
+
+    ends = batch.get("offset_host") or batch["offset"].tolist()   # one read of B small numbers
+    out = {k: [] for k in keys if k in batch}
+    grids, new_ends, start = [], [], 0
+    for b, end in enumerate(ends):
+        idx, grid = grid_sample_torch(batch["coord"][start:end], grid_size, hash_type,
+                                      None if picks is None else picks[b])
+        for k in out:
+            out[k].append(batch[k][start:end][idx])
+        grids.append(grid)
+        new_ends.append((new_ends[-1] if new_ends else 0) + int(idx.numel()))
+        start = end
+    res = dict(batch)
+    for k, parts in out.items():
+        res[k] = torch.cat(parts)
+    res["grid_coord"] = torch.cat(grids)
+    res["offset"] = torch.tensor(new_ends, dtype=batch["offset"].dtype).to(batch["offset"].device)
+    if "offset_host" in batch:
+        res["offset_host"] = list(new_ends)
+    return res

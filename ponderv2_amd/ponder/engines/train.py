@@ -18,6 +18,7 @@ from ..utils import comm
 from ..utils.optimizer import build_optimizer, build_scheduler
 from ..utils.registry import Registry
 from ..datasets.collate import loader_collate
+from ..datasets.voxelize import device_grid_sample
 from .defaults import create_ddp_model, worker_init_fn
 from .hooks import HOOKS, HookBase
 
@@ -159,6 +160,10 @@ class Trainer(TrainerBase):
         batch = self.comm_info["input_dict"]
         batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
                  for k, v in batch.items()}
+        if self.cfg.get("device_voxelize"):
+            # GridSample on the device: the loader streamed raw points; the voxel
+            # set and its order equal the host transform's (datasets/voxelize.py)
+            batch = device_grid_sample(batch, **self.cfg.device_voxelize)
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=bool(self.cfg.enable_amp)):
             out = self.model(batch)
             loss = out["loss"]

@@ -37,7 +37,9 @@ def test_trainer_two_ranks_via_launch(tmp_path):
     cfg = Config(dict(
         weight=None, resume=False, evaluate=False, seed=3, save_path=str(tmp_path), num_worker=0,
         batch_size=2, epoch=1, eval_epoch=1, sync_bn=False, enable_amp=False, empty_cache=False,
-        find_unused_parameters=True, mix_prob=0, param_dicts=None,
+        find_unused_parameters=True, mix_prob=0, max_point=2000000, param_dicts=None,
+        # the loader streams RAW points, the trainer voxelises them after the host->device copy
+        device_voxelize=dict(grid_size=0.02, hash_type="fnv"),
         hooks=[dict(type="CheckpointLoader"), dict(type="IterationTimer", warmup_iter=0),
                dict(type="InformationWriter"), dict(type="CheckpointSaver", save_freq=None)],
         train=dict(type="DefaultTrainer"), model=ddp_worker.tiny_model_cfg(),
@@ -45,7 +47,7 @@ def test_trainer_two_ranks_via_launch(tmp_path):
         scheduler=dict(type="OneCycleLR", max_lr=1e-4, pct_start=0.05, anneal_strategy="cos",
                        div_factor=10.0, final_div_factor=10000.0),
         data=dict(train=dict(type="SyntheticRGBDDataset", length=4, base_seed=80, num_views=2,
-                             image_hw=(24, 32), n_raw=5000))))
+                             image_hw=(24, 32), n_raw=5000, voxelize=False))))
     os.makedirs(tmp_path / "model", exist_ok=True)
     launch(ddp_worker.trainer_main, num_gpus_per_machine=2, cfg=(cfg,))
     rows = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]

@@ -354,3 +354,28 @@ def test_worker_seeds_follow_the_reference_formula(monkeypatch):
     monkeypatch.setattr(defaults, "set_seed", seen.append)
     defaults.worker_init_fn(3, num_workers=8, rank=2, seed=100)
     assert seen == [8 * 2 + 3 + 100]
+
+
+def test_device_voxelisation_of_a_raw_batch_equals_host_gridsample():
+    """datasets.voxelize.device_grid_sample on a collated batch of RAW points: per scene the same
+    voxel set, in the same order, with the same integer coordinates as the host GridSample
+    transform of the reference (datasets/transform.py:1078-1145); representatives are members of
+    their voxel.  This is what Trainer.run_step applies when cfg.device_voxelize is set."""
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample
+
+    kw = dict(n_raw=6000, num_views=1, image_hw=(12, 16))
+    host = [make_scene(s, **kw) for s in (5, 6)]
+    raw = collate_fn([make_scene(s, voxelize=False, **kw) for s in (5, 6)])
+    assert "grid_coord" not in raw and raw["coord"].shape[0] == 2 * 1200
+    out = device_grid_sample(raw, grid_size=0.02, hash_type="fnv")
+    ends = [0] + out["offset"].tolist()
+    assert out["offset_host"] == ends[1:]
+    for b, h in enumerate(host):
+        g = out["grid_coord"][ends[b]:ends[b + 1]].numpy()
+        assert np.array_equal(g, h["grid_coord"])                      # same voxels, same order
+        c = out["coord"][ends[b]:ends[b + 1]].numpy()
+        cell = np.floor(c.astype(np.float64) / 0.02).astype(int)
+        assert np.array_equal(cell - cell.min(0), g)                  # representative lies in its voxel
+        assert out["feat"].shape[0] == out["coord"].shape[0] == out["segment"].shape[0]
+    assert out["rgb"] is raw["rgb"]                                     # everything else passes through
