@@ -401,26 +401,22 @@ def run_ponder_ppt(device):
     return errs
 
 
-def check_model_errors(errs, loss_tol=1e-4, rest_tol=5e-3, deep_tol=0.2, flip_tol=None):
-    """Shared assertion of the end-to-end golden tests.  Loss terms to ``loss_tol``; gradients that
-    have crossed the sparse backbone's ~60 BatchNorm layers (backbone parameters, the mask token,
-    the context embedding) to ``deep_tol`` only - in these miniature scenes a different summation
-    order alone (1 thread instead of 128 on the host, atomics on the GPU) moves them by a few
-    percent while the loss moves by 1e-7..1e-4; every other gradient to ``rest_tol``.
+def check_model_errors(errs, loss_tol=1e-4, rest_tol=5e-3, deep_tol=0.2):
+    """Shared assertion of the end-to-end golden tests.  Every loss term to ``loss_tol`` (the north
+    star's 1e-4 - no exception path).  Gradients that have crossed the sparse backbone's ~60
+    BatchNorm layers (backbone parameters, the mask token, the context embedding) to ``deep_tol``:
+    in these miniature scenes a different fp32 summation order alone (1 thread instead of 128 on
+    the host) moves them by a few percent while the loss moves by 1e-7..1e-4; every other gradient
+    to ``rest_tol``.
 
-    ``flip_tol``: the importance sampler inverts a CDF with ``searchsorted`` - a discontinuous step.
-    A last-bit difference upstream can move ONE sample of ONE ray into the neighbouring bin, which
-    shifts a 288-ray depth loss by ~1e-3 and small-fan-in gradients (a bias) by tens of percent,
-    although a 1e-6 input perturbation moves the same loss by only 2e-6 and float64 runs agree to
-    1e-13 across thread counts.  When given, a loss error between ``loss_tol`` and ``flip_tol``
-    is accepted as such a flip and the gradients are then only required to stay within 50 %."""
+    The importance sampler inverts a CDF with ``searchsorted`` - integer work the full-size fixtures
+    pin bit-exactly (tests/golden/ponder_indoor_cfg*.npz: ``pdf_bins``).  The GPU tests run the
+    kernels in their DETERMINISTIC mode (output-stationary convs: identical forward bits on every
+    run), so a sample cannot land in a different bin from one run to the next."""
     deep_keys = [k for k in errs if k.startswith("grad_backbone.")
                  or k in ("grad_mtoken", "grad_embedding_table.weight")]
     losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
     rest = {k: v for k, v in errs.items() if k.startswith("grad_") and k not in deep_keys}
-    if flip_tol is not None and loss_tol <= max(losses.values()) < flip_tol:
-        assert max(v for k, v in errs.items() if k.startswith("grad_")) < 0.5, errs
-        return
     assert max(losses.values()) < loss_tol, errs
     assert not deep_keys or max(errs[k] for k in deep_keys) < deep_tol, errs
     assert not rest or max(rest.values()) < rest_tol, errs

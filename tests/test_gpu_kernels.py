@@ -70,6 +70,39 @@ def test_downsample_drops_out_of_shape(device):
     assert np.array_equal(_np(rb.pair_in), pin) and np.array_equal(_np(rb.pair_out), pout)
 
 
+def test_rulebooks_bit_exact_at_the_bench_size(device):
+    """BASELINE configs[1] geometry (2 synthetic ScanNet-shaped scenes, ~46.8 k voxels in the
+    dataset's hash order): the k5 stem and k3 rulebooks of level 0 and the whole chain of four
+    strided levels with their k3 rulebooks - voxel coordinates and (k, in, out) pair lists equal
+    the numpy oracle's, bit for bit."""
+    from oracle import rulebook as orb
+    from ponderv2_amd import kernels as K
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    b = collate_fn([make_scene(i, num_views=1, image_hw=(12, 16)) for i in range(2)])
+    batch = torch.repeat_interleave(torch.arange(2), torch.diff(b["offset"], prepend=torch.zeros(1, dtype=torch.long)))
+    coords = torch.cat([batch[:, None], b["grid_coord"]], 1).int()
+    assert len(coords) > 45000
+    c_np, c_dev = coords.numpy(), coords.to(device)
+    shape = [int(v) + 96 for v in b["grid_coord"].max(0).values]
+    for ksize in (5, 3):
+        rb = K.build_subm_rulebook(c_dev, ksize)
+        pin, pout, ks = orb.subm_rulebook(c_np, ksize)
+        assert np.array_equal(rb.kstart_host, ks) and np.array_equal(_np(rb.pair_in), pin)
+        assert np.array_equal(_np(rb.pair_out), pout)
+    for level in range(4):
+        shape = [(s - 2) // 2 + 1 for s in shape]
+        rb, oc = K.build_downsample_rulebook(c_dev, 2, shape)
+        ooc, pin, pout, ks = orb.downsample_rulebook(c_np, 2, shape)
+        assert np.array_equal(_np(oc), ooc) and np.array_equal(rb.kstart_host, ks)
+        assert np.array_equal(_np(rb.pair_in), pin) and np.array_equal(_np(rb.pair_out), pout)
+        c_np, c_dev = ooc, oc
+        rb3 = K.build_subm_rulebook(c_dev, 3)
+        pin, pout, ks = orb.subm_rulebook(c_np, 3)
+        assert np.array_equal(rb3.kstart_host, ks) and np.array_equal(_np(rb3.pair_in), pin)
+        assert np.array_equal(_np(rb3.pair_out), pout)
+
+
 # ------------------------------------------------------------------ conv arithmetic
 def _oracle_conv(feats, w, pin, pout, ks, n_out):
     from oracle.sparse_ops import sparse_conv
