@@ -141,6 +141,16 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
                        int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
                        float* out_feat, int64_t n_out, pv2_stream_t stream);
 
+/* The same scatter-add convolution with the weight tensor given REDUCTION-MAJOR, weight_t[c_in, K,
+ * c_out]: what grad-input needs - grad_in = conv(grad_out, W^T) - when W is the forward weight
+ * [c_out_fwd = c_in here, K, c_in_fwd = c_out here] as stored, so no transposed copy of the weights
+ * is materialised.  LDS-staged kernel only: c_in % 32 == 0, c_out % 4 == 0, tile_pairs = 128;
+ * `out` zero-initialised (or pre-loaded). */
+int pv2_spconv_forward_wt(const float* in_feat, int64_t n_in, int c_in, const float* weight_t, int K,
+                          int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                          const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
+                          int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream);
+
 /* Output-stationary form of the same convolution (same reference call sites): every output row is
  * computed by ONE workgroup from the gather table and written once - no atomics, no zero-fill,
  * bitwise reproducible.

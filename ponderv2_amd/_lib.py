@@ -27,7 +27,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -55,6 +55,8 @@ SIGNATURES = {
     "pv2_spconv_osl_segments": (c_int, [_P, _P, c_int, c_int64, _P, _P]),
     "pv2_spconv_osl_forward": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P]),
+    "pv2_spconv_forward_wt": (
+        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, c_int64, _P]),
     "pv2_spconv_wgrad_tile": (c_int, [c_int, c_int, c_int64, c_int]),
     "pv2_spconv_backward_weight": (
         c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,

@@ -75,28 +75,33 @@ __device__ __forceinline__ int32_t hash_lookup(const uint64_t* __restrict__ keys
   }
 }
 
-// One thread per voxel, loop over the K^3 offsets: nbr[k*n + i] is written coalesced along i.
+// One thread per (voxel, dx, dy) column of the window, looping over dz: the hash probes of a voxel
+// are independent, so spreading them over ksize^2 threads (25 for the 5x5x5 stem) hides their
+// latency; nbr[k*n + i] is still written coalesced along i (consecutive threads = consecutive i).
 __global__ void subm_table_kernel(const int4* __restrict__ coords, int64_t n, int ksize,
                                   const uint64_t* __restrict__ keys,
                                   const int32_t* __restrict__ vals, uint64_t mask,
                                   int32_t* __restrict__ nbr) {
   const int r = ksize / 2;
+  const int64_t total = n * ksize * ksize;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int4 c = coords[i];
-    int k = 0;
-    for (int dx = -r; dx <= r; ++dx)
-      for (int dy = -r; dy <= r; ++dy)
-        for (int dz = -r; dz <= r; ++dz, ++k) {
-          int x = c.y + dx, y = c.z + dy, z = c.w + dz;
-          int32_t j = -1;
-          if (dx == 0 && dy == 0 && dz == 0) {
-            j = (int32_t)i;  // centre tap: the voxel itself (keeps duplicates self-consistent)
-          } else if (x >= 0 && y >= 0 && z >= 0) {
-            j = hash_lookup(keys, vals, mask, pack_key(c.x, x, y, z));
-          }
-          nbr[(int64_t)k * n + i] = j;
-        }
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t i = e % n;
+    const int col = (int)(e / n);
+    const int dx = col / ksize - r, dy = col % ksize - r;
+    const int4 c = coords[i];
+    const int x = c.y + dx, y = c.z + dy;
+    int k = col * ksize;
+    for (int dz = -r; dz <= r; ++dz, ++k) {
+      const int z = c.w + dz;
+      int32_t j = -1;
+      if (dx == 0 && dy == 0 && dz == 0) {
+        j = (int32_t)i;  // centre tap: the voxel itself (keeps duplicates self-consistent)
+      } else if (x >= 0 && y >= 0 && z >= 0) {
+        j = hash_lookup(keys, vals, mask, pack_key(c.x, x, y, z));
+      }
+      nbr[(int64_t)k * n + i] = j;
+    }
   }
 }
 
@@ -347,7 +352,7 @@ int pv2_subm_neighbor_table(const int32_t* coords, int64_t n, int ksize,
   PV2_REQUIRE(ksize >= 1 && (ksize & 1) && ksize <= 2 * kBias + 1,
               "pv2_subm_neighbor_table: ksize must be odd and <= 33");
   if (n == 0) return PV2_OK;
-  hipLaunchKernelGGL(subm_table_kernel, dim3(pv2::grid_for(n, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(subm_table_kernel, dim3(pv2::grid_for(n * ksize * ksize, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const int4*)coords, n, ksize, table_keys, table_vals,
                      (uint64_t)(table_size - 1), nbr);
   return pv2::check_launch("subm_table");

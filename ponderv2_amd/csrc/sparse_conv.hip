@@ -197,14 +197,20 @@ constexpr int kFwdTile = 128;
 constexpr int kKC = 32;
 constexpr int kWPad = kKC + 4;
 
-template <int NB>
+// TRANS: W is the FORWARD weight [c_in, K, c_out] of the conv whose grad-input this launch computes
+// (reduction axis outermost): slabs are staged reduction-major in LDS (coalesced 16-byte reads
+// along the output-channel axis, no transposed copy of the weights in HBM) and the B fragment is
+// four 4-byte LDS reads instead of one 16-byte read.
+template <int NB, bool TRANS>
 __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int n_groups,
     float* __restrict__ Y, int ablate, int tile_base, int skip_lo, int skip_len, int store) {
   constexpr int NT = 32 * NB;
+  constexpr int LDT = NT + 4;  // row stride of the reduction-major (TRANS) slab
   __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
+  static_assert(kKC * LDT <= NT * kWPad, "TRANS slab fits the same buffer");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int tile = blockIdx.x / n_groups + tile_base;
   if (tile >= skip_lo) tile += skip_len;  // the tiles of the centre offset ran in the store pass
@@ -223,10 +229,26 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 
   // weight staging: NT rows x 8 float4 per slab; thread t owns float4 q = t + 256*u, i.e. row
   // (t >> 3) + 32*u and 16-byte column t & 7
+  // plain layout: thread t stages float4 (row r0 + 32u, 16-byte column c4) of the [NT x 32] slab;
+  // TRANS: float4 q = t + 256u of the [32 x NT] slab: reduction row q / (NT/4), columns 4 (q % (NT/4))
   const int r0 = tid >> 3, c4 = tid & 7;
   const float* wbase = W + ((int64_t)(n0 + r0) * K + k) * c_in + 4 * c4;
   const int64_t wstride = (int64_t)32 * K * c_in;
   const int wdst0 = r0 * kWPad + 4 * c4;
+  auto load_w = [&](int u, int kk) -> float4 {
+    if (!TRANS) return ld4(wbase + u * wstride + kk, n0 + r0 + 32 * u < c_out);
+    const int q = tid + 256 * u;
+    const int rr = q / (NT / 4), nn = n0 + 4 * (q % (NT / 4));
+    return ld4(W + ((int64_t)(kk + rr) * K + k) * c_out + nn, nn < c_out);
+  };
+  auto store_w = [&](int buf, int u, const float4& v) {
+    if (!TRANS) {
+      *reinterpret_cast<float4*>(&sW[buf][wdst0 + u * 32 * kWPad]) = v;
+    } else {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<float4*>(&sW[buf][(q / (NT / 4)) * LDT + 4 * (q % (NT / 4))]) = v;
+    }
+  };
 
   f32x16 acc[NB];
 #pragma unroll
@@ -238,10 +260,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 #pragma unroll
   for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow + 8 * s, pv);
 #pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    *reinterpret_cast<float4*>(&sW[0][wdst0 + u * 32 * kWPad]) =
-        ld4(wbase + u * wstride, n0 + r0 + 32 * u < c_out);
-  }
+  for (int u = 0; u < NB; ++u) store_w(0, u, load_w(u, 0));
   __syncthreads();
 
   const int nslab = c_in / kKC;
@@ -254,14 +273,19 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
       for (int s = 0; s < 4; ++s)
         a_nxt[s] = ld4(xrow + kk + 8 * s, pv);
 #pragma unroll
-      for (int u = 0; u < NB; ++u)
-        w_nxt[u] = ld4(wbase + u * wstride + kk, n0 + r0 + 32 * u < c_out);
+      for (int u = 0; u < NB; ++u) w_nxt[u] = load_w(u, kk);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const float4 b = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
+        float4 b;
+        if (!TRANS) {
+          b = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
+        } else {
+          const float* col = &sW[buf][(8 * s + 4 * h) * LDT + nb * 32 + i];
+          b = make_float4(col[0], col[LDT], col[2 * LDT], col[3 * LDT]);
+        }
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b.x, acc[nb], 0, 0, 0);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b.y, acc[nb], 0, 0, 0);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b.z, acc[nb], 0, 0, 0);
@@ -270,8 +294,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     }
     if (more) {
 #pragma unroll
-      for (int u = 0; u < NB; ++u)
-        *reinterpret_cast<float4*>(&sW[buf ^ 1][wdst0 + u * 32 * kWPad]) = w_nxt[u];
+      for (int u = 0; u < NB; ++u) store_w(buf ^ 1, u, w_nxt[u]);
 #pragma unroll
       for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
     }
@@ -812,7 +835,7 @@ int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const
 
 int ablate_flags();
 
-template <int NB>
+template <int NB, bool TRANS>
 int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                    const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
                    float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi) {
@@ -825,16 +848,16 @@ int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, c
     // pass A: the centre offset touches every output row exactly once -> plain stores initialise
     // the output (no zero-fill, no atomics); pass B: every other offset accumulates on top.
     const int64_t nc = center_hi - center_lo;
-    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
                        s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(),
                        (int)center_lo, 0x7fffffff, 0, 1);
     const int64_t rest = n_tiles - nc;
     if (rest > 0)
-      hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(rest * n_groups)), dim3(256),
+      hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(rest * n_groups)), dim3(256),
                          0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
                          (int)center_lo, (int)nc, 0);
   } else {
-    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
                        0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
                        0x7fffffff, 0, 0);
   }
@@ -870,11 +893,14 @@ int pv2_spconv_forward_tile(int c_in, int c_out) {
   return ((c_in % kKC) == 0 && !force_generic()) ? kFwdTile : PV2_PAIR_TILE;
 }
 
-int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
-                       int c_out, const int32_t* pair_in, const int32_t* pair_out,
-                       const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
-                       int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
-                       float* out_feat, int64_t n_out, pv2_stream_t stream) {
+}  // extern "C"
+
+static int spconv_forward_impl(bool trans, const float* in_feat, int64_t n_in, int c_in,
+                               const float* weight, int K, int c_out, const int32_t* pair_in,
+                               const int32_t* pair_out, const int32_t* kstart,
+                               const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                               int64_t center_tile_lo, int64_t center_tile_hi, float* out_feat,
+                               int64_t n_out, pv2_stream_t stream) {
   PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_forward: bad channel/offset count");
   PV2_REQUIRE(tile_pairs == pv2_spconv_forward_tile(c_in, c_out),
               "pv2_spconv_forward: tile_pairs must be pv2_spconv_forward_tile(c_in, c_out)");
@@ -887,13 +913,23 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
   if (tile_pairs == kFwdTile) {
     PV2_REQUIRE(center_tile_hi <= n_tiles && center_tile_lo <= center_tile_hi,
                 "pv2_spconv_forward: bad centre tile range");
+    if (trans) {
+      PV2_REQUIRE((c_out % 4) == 0, "pv2_spconv_forward_wt: c_out must be a multiple of 4");
+      switch (nblk >= 4 ? 4 : nblk) {
+        case 1: return launch_fwd_lds<1, true>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+        case 2: return launch_fwd_lds<2, true>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+        case 3: return launch_fwd_lds<3, true>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+        default: return launch_fwd_lds<4, true>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      }
+    }
     switch (nblk >= 4 ? 4 : nblk) {
-      case 1: return launch_fwd_lds<1>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
-      case 2: return launch_fwd_lds<2>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
-      case 3: return launch_fwd_lds<3>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
-      default: return launch_fwd_lds<4>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      case 1: return launch_fwd_lds<1, false>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      case 2: return launch_fwd_lds<2, false>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      case 3: return launch_fwd_lds<3, false>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
+      default: return launch_fwd_lds<4, false>(PV2_FWD_ARGS, center_tile_lo, center_tile_hi);
     }
   }
+  PV2_REQUIRE(!trans, "pv2_spconv_forward_wt: needs the LDS-staged kernel (c_in % 32 == 0)");
   PV2_REQUIRE(center_tile_hi <= center_tile_lo,
               "pv2_spconv_forward: the generic kernel has no store pass (pass an empty centre range)");
   // generic path (any c_in): one wave per 32-pair tile, operands straight from global memory
@@ -906,6 +942,26 @@ int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float
     default: return launch_fwd<4>(PV2_FWD_ARGS);
   }
 #undef PV2_FWD_ARGS
+}
+
+extern "C" {
+
+int pv2_spconv_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                       int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                       const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
+                       int64_t n_tiles, int64_t center_tile_lo, int64_t center_tile_hi,
+                       float* out_feat, int64_t n_out, pv2_stream_t stream) {
+  return spconv_forward_impl(false, in_feat, n_in, c_in, weight, K, c_out, pair_in, pair_out, kstart,
+                             tile_start, tile_pairs, n_tiles, center_tile_lo, center_tile_hi,
+                             out_feat, n_out, stream);
+}
+
+int pv2_spconv_forward_wt(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
+                          int c_out, const int32_t* pair_in, const int32_t* pair_out,
+                          const int32_t* kstart, const int32_t* tile_start, int tile_pairs,
+                          int64_t n_tiles, float* out_feat, int64_t n_out, pv2_stream_t stream) {
+  return spconv_forward_impl(true, in_feat, n_in, c_in, weight, K, c_out, pair_in, pair_out, kstart,
+                             tile_start, tile_pairs, n_tiles, 0, 0, out_feat, n_out, stream);
 }
 
 int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,

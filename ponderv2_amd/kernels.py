@@ -15,6 +15,7 @@ from ._lib import PAIR_TILE, SCAN_CHUNK, WGRAD_TILE, PointsDesc, VolumeDesc
 import os
 
 FWD_LDS_TILE = 128  # tile of the LDS-staged forward kernel (pv2_spconv_forward_tile)
+FWD_LDS_TILE_K = 32  # ... which needs the reduction width to be a multiple of this
 # Which forward / grad-input kernel a conv with a gather table on its rulebook runs on:
 #   "auto" (default)  the output-stationary kernel (no atomics, no zero-fill, bitwise reproducible)
 #                     where it is the faster one on MI355X - strided and inverse convs, 1.0-1.7x
@@ -327,6 +328,29 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     return dw
 
 
+def spconv_grad_input(grad_out: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook) -> torch.Tensor:
+    """d loss / d feats of ``out = conv(feats, W)``: the conv of ``grad_out`` over the transposed
+    rulebook with W^T.  On the scatter-add path the forward weight [c_out, K, c_in] is read as it is
+    stored (reduction-major for this pass, pv2_spconv_forward_wt) - no transposed copy per layer per
+    step; the output-stationary kernels read 16-byte pieces along their reduction axis and take the
+    materialised transpose."""
+    rbt = rb.transposed()
+    c_out, K, c_in = weight_okc.shape
+    scatter = not (_use_osl(rbt, c_out, c_in) or _use_os(rbt))
+    if scatter and c_out % FWD_LDS_TILE_K == 0 and c_in % 4 == 0 and rbt.n_pairs > 0:
+        grad_out = grad_out.contiguous()
+        weight_okc = weight_okc.contiguous()
+        L = _lib.lib()
+        tile_start, n_tiles, _ = rbt.tiles(FWD_LDS_TILE)
+        out = zeros_by_kernel((rbt.n_out, c_in), torch.float32, grad_out.device)
+        _lib.check(L.pv2_spconv_forward_wt(
+            _ptr(grad_out), rbt.n_in, c_out, _ptr(weight_okc), K, c_in, _ptr(rbt.pair_in),
+            _ptr(rbt.pair_out), _ptr(rbt.kstart), _ptr(tile_start), FWD_LDS_TILE, n_tiles, _ptr(out),
+            rbt.n_out, _stream(grad_out)), "pv2_spconv_forward_wt")
+        return out
+    return spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(), rbt)
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Differentiable sparse conv on a fixed rulebook (features and weight get gradients)."""
 
@@ -343,8 +367,7 @@ class SparseConvFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         g_feats = g_w = None
         if ctx.needs_input_grad[0]:
-            w_t = weight_okc.permute(2, 1, 0).contiguous()  # [c_in, K, c_out]
-            g_feats = spconv_forward(grad_out, w_t, rb.transposed())
+            g_feats = spconv_grad_input(grad_out, weight_okc, rb)
         if ctx.needs_input_grad[1]:
             g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
         return g_feats, g_w, None
@@ -371,8 +394,7 @@ class SparseConvIntoFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         g_feats = g_w = None
         if ctx.needs_input_grad[0]:
-            g_feats = spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(),
-                                     rb.transposed())
+            g_feats = spconv_grad_input(grad_out, weight_okc, rb)
         if ctx.needs_input_grad[1]:
             g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
         return g_feats, g_w, None, grad_out

@@ -467,6 +467,25 @@ def test_raymarch_weighted_sum_vs_oracle(device, features):
         assert err < 1e-5, (name, err)
 
 
+@pytest.mark.parametrize("c_in,c_out", [(32, 32), (96, 128), (256, 96), (64, 12)])
+def test_grad_input_reads_the_forward_weight_in_place(device, c_in, c_out, monkeypatch):
+    """spconv_grad_input on the scatter path (pv2_spconv_forward_wt: the forward weight staged
+    reduction-major through LDS) equals the conv of grad_out with an explicitly transposed copy."""
+    from ponderv2_amd import kernels as K
+
+    monkeypatch.setattr(K, "USE_OS", False)
+    torch.manual_seed(c_in * 7 + c_out)
+    coords = random_voxels(13, batch=2, n_per_batch=1200)
+    n = len(coords)
+    rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), 3)
+    w = torch.randn(c_out, 27, c_in, device=device) * 0.1
+    g = torch.randn(n, c_out, device=device)
+    got = K.spconv_grad_input(g, w, rb)
+    ref = K.spconv_forward(g, w.permute(2, 1, 0).contiguous(), rb.transposed())
+    assert got.shape == (n, c_in)
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
 # ------------------------------------------------------------------ output-stationary conv
 @pytest.mark.parametrize("c_in,c_out,ksize", [(6, 32, 5), (32, 64, 3), (128, 128, 3), (256, 96, 3)])
 def test_output_stationary_conv_is_bitwise_reproducible_and_equals_scatter_kernel(
