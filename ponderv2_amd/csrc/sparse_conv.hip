@@ -685,91 +685,201 @@ __global__ __launch_bounds__(256) void spconv_os_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Output-stationary conv with an LDS accumulator tile (submanifold convs: K = 27 offsets).
+// LDS-tile output-stationary kernel (submanifold convs: K <= 27 offsets): a workgroup keeps its
+// output rows x channels as an fp32 tile in LDS for the whole launch and writes every element once -
+// no atomics to memory, no zero-fill.  Exclusive (rows x channels) per wave, no barrier between
+// offsets, a three-stage software pipeline (chunk descriptor -> pair indices -> gathered rows and
+// weight rows -> MFMA) so that no load latency is exposed, and 16-row chunks
+// (v_mfma_f32_16x16x4_f32, same rate as 32x32x2) for finer compaction.
 //
-// A workgroup owns TOUT consecutive output rows x 32*NB output channels, kept as an fp32 tile in
-// LDS for the whole kernel.  For every offset k the tile's pairs are a contiguous run of the
-// canonical (k, output row) pair list - `seg[k * (n_tiles64 + 1) + t64]` marks where 64-row block
-// t64 starts inside offset k - so they are processed COMPACTED, 32 pairs per MFMA row block,
-// without empty rows.  Wave (cb, ph) owns channel block cb and every NPH-th chunk; its weight rows
-// W[n, k, :] go from L2 to registers once per offset, the gathered input rows stream into the A
-// operand, and the 32 x 32 result block is added to the tile's rows with ds_add (within one offset
-// every output row occurs once, and a barrier separates the offsets: no two additions to an
-// element race, so the result is bitwise reproducible).  At the end each element is written once,
-// 16 bytes per lane: no atomics to global memory, no zero-fill.
-// Grad-input runs the same kernel on grad_out with the transposed weights and kflip = 1: the pair
-// (j -> i) of offset k is the pair (i -> j) of offset K-1-k in the same canonical list.
-constexpr int kOslPad = 4;
+// Wave (cb, ph) owns output rows [row0 + ph*RW, +RW) x channels [n0 + 32 cb, +32).  Per offset k its
+// pairs are the contiguous run seg[k][blk .. blk + RW/64) of the canonical (k, output row) list; they
+// are cut into chunks of 16 and listed in LDS once (kChunkCap descriptors per row range), then
+// streamed: while chunk c's 8 * (c_in / 128 slabs) MFMA pairs execute, chunk c+1's rows and (when
+// the offset or slab changes) weight rows are in flight and chunk c+2's pair indices are being
+// read.  Results go into the wave's private part of the LDS tile with ds_add_f32; one coalesced
+// store per element at the end.  Deterministic: every element is owned by one wave, which adds its
+// contributions in the fixed order of the canonical list.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kChunkCap = 27 * 8;   // K <= 27 offsets x RW/16 chunks (RW <= 128)
 
-template <int NB, int TOUT>
-__global__ __launch_bounds__(256) void spconv_osl_kernel(
+template <int NB, int RW>
+__global__ __launch_bounds__(256) void spconv_osl2_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ seg, int n_tiles64, int kflip, const float* __restrict__ bias,
     int64_t n_out, float* __restrict__ Y) {
-  constexpr int NT = 32 * NB, LD = NT + kOslPad;
-  constexpr int NPH = 4 / NB >= 1 ? 4 / NB : 1;  // waves that share a channel block
-  constexpr int B64 = TOUT / 64;                 // 64-row blocks per tile
+  constexpr int NPH = 4 / NB;          // row ranges per workgroup (NB in {1, 2, 4})
+  constexpr int TOUT = RW * NPH;
+  constexpr int NT = 32 * NB, LD = NT + 4;
+  constexpr int B64 = RW / 64;
   __shared__ __attribute__((aligned(16))) float acc_s[TOUT * LD];
+  __shared__ int s_p0[NPH][kChunkCap];   // first pair of the chunk
+  __shared__ int s_kn[NPH][kChunkCap];   // offset k | valid rows << 8
+  __shared__ int s_cnt[NPH][32], s_src[NPH][32], s_base[NPH][32];
+  __shared__ int s_total[NPH];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 31, h = lane >> 5;
+  const int i = lane & 15, q = lane >> 4;
   const int cb = wave % NB, ph = wave / NB;
-  const bool active = wave < NB * NPH;
-  const int tile = blockIdx.x;
-  const int64_t row0 = (int64_t)tile * TOUT;
+  const int64_t row0 = (int64_t)blockIdx.x * TOUT;
   const int n0 = blockIdx.y * NT;
+
   for (int e = tid; e < TOUT * LD; e += 256) acc_s[e] = 0.f;
+  // chunk lists: thread (l, k) counts offset k's pairs in row range l
+  {
+    const int l = tid >> 5, k = tid & 31;
+    if (l < NPH && k < K) {
+      const int b0 = ((int)blockIdx.x * NPH + l) * B64;
+      const int b1 = min(b0 + B64, n_tiles64);
+      const int32_t* sk = seg + (int64_t)k * (n_tiles64 + 1);
+      const int s = b0 < n_tiles64 ? sk[b0] : 0, e = b0 < n_tiles64 ? sk[b1] : 0;
+      s_src[l][k] = s;
+      s_cnt[l][k] = e - s;
+    }
+  }
+  __syncthreads();
+  if (tid < NPH) {
+    int base = 0;
+    for (int k = 0; k < K; ++k) {
+      s_base[tid][k] = base;
+      base += (s_cnt[tid][k] + 15) >> 4;
+    }
+    s_total[tid] = base;
+  }
+  __syncthreads();
+  {
+    const int l = tid >> 5, k = tid & 31;
+    if (l < NPH && k < K) {
+      const int n = s_cnt[l][k], s = s_src[l][k], base = s_base[l][k];
+      for (int j = 0; 16 * j < n; ++j) {
+        s_p0[l][base + j] = s + 16 * j;
+        s_kn[l][base + j] = k | (min(16, n - 16 * j) << 8);
+      }
+    }
+  }
   __syncthreads();
 
-  const int n = n0 + cb * 32 + i;
-  const bool nok = active && n < c_out;
-  const float* wrow = W + (int64_t)(nok ? n : 0) * K * c_in + 4 * h;
-  const int t64 = tile * B64;
-  const int t64e = min(t64 + B64, n_tiles64);
+  const int total = s_total[ph];
+  const int nslab = (c_in + 127) >> 7;
+  const int64_t wave_row0 = row0 + (int64_t)ph * RW;
+  const float* wrow[2];
+  bool nok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = n0 + cb * 32 + u * 16 + i;
+    nok[u] = n < c_out;
+    wrow[u] = W + (int64_t)(nok[u] ? n : 0) * K * c_in + 4 * q;
+  }
 
-  for (int k = 0; k < K; ++k) {
-    const int32_t* sk = seg + (int64_t)k * (n_tiles64 + 1);
-    const int s = sk[t64], e = sk[t64e];
-    if (e > s && active) {
-      const int kw = kflip ? K - 1 - k : k;
-      const float* wk = wrow + (int64_t)kw * c_in;
-      const int nchunk = (e - s + 31) >> 5;
-      for (int c0 = 0; c0 < c_in; c0 += 128) {      // reduction axis in slabs of <= 128
-        const int cw = min(128, c_in - c0);
-        float4 b[16];
+  // pipeline state: unit = (chunk c, slab sl)
+  float4 a_cur[8], a_nxt[8], b_cur[2][8], b_nxt[2][8];
+  int in_cur = 0, ol_cur = -1, k_cur = -1;       // rows of the chunk being multiplied
+  int in_nxt = 0, ol_nxt = -1, k_nxt = -1, c_nxt = 0, sl_nxt = 0;
+  int in_n2 = 0, ol_n2 = -1, k_n2 = -1;          // indices of the chunk after next
+
+  auto load_idx = [&](int c, int* in, int* ol, int* k) {
+    if (c < total) {
+      const int kn = s_kn[ph][c];
+      const int p = s_p0[ph][c] + i;
+      const bool v = i < (kn >> 8);
+      *k = kn & 0xff;
+      *in = v ? pair_in[p] : 0;
+      *ol = v ? (int)(pair_out[p] - wave_row0) : -1;
+    } else {
+      *k = -1;
+      *in = 0;
+      *ol = -1;
+    }
+  };
+  auto load_a = [&](float4 (&a)[8], int in, int ol, int sl) {
+    const float* xrow = X + (int64_t)in * c_in + sl * 128 + 4 * q;
+    const int cw = min(128, c_in - sl * 128);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) b[q] = ld4(wk + c0 + 8 * q, nok && 8 * q < cw);
-        for (int j = ph; j < nchunk; j += NPH) {
-          const int p = s + 32 * j + i;
-          const bool pv = p < e;
-          const int rin = pv ? pair_in[p] : 0;
-          const int rout = pv ? (int)(pair_out[p] - row0) : -1;
-          const float* xrow = X + (int64_t)rin * c_in + c0 + 4 * h;
-          f32x16 d;
+    for (int s8 = 0; s8 < 8; ++s8) a[s8] = ld4(xrow + 16 * s8, ol >= 0 && 16 * s8 < cw);
+  };
+  auto load_b = [&](float4 (&b)[2][8], int k, int sl) {
+    const int kw = kflip ? K - 1 - k : k;
+    const int cw = min(128, c_in - sl * 128);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            if (8 * q < cw) {
-              const float4 a = ld4(xrow + 8 * q, pv);
-              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[q].x, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[q].y, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[q].z, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[q].w, d, 0, 0, 0);
-            }
-          }
+      for (int s8 = 0; s8 < 8; ++s8)
+        b[u][s8] = ld4(wrow[u] + (int64_t)kw * c_in + sl * 128 + 16 * s8, nok[u] && 16 * s8 < cw);
+  };
+
+  if (total > 0) {
+    load_idx(0, &in_nxt, &ol_nxt, &k_nxt);
+    load_idx(1, &in_n2, &ol_n2, &k_n2);
+    load_a(a_nxt, in_nxt, ol_nxt, 0);
+    load_b(b_nxt, k_nxt, 0);
+  }
+  int k_loaded = -1, sl_loaded = -1;   // which (k, slab) b_cur holds
+  f32x4 d[2];
+  const int n_units = total * nslab;
+  for (int u = 0; u < n_units; ++u) {
+    // ---- rotate: next -> current
+    const int c = c_nxt, sl = sl_nxt;
+    in_cur = in_nxt;
+    ol_cur = ol_nxt;
+    k_cur = k_nxt;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int orow = __shfl(rout, (r & 3) + 8 * (r >> 2) + 4 * h);
-            if (orow >= 0) atomicAdd(&acc_s[orow * LD + cb * 32 + i], d[r]);
-          }
+    for (int s8 = 0; s8 < 8; ++s8) a_cur[s8] = a_nxt[s8];
+    if (k_cur != k_loaded || sl != sl_loaded) {
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) b_cur[w2][s8] = b_nxt[w2][s8];
+      k_loaded = k_cur;
+      sl_loaded = sl;
+    }
+    // ---- issue the loads of the next unit
+    if (u + 1 < n_units) {
+      if (sl + 1 < nslab) {
+        sl_nxt = sl + 1;            // same chunk, next slab of the reduction axis
+      } else {
+        c_nxt = c + 1;
+        sl_nxt = 0;
+        in_nxt = in_n2;
+        ol_nxt = ol_n2;
+        k_nxt = k_n2;
+        load_idx(c + 2, &in_n2, &ol_n2, &k_n2);
+      }
+      load_a(a_nxt, in_nxt, ol_nxt, sl_nxt);
+      if (k_nxt != k_loaded || sl_nxt != sl_loaded) load_b(b_nxt, k_nxt, sl_nxt);
+    }
+    // ---- multiply
+    if (sl == 0) {
+      d[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int cw = min(128, c_in - sl * 128);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      if (16 * s8 < cw) {
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].x, b_cur[w2][s8].x, d[w2], 0, 0, 0);
+          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].y, b_cur[w2][s8].y, d[w2], 0, 0, 0);
+          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].z, b_cur[w2][s8].z, d[w2], 0, 0, 0);
+          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].w, b_cur[w2][s8].w, d[w2], 0, 0, 0);
         }
       }
     }
-    __syncthreads();   // offsets are separated: two additions to one element never overlap
+    // ---- accumulate into the tile after the chunk's last slab
+    if (sl == nslab - 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = __shfl(ol_cur, q * 4 + r);
+        if (orow >= 0) {
+          float* dst = &acc_s[(ph * RW + orow) * LD + cb * 32 + i];
+          atomicAdd(dst, d[0][r]);
+          atomicAdd(dst + 16, d[1][r]);
+        }
+      }
+    }
   }
+  __syncthreads();
 
-  // one coalesced write per output element (16 bytes per lane), bias fused
   constexpr int Q = NT / 4;
   for (int e4 = tid; e4 < TOUT * Q; e4 += 256) {
     const int r = e4 / Q, c4 = (e4 % Q) * 4;
@@ -777,19 +887,13 @@ __global__ __launch_bounds__(256) void spconv_osl_kernel(
     const int nn = n0 + c4;
     if (orow >= n_out || nn >= c_out) continue;
     float4 v = *reinterpret_cast<const float4*>(&acc_s[r * LD + c4]);
-    if (nn + 3 < c_out) {
-      if (bias) {
-        v.x += bias[nn];
-        v.y += bias[nn + 1];
-        v.z += bias[nn + 2];
-        v.w += bias[nn + 3];
-      }
-      *reinterpret_cast<float4*>(Y + orow * c_out + nn) = v;
-    } else {
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      for (int u = 0; u < 4 && nn + u < c_out; ++u)
-        Y[orow * c_out + nn + u] = vv[u] + (bias ? bias[nn + u] : 0.f);
+    if (bias) {
+      v.x += bias[nn];
+      v.y += bias[nn + 1];
+      v.z += bias[nn + 2];
+      v.w += bias[nn + 3];
     }
+    *reinterpret_cast<float4*>(Y + orow * c_out + nn) = v;
   }
 }
 
@@ -1016,39 +1120,36 @@ int pv2_spconv_osl_forward(const float* in_feat, int64_t n_in, int c_in, const f
                            const int32_t* seg, int kflip, const float* bias, float* out_feat,
                            int64_t n_out, pv2_stream_t stream) {
   PV2_REQUIRE(c_in >= 32 && (c_in % 32) == 0, "pv2_spconv_osl_forward: c_in must be a multiple of 32");
-  PV2_REQUIRE(c_out >= 1 && K >= 1 && (c_out % 4) == 0, "pv2_spconv_osl_forward: bad channel count");
+  PV2_REQUIRE(c_out >= 4 && K >= 1 && K <= 27 && (c_out % 4) == 0,
+              "pv2_spconv_osl_forward: c_out % 4 == 0 and K <= 27");
   PV2_REQUIRE(n_out >= 0 && n_out < 0x7fffffffLL, "pv2_spconv_osl_forward: bad row count");
   (void)n_in;
   if (n_out == 0) return PV2_OK;
   const int n_tiles64 = (int)((n_out + 63) / 64);
   const int nblk = (c_out + 31) / 32;
-  const int nb = nblk >= 4 ? 4 : nblk;
+  const int nb = nblk >= 3 ? 4 : nblk;           // 96 channels run as 4 blocks, one of them masked
   const int groups = (nblk + nb - 1) / nb;
-  // 128-row tiles halve the weight traffic per pair; 64-row tiles keep all CUs busy on the
-  // coarse levels (a few thousand rows)
-  const bool big = (int64_t)((n_tiles64 + 1) / 2) * groups >= 768;
-  const int tiles = big ? (n_tiles64 + 1) / 2 : n_tiles64;
+  const int nph = 4 / nb;
+  // 128 rows per wave compact better (16-row chunks of ~36 pairs per offset); 64 keep the coarse
+  // levels' few thousand rows spread over the CUs
+  const bool big = ((n_out + 128LL * nph - 1) / (128LL * nph)) * groups >= 160;
+  const int rw = big ? 128 : 64;
+  const int64_t tiles = (n_out + (int64_t)rw * nph - 1) / ((int64_t)rw * nph);
   const dim3 grid((unsigned)tiles, (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
-#define PV2_LAUNCH_OSL(NB, TOUT)                                                                   \
-  hipLaunchKernelGGL((spconv_osl_kernel<NB, TOUT>), grid, dim3(256), 0, s, in_feat, c_in, weight,  \
-                     K, c_out, pair_in, pair_out, seg, n_tiles64, kflip, bias, n_out, out_feat)
+#define PV2_LAUNCH_OSL2(NB, RW)                                                                     \
+  hipLaunchKernelGGL((spconv_osl2_kernel<NB, RW>), grid, dim3(256), 0, s, in_feat, c_in, weight, K, \
+                     c_out, pair_in, pair_out, seg, n_tiles64, kflip, bias, n_out, out_feat)
   if (big) {
-    switch (nb) {
-      case 1: PV2_LAUNCH_OSL(1, 128); break;
-      case 2: PV2_LAUNCH_OSL(2, 128); break;
-      case 3: PV2_LAUNCH_OSL(3, 128); break;
-      default: PV2_LAUNCH_OSL(4, 128); break;
-    }
+    if (nb == 1) PV2_LAUNCH_OSL2(1, 128);
+    else if (nb == 2) PV2_LAUNCH_OSL2(2, 128);
+    else PV2_LAUNCH_OSL2(4, 128);
   } else {
-    switch (nb) {
-      case 1: PV2_LAUNCH_OSL(1, 64); break;
-      case 2: PV2_LAUNCH_OSL(2, 64); break;
-      case 3: PV2_LAUNCH_OSL(3, 64); break;
-      default: PV2_LAUNCH_OSL(4, 64); break;
-    }
+    if (nb == 1) PV2_LAUNCH_OSL2(1, 64);
+    else if (nb == 2) PV2_LAUNCH_OSL2(2, 64);
+    else PV2_LAUNCH_OSL2(4, 64);
   }
-#undef PV2_LAUNCH_OSL
+#undef PV2_LAUNCH_OSL2
   return pv2::check_launch("spconv_osl_forward");
 }
 

@@ -28,11 +28,12 @@ _OS_ENV = os.environ.get("PV2_SPCONV_OS", "auto")
 USE_OS = True if _OS_ENV == "1" else False if _OS_ENV == "0" else "auto"
 
 
-# The LDS-accumulator output-stationary kernel (pv2_spconv_osl_forward) for submanifold convs is
-# EXPERIMENTAL and off: it removes the atomics (compacted pair chunks, one store per element) but
-# its per-offset chain of dependent loads (segment -> pair -> row -> MFMA) is not yet pipelined and
-# it measures 3-7x SLOWER than the scatter-add kernel (profiles/r02_spconv_os_ab_v2.txt).
-# PV2_SPCONV_OSL=1 switches it on for A/B runs.
+# The LDS-tile output-stationary kernel (pv2_spconv_osl_forward) for submanifold convs is
+# EXPERIMENTAL and off: no atomics (compacted 16-row pair chunks at full MFMA row efficiency, a
+# three-stage software pipeline, one store per element), bitwise reproducible, but with one fat
+# workgroup per ~128 output rows the machine holds too few waves to hide the gather latency and it
+# measures 2.6-4x SLOWER than the scatter-add kernel, whose 1500 small workgroups oversubscribe the
+# CUs (profiles/r02_spconv_os_ab_v3.txt).  PV2_SPCONV_OSL=1 switches it on for A/B runs.
 USE_OSL = os.environ.get("PV2_SPCONV_OSL", "0") == "1"
 
 
