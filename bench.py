@@ -83,9 +83,9 @@ def parse():
     ap.add_argument("--amp", default=None, choices=["bf16", "fp16"],
                     help="run the WHOLE model under torch.autocast, as the reference's shipped ScanNet "
                          "config does (enable_amp=True): a separate, labelled line - the fp32 run "
-                         "stays the headline / parity number.  The hand-written kernels keep fp32 "
-                         "arithmetic inside the region (inputs widened on entry); the dense UNet3D "
-                         "and the remaining torch ops run reduced")
+                         "stays the headline / parity number.  The model scopes the reduced "
+                         "precision to the dense UNet3D (library convolutions); the hand-written "
+                         "kernels keep fp32 arithmetic")
     ap.add_argument("--config", default=None,
                     help="config file to take the model / optimizer / scheduler sections from "
                          "(default: the repository's synthetic-data config of the workload; the "
@@ -532,8 +532,9 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": (f"{args.amp} autocast over the whole model (reference enable_amp=True): dense "
-                      "UNet3D + torch ops reduced, hand-written kernels f32" if args.amp else
+            "dtype": (f"{args.amp} autocast entered around the whole model (reference enable_amp=True); "
+                      "the model scopes it to the dense UNet3D, hand-written kernels and losses f32"
+                      if args.amp else
                       "f32" if args.dense_dtype == "float32" else
                       f"f32 sparse conv + render head; {args.dense_dtype} autocast for the dense "
                       "UNet3D convs (reference enable_amp=True)"),

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_cache", "db"))
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(ROOT, "miopen_cache", "cache"))
 import bench  # noqa: E402
 
 
@@ -22,8 +24,8 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     t0 = time.time()
-    torch.backends.cudnn.benchmark = True
-    model = build_model(ConfigDict(bench.model_cfg(256, os.environ.get("DENSE_DTYPE", "bfloat16")))).to(dev).train()
+    torch.backends.cudnn.benchmark = False
+    model = build_model(ConfigDict(bench.model_cfg(256, os.environ.get("DENSE_DTYPE", "float32")))).to(dev).train()
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True)
     batch = bench.make_batch(0, 2, 2, dev)
     print("setup %.1fs" % (time.time() - t0), flush=True)
@@ -44,8 +46,9 @@ def main():
         vol = model.prepare_volume(d)[0]
         mark("proj_net_fwd")
         ro = model.render_func(ray_dict, [vol])
-        loss, _ = model.render_loss(ro, ray_dict)
         mark("render_fwd")
+        loss, _ = model.render_loss(ro, ray_dict)
+        mark("losses_fwd")
         opt.zero_grad(set_to_none=True)
         loss.backward()
         mark("backward")
