@@ -48,7 +48,11 @@ const char* pv2_last_error(void);
  * the reference through spconv.SubMConv3d / SparseConv3d / SparseInverseConv3d at
  * ponder/models/sparse_unet/spconv_unet_v1m1_base.py:41,47,58,112,135,171.
  *
- * coords      int32 [n,4] rows (b,x,y,z), 0 <= b < 65536, 0 <= x,y,z < 65504.
+ * coords      int32 [n,4] rows (b,x,y,z), 0 <= b < 65536, 0 <= x,y,z < 65504.  Rows with b < 0 are
+ *             PADDING (a capacity-sized array whose valid count lives on the device, e.g. the
+ *             out_coords of pv2_downsample_unique past *n_out): they enter no hash, have no
+ *             neighbours and produce no output voxel - so a chain of levels can be built without
+ *             reading any count back to the host.
  * Kernel offset index k = ((ix*K)+iy)*K+iz over the K^3 window, spatial dims in the order they
  * appear in `coords` (first spatial dim slowest), matching a dense conv3d weight [.,kx,ky,kz,.].
  *

@@ -49,6 +49,7 @@ __global__ void hash_insert_kernel(const int4* __restrict__ coords, int64_t n,
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int4 c = coords[i];
+    if (c.x < 0) continue;  // padding row of a capacity-sized coordinate array
     uint64_t key = pack_key(c.x, c.y, c.z, c.w);
     uint64_t slot = mix64(key) & mask;
     for (;;) {
@@ -95,7 +96,9 @@ __global__ void subm_table_kernel(const int4* __restrict__ coords, int64_t n, in
     for (int dz = -r; dz <= r; ++dz, ++k) {
       const int z = c.w + dz;
       int32_t j = -1;
-      if (dx == 0 && dy == 0 && dz == 0) {
+      if (c.x < 0) {
+        // padding row: no neighbours, not even itself
+      } else if (dx == 0 && dy == 0 && dz == 0) {
         j = (int32_t)i;  // centre tap: the voxel itself (keeps duplicates self-consistent)
       } else if (x >= 0 && y >= 0 && z >= 0) {
         j = hash_lookup(keys, vals, mask, pack_key(c.x, x, y, z));
@@ -216,7 +219,7 @@ __global__ void down_keys_kernel(const int4* __restrict__ coords, int64_t n, int
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int4 c = coords[i];
     int x = c.y / s, y = c.z / s, z = c.w / s;
-    keys[i] = (x < ox && y < oy && z < oz) ? pack_key(c.x, x, y, z) : kEmptyKey;
+    keys[i] = (c.x >= 0 && x < ox && y < oy && z < oz) ? pack_key(c.x, x, y, z) : kEmptyKey;
   }
 }
 
@@ -258,7 +261,7 @@ __global__ void down_table_kernel(const int4* __restrict__ coords, int64_t n, in
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int4 c = coords[i];
     int x = c.y / s, y = c.z / s, z = c.w / s;
-    if (!(x < ox && y < oy && z < oz)) continue;
+    if (c.x < 0 || !(x < ox && y < oy && z < oz)) continue;
     uint64_t key = pack_key(c.x, x, y, z);
     int64_t lo = 0, hi = cnt;  // lower_bound
     while (lo < hi) {

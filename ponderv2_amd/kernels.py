@@ -203,10 +203,11 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if n > 0:
         # the neighbour table is its own transpose up to mirroring the offsets (coordinates are
         # unique): grad-input reads the same table with the weight offsets flipped
-        seg = torch.empty(K * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
-        _lib.check(L.pv2_spconv_osl_segments(_ptr(pair_out), _ptr(kstart), K, n, _ptr(seg),
-                                             _stream(coords)), "pv2_spconv_osl_segments")
-        rb.osl = (pair_in, pair_out, seg, 0)
+        if USE_OSL and K <= 27:
+            seg = torch.empty(K * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
+            _lib.check(L.pv2_spconv_osl_segments(_ptr(pair_out), _ptr(kstart), K, n, _ptr(seg),
+                                                 _stream(coords)), "pv2_spconv_osl_segments")
+            rb.osl = (pair_in, pair_out, seg, 0)
         # (the mask sort is only worth its launches when the submanifold convs run output-stationary)
         rb.nbr, rb.nbr_stride = nbr, n
         rb.perm = _mask_order(nbr, K, n, n) if USE_OS is True else None
@@ -260,6 +261,131 @@ def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List
         rb.nbr, rb.nbr_stride, rb.perm = tbl, n, _mask_order(tbl, K, n_out, n)
         rb._transposed_os = (parent, n, _mask_order(parent, K, n, n), 0)
     return rb, out_coords[:n_out]
+
+
+def prepare_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 4,
+                          stem_ksize: int = 5, stem_key: str = "stem") -> dict:
+    """Every rulebook a SpUNet forward needs, built in ONE pass with ONE device->host read.
+
+    The lazy builders above read a count back per rulebook (to size its pair arrays) and the
+    strided convs another one (the number of output voxels): ~14 blocking reads per forward, each
+    of which stalls the host until the GPU has drained.  Here the four strided levels are chained
+    on capacity-sized coordinate arrays (rows past the device-side count are padding with batch
+    index -1, which the kernels skip), every table is compacted into worst-case-sized pair arrays,
+    and all ``kstart`` prefixes and voxel counts come back in a single copy at the end.  Returns an
+    ``indice_dict`` for ``SparseConvTensor``: ``stem`` (k5) and ``subm0..n`` (k3) submanifold
+    entries, ``spconv1..n`` strided entries (with their output indices / shapes).  Identical
+    rulebooks, bit for bit, to the lazy builders (tests/test_gpu_kernels.py)."""
+    _require_device(indices)
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+    L = _lib.lib()
+    dev = indices.device
+    st = _stream(indices)
+    cap = indices.shape[0]
+    if cap == 0:
+        return {}
+    coords = [indices.contiguous()]
+    n_dev = [None]                      # device-side valid count of each level (None: all rows)
+    shapes = [[int(v) for v in spatial_shape]]
+    downs, readback = [], []
+
+    def compact(tbl, K, n_rows_dev, out_cap):
+        nchunks = max(1, (cap + SCAN_CHUNK - 1) // SCAN_CHUNK)
+        block_sums = torch.empty(K * nchunks, dtype=torch.int32, device=dev)
+        kstart = torch.empty(K + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_table_count(_ptr(tbl), K, cap, _ptr(n_rows_dev), _ptr(block_sums),
+                                     _ptr(kstart), st), "pv2_table_count")
+        other = torch.empty(out_cap, dtype=torch.int32, device=dev)
+        row = torch.empty(out_cap, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_table_compact(_ptr(tbl), K, cap, _ptr(n_rows_dev), _ptr(block_sums),
+                                       _ptr(other), _ptr(row), st), "pv2_table_compact")
+        readback.append(kstart)
+        return other, row, kstart
+
+    def order(tbl, K, n_cols_dev):
+        mask = torch.empty(cap, dtype=torch.int64, device=dev)
+        _lib.check(L.pv2_table_masks(_ptr(tbl), K, cap, cap, _ptr(n_cols_dev), _ptr(mask), st),
+                   "pv2_table_masks")
+        return torch.argsort(mask, stable=True).to(torch.int32)
+
+    ws_bytes = int(L.pv2_downsample_workspace_bytes(cap))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    for l in range(1, n_levels + 1):
+        out_shape = [(s - 2) // 2 + 1 for s in shapes[-1]]
+        shape_c = (ctypes.c_int32 * 3)(*out_shape)
+        keys_a = torch.empty(cap, dtype=torch.int64, device=dev)
+        keys_b = torch.empty(cap, dtype=torch.int64, device=dev)
+        out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_downsample_unique(_ptr(coords[-1]), cap, 2, shape_c, _ptr(keys_a),
+                                           _ptr(keys_b), _ptr(out_coords), _ptr(n_out_dev), _ptr(ws),
+                                           ws_bytes, st), "pv2_downsample_unique")
+        tbl = torch.empty(8 * cap, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_downsample_table(_ptr(coords[-1]), cap, 2, shape_c, _ptr(keys_b),
+                                          _ptr(n_out_dev), _ptr(tbl), cap, st), "pv2_downsample_table")
+        pair_in, pair_out, kstart = compact(tbl, 8, n_out_dev, cap)
+        parent = torch.empty(8 * cap, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_table_invert(_ptr(tbl), 8, cap, cap, _ptr(n_out_dev), _ptr(parent), cap, st),
+                   "pv2_table_invert")
+        downs.append(dict(pair_in=pair_in, pair_out=pair_out, kstart=kstart, tbl=tbl, parent=parent,
+                          perm=order(tbl, 8, n_out_dev), perm_t=order(parent, 8, n_dev[-1]),
+                          out_shape=out_shape))
+        coords.append(out_coords)
+        n_dev.append(n_out_dev)
+        shapes.append(out_shape)
+    subms = []
+    tsize = 1 << max(4, int(2 * cap - 1).bit_length())
+    for level in range(n_levels + 1):
+        keys = torch.empty(tsize, dtype=torch.int64, device=dev)
+        vals = torch.empty(tsize, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_hash_build(_ptr(coords[level]), cap, _ptr(keys), _ptr(vals), tsize, st),
+                   "pv2_hash_build")
+        for ksize, key in ([(stem_ksize, stem_key)] if level == 0 else []) + [(3, f"subm{level}")]:
+            K = ksize ** 3
+            nbr = torch.empty(K * cap, dtype=torch.int32, device=dev)
+            _lib.check(L.pv2_subm_neighbor_table(_ptr(coords[level]), cap, ksize, _ptr(keys),
+                                                 _ptr(vals), tsize, _ptr(nbr), st),
+                       "pv2_subm_neighbor_table")
+            # a voxel pairs with at most its K window cells, and only valid rows pair at all; the
+            # level-0 count is exact, coarser levels are bounded by the level above
+            pair_in, pair_out, kstart = compact(nbr, K, None, K * cap if level == 0 else 27 * cap)
+            subms.append(dict(key=key, ksize=ksize, level=level, K=K, nbr=nbr, pair_in=pair_in,
+                              pair_out=pair_out, kstart=kstart,
+                              perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None))
+    # ---- the one device->host read
+    host = torch.cat([t.reshape(-1) for t in readback + n_dev[1:]]).cpu().numpy().astype(np.int64)
+    pos = 0
+    hosts = []
+    for t in readback:
+        hosts.append(host[pos:pos + t.numel()])
+        pos += t.numel()
+    n_lvl = [cap] + [int(v) for v in host[pos:pos + n_levels]]
+    out = {}
+    for l, d in enumerate(downs, start=1):
+        kh = hosts[l - 1]
+        P = int(kh[-1])
+        rb = Rulebook(8, n_lvl[l - 1], n_lvl[l], d["pair_in"][:P], d["pair_out"][:P], d["kstart"], kh)
+        if n_lvl[l] > 0:
+            rb.nbr, rb.nbr_stride, rb.perm = d["tbl"], cap, d["perm"]
+            rb._transposed_os = (d["parent"], cap, d["perm_t"], 0)
+        out[f"spconv{l}"] = dict(kind="down", ksize=2, rulebook=rb, in_indices=coords[l - 1][:n_lvl[l - 1]],
+                                 in_spatial_shape=shapes[l - 1], out_indices=coords[l][:n_lvl[l]],
+                                 out_shape=d["out_shape"], prebuilt=True)
+    for d, kh in zip(subms, hosts[n_levels:]):
+        n = n_lvl[d["level"]]
+        P = int(kh[-1])
+        rb = Rulebook(d["K"], n, n, d["pair_in"][:P], d["pair_out"][:P], d["kstart"], kh,
+                      center_k=d["K"] // 2)
+        if n > 0:
+            rb.nbr, rb.nbr_stride, rb.perm = d["nbr"], cap, d["perm"]
+            rb._transposed_os = (d["nbr"], cap, d["perm"], 1)
+            if USE_OSL and d["K"] <= 27:
+                seg = torch.empty(d["K"] * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
+                _lib.check(L.pv2_spconv_osl_segments(_ptr(rb.pair_out), _ptr(rb.kstart), d["K"], n,
+                                                     _ptr(seg), st), "pv2_spconv_osl_segments")
+                rb.osl = (rb.pair_in, rb.pair_out, seg, 0)
+        out[d["key"]] = dict(kind="subm", ksize=d["ksize"], n=n, rulebook=rb)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

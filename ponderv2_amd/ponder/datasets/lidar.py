@@ -254,6 +254,8 @@ def lidar_collate_fn(samples):
                 offset=torch.tensor(n_pts, dtype=torch.int64), offset_host=[int(v) for v in n_pts],
                 ray_offset=torch.tensor(n_ray, dtype=torch.int64),
                 ray_offset_host=[int(v) for v in n_ray],
+                sparse_shape=[int(v) + 96 for v in
+                              np.max([s["grid_coord"].max(0) for s in samples], axis=0)],
                 condition=[s["condition"] for s in samples])
 
 

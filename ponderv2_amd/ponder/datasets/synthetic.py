@@ -159,7 +159,12 @@ def collate_fn(samples):
     stack = lambda k: torch.from_numpy(np.stack([s[k] for s in samples]))  # noqa: E731
     counts = [len(s["coord"]) for s in samples]
     feat = np.concatenate([np.concatenate([s["color"] / 127.5 - 1, s["normal"]], 1) for s in samples])
-    grid = dict(grid_coord=cat("grid_coord", np.int64)) if "grid_coord" in samples[0] else {}
+    grid = {}
+    if "grid_coord" in samples[0]:
+        # sparse_shape = max grid coordinate + 96 (spconv_unet_v1m1_base.py:248), computed here on
+        # the host so the backbone does not read it back from the device
+        top = np.max([s["grid_coord"].max(0) for s in samples], axis=0)
+        grid = dict(grid_coord=cat("grid_coord", np.int64), sparse_shape=[int(v) + 96 for v in top])
     return dict(coord=cat("coord", np.float32), **grid,
                 feat=torch.from_numpy(feat.astype(np.float32)), segment=cat("segment", np.int64),
                 offset=torch.tensor(np.cumsum(counts), dtype=torch.int64),

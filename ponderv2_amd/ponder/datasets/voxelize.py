@@ -154,6 +154,7 @@ def device_grid_sample(batch, grid_size=0.02, hash_type="fnv", keys=("coord", "f
         new_ends.append((new_ends[-1] if new_ends else 0) + int(idx.numel()))
         start = end
     res = dict(batch)
+    res.pop("sparse_shape", None)   # the voxel set changed: the backbone derives it again
     for k, parts in out.items():
         res[k] = torch.cat(parts)
     res["grid_coord"] = torch.cat(grids)

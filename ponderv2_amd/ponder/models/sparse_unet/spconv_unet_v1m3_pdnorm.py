@@ -256,6 +256,15 @@ class SpUNetBase(nn.Module):
                 nn.init.constant_(m.modulation[-1].weight, 0)
                 nn.init.constant_(m.modulation[-1].bias, 0)
 
+    def _geometry(self, feat, batch, grid_coord, sparse_shape):
+        """All ten rulebooks with ONE device->host read (kernels.prepare_unet_geometry)."""
+        if not feat.is_cuda or getattr(self, "cls_mode", False):
+            return None
+        from ponderv2_amd import kernels as K
+
+        indices = torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous()
+        return K.prepare_unet_geometry(indices, sparse_shape, n_levels=self.num_stages)
+
     def forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
         condition = input_dict["condition"][0]
@@ -267,7 +276,8 @@ class SpUNetBase(nn.Module):
         x = spconv.SparseConvTensor(
             features=feat,
             indices=torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous(),
-            spatial_shape=sparse_shape, batch_size=offset.numel())
+            spatial_shape=sparse_shape, batch_size=offset.numel(),
+            indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape))
         x = self.conv_input([x, condition, context])
         skips = [x]
         for s in range(self.num_stages):

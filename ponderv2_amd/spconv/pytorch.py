@@ -120,11 +120,19 @@ class SparseConv3d(_SparseConvBase):
             raise NotImplementedError(
                 "SparseConv3d: only kernel_size == stride, padding == 0 (the SpUNet down-conv)")
         out_shape = [(s - ks) // st + 1 for s in x.spatial_shape]
-        rb, out_indices = K.build_downsample_rulebook(x.indices, st, out_shape)
-        if self.indice_key is not None:
-            x.indice_dict[self.indice_key] = dict(
-                kind="down", ksize=ks, rulebook=rb, in_indices=x.indices,
-                in_spatial_shape=x.spatial_shape)
+        entry = x.indice_dict.get(self.indice_key) if self.indice_key is not None else None
+        if (entry is not None and entry.get("prebuilt") and entry["kind"] == "down"
+                and entry["ksize"] == ks and entry["rulebook"].n_in == x.indices.shape[0]
+                and entry["out_shape"] == out_shape):
+            # built ahead by kernels.prepare_unet_geometry (one host read for the whole U-Net)
+            rb, out_indices = entry["rulebook"], entry["out_indices"]
+            entry["in_indices"] = x.indices
+        else:
+            rb, out_indices = K.build_downsample_rulebook(x.indices, st, out_shape)
+            if self.indice_key is not None:
+                x.indice_dict[self.indice_key] = dict(
+                    kind="down", ksize=ks, rulebook=rb, in_indices=x.indices,
+                    in_spatial_shape=x.spatial_shape)
         return SparseConvTensor(self._apply_conv(x.features, rb), out_indices, out_shape,
                                 x.batch_size, x.indice_dict)
 

@@ -525,6 +525,7 @@ def test_lds_tile_output_stationary_conv(device, c_in, c_out, n_per, monkeypatch
     torch.manual_seed(c_in + 3 * c_out)
     coords = random_voxels(12, batch=2, n_per_batch=n_per)
     n = len(coords)
+    monkeypatch.setattr(K, "USE_OSL", True)   # (the segment table is built with the rulebook)
     rb = K.build_subm_rulebook(torch.from_numpy(coords).to(device), 3)
     assert rb.osl is not None
     x = torch.randn(n, c_in, device=device)
@@ -593,3 +594,43 @@ def test_spunet_forward_is_bitwise_reproducible(device, monkeypatch):
                  offset=torch.from_numpy(np.cumsum(counts)).long().to(device))
     outs = [model(dict(batch)).clone() for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("seed,batch,n", [(0, 2, 1500), (21, 1, 6000), (22, 3, 50)])
+def test_one_read_geometry_prepass_equals_the_lazy_builders(device, seed, batch, n):
+    """kernels.prepare_unet_geometry (all ten rulebooks of the U-Net chained on capacity-sized,
+    padded arrays, one device->host read) produces exactly the rulebooks, output voxels and gather
+    tables of the per-rulebook builders."""
+    from ponderv2_amd import kernels as K
+
+    coords = torch.from_numpy(random_voxels(seed, batch=batch, n_per_batch=n)).to(device)
+    shape = [40 + 96, 36 + 96, 20 + 96]
+    geo = K.prepare_unet_geometry(coords, shape, n_levels=4)
+    assert set(geo) == {"stem", "subm0", "subm1", "subm2", "subm3", "subm4",
+                        "spconv1", "spconv2", "spconv3", "spconv4"}
+    level, lshape = coords, shape
+    for l in range(5):
+        for key, ks in ([("stem", 5)] if l == 0 else []) + [(f"subm{l}", 3)]:
+            ref, got = K.build_subm_rulebook(level, ks), geo[key]["rulebook"]
+            assert geo[key]["n"] == len(level) and got.n_pairs == ref.n_pairs
+            assert np.array_equal(got.kstart_host, ref.kstart_host)
+            assert torch.equal(got.pair_in, ref.pair_in) and torch.equal(got.pair_out, ref.pair_out)
+            assert torch.equal(got.kstart, ref.kstart)
+            tbl = got.nbr.reshape(got.K, got.nbr_stride)[:, :len(level)]
+            assert torch.equal(tbl, ref.nbr.reshape(ref.K, ref.nbr_stride))
+        if l == 4:
+            break
+        lshape = [(s - 2) // 2 + 1 for s in lshape]
+        ref, oc = K.build_downsample_rulebook(level, 2, lshape)
+        e = geo[f"spconv{l + 1}"]
+        got = e["rulebook"]
+        assert e["out_shape"] == lshape and torch.equal(e["out_indices"], oc)
+        assert (got.n_in, got.n_out, got.n_pairs) == (ref.n_in, ref.n_out, ref.n_pairs)
+        assert torch.equal(got.pair_in, ref.pair_in) and torch.equal(got.pair_out, ref.pair_out)
+        x = torch.randn(got.n_in, 32, device=device)
+        w = torch.randn(48, 8, 32, device=device) * 0.1
+        y, y_ref = K.spconv_forward(x, w, got), K.spconv_forward(x, w, ref)
+        assert torch.equal(y, y_ref)            # same table, same row order -> same bits
+        g = torch.randn(got.n_out, 48, device=device)
+        assert torch.equal(K.spconv_grad_input(g, w, got), K.spconv_grad_input(g, w, ref))
+        level = oc
