@@ -32,6 +32,11 @@ typedef void* pv2_stream_t; /* hipStream_t */
 #define PV2_E_UNSUPPORTED (-2)
 #define PV2_E_WORKSPACE (-3)
 
+/* element type codes of the entry points that take 16-bit feature matrices (void* arguments) */
+#define PV2_F32 0
+#define PV2_BF16 1
+#define PV2_F16 2
+
 int pv2_abi_version(void);
 /* Zero `nbytes` (multiple of 4) with a KERNEL on `stream`.  Scratch and accumulate-into buffers of
  * this library are cleared with a kernel rather than hipMemsetAsync: on ROCm 7.2 a hipMemsetAsync
@@ -40,6 +45,7 @@ int pv2_abi_version(void);
 int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream);
 /* Debug only: kernel ablation flags used by tools/bench_spconv_kernels.py (0 = production). */
 int pv2_debug_set_ablate(int flags);
+int pv2_debug_set_os16_variant(int v); /* tuning knob of pv2_spconv16_os_forward (tools/bench_spconv16.py) */
 const char* pv2_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -213,6 +219,38 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
                 pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same sparse convolutions on 16-bit features (bf16 / fp16 storage, fp32 accumulation on
+ * v_mfma_f32_32x32x16_{bf16,f16}): what spconv runs under the reference's shipped training mode
+ * (enable_amp = True, configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:12; the autocast region
+ * of ponder/engines/train.py:183-196).  Same call sites as above.
+ *   pv2_spconv16_pack_weights: the fp32 master weight [c_out, K, c_in] -> two 16-bit copies in
+ *       MFMA-fragment order (once per optimiser step): packed_fwd for the forward pass
+ *       (pv2_spconv16_packed_elems(c_out, K, c_in) elements) and packed_bwd, the transposed
+ *       operand of the grad-input pass (pv2_spconv16_packed_elems(c_in, K, c_out) elements).
+ *   pv2_spconv16_os_forward: the output-stationary conv of pv2_spconv_os_forward (gather table,
+ *       perm, kflip and bias as there; no atomics, every element written once, bitwise
+ *       reproducible) on 16-bit in_feat [n_in, c_in] -> out_feat [n_out, c_out] with a PACKED
+ *       weight.  Grad-input = the same call on grad_out with packed_bwd, channel counts swapped
+ *       and the transposed gather table.  c_in % 8 == 0, c_out % 8 == 0.
+ *   pv2_spconv16_backward_weight: dweight (fp32 [c_out, K, c_in], ZERO-initialised by the caller)
+ *       += the pair-major reduction over 16-bit in_feat / grad_out; tile_start / n_tiles count
+ *       chunks of tile_pairs pairs (a multiple of 64, at most 512: PV2_WGRAD_TILE).
+ * dtype: PV2_BF16 or PV2_F16.
+ * ------------------------------------------------------------------------------------------ */
+int64_t pv2_spconv16_packed_elems(int rows, int K, int reduction);
+int pv2_spconv16_pack_weights(const float* weight, int c_out, int K, int c_in, int dtype,
+                              void* packed_fwd, void* packed_bwd, pv2_stream_t stream);
+int pv2_spconv16_os_forward(const void* in_feat, int64_t n_in, int c_in, const void* packed_weight,
+                            int K, int c_out, int dtype, const int32_t* nbr, int64_t nbr_stride,
+                            const int32_t* perm, int kflip, const float* bias, void* out_feat,
+                            int64_t n_out, pv2_stream_t stream);
+int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, const void* grad_out,
+                                 int64_t n_out, int c_out, int dtype, int K, const int32_t* pair_in,
+                                 const int32_t* pair_out, const int32_t* kstart,
+                                 const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                                 float* grad_weight, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d over the active-voxel feature matrix x[n, c], fused with the optional
  * residual add and ReLU that follow it in SpUNet's blocks; and a column sum.
  * Replaces the ATen batch_norm / add / relu kernels behind BasicBlock.forward
@@ -238,6 +276,19 @@ int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     const float* mean_invstd, const float* weight, int64_t n, int c,
                     float* workspace, float* gsum, float* dx, float* dresidual_or_null,
                     pv2_stream_t stream);
+/* The same two operations on mixed element types (the reduced-precision training mode,
+ * configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:12 enable_amp): x / dx are `x_dtype`,
+ * y / residual / dy / dresidual are `y_dtype`; statistics, parameters and their gradients stay
+ * fp32.  Supported (x, y) pairs: (F32, F32), (F32, BF16), (F32, F16), (BF16, BF16), (F16, F16). */
+int pv2_bn_forward_mixed(const void* x, int x_dtype, int64_t n, int c, const float* weight,
+                         const float* bias, const void* residual, int relu, float eps,
+                         float momentum, float* running_mean, float* running_var,
+                         float* workspace, float* mean_invstd, void* y, int y_dtype,
+                         pv2_stream_t stream);
+int pv2_bn_backward_mixed(const void* dy, const void* x, int x_dtype, const void* y_or_null,
+                          int y_dtype, const float* mean_invstd, const float* weight, int64_t n,
+                          int c, float* workspace, float* gsum, void* dx,
+                          void* dresidual_or_null, pv2_stream_t stream);
 /* out[c] = sum_r x[r, c] */
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
 

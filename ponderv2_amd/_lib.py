@@ -27,12 +27,13 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
     "pv2_last_error": (c_char_p, []),
     "pv2_debug_set_ablate": (c_int, [c_int]),
+    "pv2_debug_set_os16_variant": (c_int, [c_int]),
     "pv2_zero_fill": (c_int, [_P, c_int64, _P]),
     "pv2_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
     "pv2_subm_neighbor_table": (c_int, [_P, c_int64, c_int, _P, _P, c_int64, _P, _P]),
@@ -57,6 +58,14 @@ SIGNATURES = {
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P]),
     "pv2_spconv_forward_wt": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, c_int64, _P]),
+    "pv2_spconv16_packed_elems": (c_int64, [c_int, c_int, c_int]),
+    "pv2_spconv16_pack_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "pv2_spconv16_os_forward": (
+        c_int, [_P, c_int64, c_int, _P, c_int, c_int, c_int, _P, c_int64, _P, c_int, _P, _P, c_int64,
+                _P]),
+    "pv2_spconv16_backward_weight": (
+        c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int64,
+                _P, _P]),
     "pv2_spconv_wgrad_tile": (c_int, [c_int, c_int, c_int64, c_int]),
     "pv2_spconv_backward_weight": (
         c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,
@@ -64,6 +73,10 @@ SIGNATURES = {
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_bn_workspace_floats": (c_int64, [c_int]),
+    "pv2_bn_forward_mixed": (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, c_int, c_float, c_float, _P,
+                                     _P, _P, _P, _P, c_int, _P]),
+    "pv2_bn_backward_mixed": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int64, c_int, _P, _P, _P, _P,
+                                      _P]),
     "pv2_bn_forward": (c_int, [_P, c_int64, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P,
                                _P, _P, _P]),
     "pv2_bn_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),

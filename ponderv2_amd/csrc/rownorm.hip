@@ -21,6 +21,29 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Element types of the feature matrices: fp32, or the 16-bit storage of the reduced-precision
+// training mode (statistics and arithmetic stay fp32; only loads and stores change).
+struct F32 { using type = float; };
+struct B16 { using type = unsigned short; };  // bfloat16
+struct H16 { using type = unsigned short; };  // IEEE half
+
+template <typename E> __device__ __forceinline__ float ld(const typename E::type* p, int64_t i);
+template <> __device__ __forceinline__ float ld<F32>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld<B16>(const unsigned short* p, int64_t i) {
+  return __uint_as_float((uint32_t)p[i] << 16);
+}
+template <> __device__ __forceinline__ float ld<H16>(const unsigned short* p, int64_t i) {
+  return (float)__builtin_bit_cast(_Float16, p[i]);
+}
+template <typename E> __device__ __forceinline__ void st(typename E::type* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st<F32>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st<B16>(unsigned short* p, int64_t i, float v) {
+  p[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+template <> __device__ __forceinline__ void st<H16>(unsigned short* p, int64_t i, float v) {
+  p[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+
 // Statistics in two steps without atomics (bitwise reproducible, nothing to clear):
 //   1. col_partials_kernel: block b reduces its run of rows and writes partial[b][0..2C);
 //   2. col_combine_kernel: one block per 32 channels adds the partial rows in a FIXED order (double
@@ -33,10 +56,11 @@ constexpr int kThreads = 256;
 constexpr int kMaxPartialBlocks = 1024;
 constexpr int kMaxChannels = 1024;
 
-template <int MODE>
+// EA: element type of `a` (the input x in MODE 0, dy in MODE 1); EX / EY: of x and y in MODE 1.
+template <int MODE, typename EA, typename EX, typename EY>
 __global__ __launch_bounds__(kThreads) void col_partials_kernel(
-    const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
-    const float* __restrict__ mean_invstd, int64_t n, int c, int64_t rows_per_block,
+    const typename EA::type* __restrict__ a, const typename EX::type* __restrict__ x,
+    const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd, int64_t n, int c, int64_t rows_per_block,
     float* __restrict__ partial) {
   __shared__ float s0[kThreads];
   __shared__ float s1[kThreads];
@@ -55,19 +79,19 @@ __global__ __launch_bounds__(kThreads) void col_partials_kernel(
         mu = mean_invstd[cb + cc];
         is = mean_invstd[c + cb + cc];
       } else {
-        mu = a[cb + cc];  // the shift: row 0 of this column
+        mu = ld<EA>(a, cb + cc);  // the shift: row 0 of this column
       }
       for (int64_t r = r0 + rr; r < r1; r += rpi) {
         const int64_t idx = r * c + cb + cc;
         if (MODE == 0) {
-          const float v = a[idx] - mu;
+          const float v = ld<EA>(a, idx) - mu;
           acc0 += v;
           acc1 += v * v;
         } else {
-          float g = a[idx];
-          if (y != nullptr && !(y[idx] > 0.f)) g = 0.f;
+          float g = ld<EA>(a, idx);
+          if (y != nullptr && !(ld<EY>(y, idx) > 0.f)) g = 0.f;
           acc0 += g;
-          acc1 += g * (x[idx] - mu) * is;
+          acc1 += g * (ld<EX>(x, idx) - mu) * is;
         }
       }
     }
@@ -92,9 +116,9 @@ __global__ __launch_bounds__(kThreads) void col_partials_kernel(
 // turns the totals into the layer's statistics.
 //   MODE 0: out[0..C) = mean, out[C..2C) = invstd (biased variance); running statistics updated
 //   MODE 1: out[0..C) = sum g (= dbias), out[C..2C) = sum g*xhat (= dweight)
-template <int MODE>
+template <int MODE, typename EX>
 __global__ __launch_bounds__(kThreads) void col_combine_kernel(
-    const float* __restrict__ partial, int nb, int c, const float* __restrict__ x0, int64_t n,
+    const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0, int64_t n,
     float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ out) {
   __shared__ double r0[kThreads];
@@ -121,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void col_combine_kernel(
   if (MODE == 0) {
     const double inv_n = 1.0 / (double)n;
     const double d = t0 * inv_n;                 // mean - shift
-    const double mean = (double)x0[ch] + d;
+    const double mean = (double)ld<EX>(x0, ch) + d;
     double var = t1 * inv_n - d * d;
     if (var < 0.0) var = 0.0;
     out[ch] = (float)mean;
@@ -138,39 +162,41 @@ __global__ __launch_bounds__(kThreads) void col_combine_kernel(
 }
 
 // y = [relu]( (x - mean) * invstd * w + b [+ residual] )
+template <typename EX, typename EY>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(
-    const float* __restrict__ x, int64_t total, int c, const float* __restrict__ mean_invstd,
-    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ residual,
-    int relu, float* __restrict__ y) {
+    const typename EX::type* __restrict__ x, int64_t total, int c,
+    const float* __restrict__ mean_invstd, const float* __restrict__ w, const float* __restrict__ b,
+    const typename EY::type* __restrict__ residual, int relu, typename EY::type* __restrict__ y) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int ch = (int)(i % c);
-    float v = (x[i] - mean_invstd[ch]) * mean_invstd[c + ch];
+    float v = (ld<EX>(x, i) - mean_invstd[ch]) * mean_invstd[c + ch];
     v = v * (w ? w[ch] : 1.f) + (b ? b[ch] : 0.f);
-    if (residual) v += residual[i];
+    if (residual) v += ld<EY>(residual, i);
     if (relu && !(v > 0.f)) v = 0.f;
-    y[i] = v;
+    st<EY>(y, i, v);
   }
 }
 
 // g = dy * mask;  dx = w * invstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g
+template <typename EX, typename EY>
 __global__ __launch_bounds__(kThreads) void bn_backward_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-    const float* __restrict__ mean_invstd, const float* __restrict__ w,
-    const float* __restrict__ gsum, int64_t n, int c, float* __restrict__ dx,
-    float* __restrict__ dres) {
+    const typename EY::type* __restrict__ dy, const typename EX::type* __restrict__ x,
+    const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd,
+    const float* __restrict__ w, const float* __restrict__ gsum, int64_t n, int c,
+    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres) {
   const int64_t total = n * c;
   const float inv_n = 1.0f / (float)n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int ch = (int)(i % c);
-    float g = dy[i];
-    if (y != nullptr && !(y[i] > 0.f)) g = 0.f;
+    float g = ld<EY>(dy, i);
+    if (y != nullptr && !(ld<EY>(y, i) > 0.f)) g = 0.f;
     const float is = mean_invstd[c + ch];
-    const float xh = (x[i] - mean_invstd[ch]) * is;
+    const float xh = (ld<EX>(x, i) - mean_invstd[ch]) * is;
     const float mg = gsum[ch] * inv_n, mgx = gsum[c + ch] * inv_n;
-    dx[i] = (w ? w[ch] : 1.f) * is * (g - mg - xh * mgx);
-    if (dres) dres[i] = g;
+    st<EX>(dx, i, (w ? w[ch] : 1.f) * is * (g - mg - xh * mgx));
+    if (dres) st<EY>(dres, i, g);
   }
 }
 
@@ -239,43 +265,105 @@ extern "C" {
 
 int64_t pv2_bn_workspace_floats(int c) { return (int64_t)kMaxPartialBlocks * 2 * c; }
 
+}  // extern "C"
+
+namespace {
+
+template <typename EX, typename EY>
+int bn_forward_t(const void* x, int64_t n, int c, const float* weight, const float* bias,
+                 const void* residual, int relu, float eps, float momentum, float* running_mean,
+                 float* running_var, float* workspace, float* mean_invstd, void* y, hipStream_t s) {
+  using TX = typename EX::type;
+  using TY = typename EY::type;
+  int blocks;
+  int64_t rpb;
+  partial_geometry(n, c, &blocks, &rpb);
+  hipLaunchKernelGGL((col_partials_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                     (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
+                     workspace);
+  hipLaunchKernelGGL((col_combine_kernel<0, EX>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+                     workspace, blocks, c, (const TX*)x, n, eps, momentum, running_mean, running_var,
+                     mean_invstd);
+  hipLaunchKernelGGL((bn_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
+                     dim3(kThreads), 0, s, (const TX*)x, n * c, c, mean_invstd, weight, bias,
+                     (const TY*)residual, relu, (TY*)y);
+  return pv2::check_launch("bn_forward");
+}
+
+template <typename EX, typename EY>
+int bn_backward_t(const void* dy, const void* x, const void* y_or_null, const float* mean_invstd,
+                  const float* weight, int64_t n, int c, float* workspace, float* gsum, void* dx,
+                  void* dres, hipStream_t s) {
+  using TX = typename EX::type;
+  using TY = typename EY::type;
+  int blocks;
+  int64_t rpb;
+  partial_geometry(n, c, &blocks, &rpb);
+  hipLaunchKernelGGL((col_partials_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                     (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
+                     workspace);
+  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+                     workspace, blocks, c, (const float*)nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
+  hipLaunchKernelGGL((bn_backward_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
+                     dim3(kThreads), 0, s, (const TY*)dy, (const TX*)x, (const TY*)y_or_null,
+                     mean_invstd, weight, gsum, n, c, (TX*)dx, (TY*)dres);
+  return pv2::check_launch("bn_backward");
+}
+
+}  // namespace
+
+extern "C" {
+
+// (x dtype, y dtype) pairs the sparse backbone produces: all-fp32; 16-bit throughout; and the
+// fp32 -> 16-bit boundary after the stem conv (whose 6-channel input stays fp32).
+#define PV2_BN_DISPATCH(FN, ...)                                                        \
+  do {                                                                                  \
+    if (x_dtype == PV2_F32 && y_dtype == PV2_F32) return FN<F32, F32>(__VA_ARGS__);     \
+    if (x_dtype == PV2_F32 && y_dtype == PV2_BF16) return FN<F32, B16>(__VA_ARGS__);    \
+    if (x_dtype == PV2_F32 && y_dtype == PV2_F16) return FN<F32, H16>(__VA_ARGS__);     \
+    if (x_dtype == PV2_BF16 && y_dtype == PV2_BF16) return FN<B16, B16>(__VA_ARGS__);   \
+    if (x_dtype == PV2_F16 && y_dtype == PV2_F16) return FN<H16, H16>(__VA_ARGS__);     \
+    pv2::set_error("pv2_bn: unsupported (x, y) dtype pair");                            \
+    return PV2_E_UNSUPPORTED;                                                           \
+  } while (0)
+
+int pv2_bn_forward_mixed(const void* x, int x_dtype, int64_t n, int c, const float* weight,
+                         const float* bias, const void* residual, int relu, float eps,
+                         float momentum, float* running_mean, float* running_var,
+                         float* workspace, float* mean_invstd, void* y, int y_dtype,
+                         pv2_stream_t stream) {
+  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_forward: empty input");
+  PV2_REQUIRE(c <= kMaxChannels, "pv2_bn_forward: at most 1024 channels");
+  hipStream_t s = (hipStream_t)stream;
+  PV2_BN_DISPATCH(bn_forward_t, x, n, c, weight, bias, residual, relu, eps, momentum, running_mean,
+                  running_var, workspace, mean_invstd, y, s);
+}
+
+int pv2_bn_backward_mixed(const void* dy, const void* x, int x_dtype, const void* y_or_null,
+                          int y_dtype, const float* mean_invstd, const float* weight, int64_t n,
+                          int c, float* workspace, float* gsum, void* dx,
+                          void* dresidual_or_null, pv2_stream_t stream) {
+  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_backward: empty input");
+  PV2_REQUIRE(c <= kMaxChannels, "pv2_bn_backward: at most 1024 channels");
+  hipStream_t s = (hipStream_t)stream;
+  PV2_BN_DISPATCH(bn_backward_t, dy, x, y_or_null, mean_invstd, weight, n, c, workspace, gsum, dx,
+                  dresidual_or_null, s);
+}
+
 int pv2_bn_forward(const float* x, int64_t n, int c, const float* weight, const float* bias,
                    const float* residual, int relu, float eps, float momentum,
                    float* running_mean, float* running_var, float* workspace,
                    float* mean_invstd, float* y, pv2_stream_t stream) {
-  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_forward: empty input");
-  PV2_REQUIRE(c <= kMaxChannels, "pv2_bn_forward: at most 1024 channels");
-  hipStream_t s = (hipStream_t)stream;
-  int blocks;
-  int64_t rpb;
-  partial_geometry(n, c, &blocks, &rpb);
-  hipLaunchKernelGGL((col_partials_kernel<0>), dim3(blocks), dim3(kThreads), 0, s, x, nullptr,
-                     nullptr, nullptr, n, c, rpb, workspace);
-  hipLaunchKernelGGL((col_combine_kernel<0>), dim3((c + 31) / 32), dim3(kThreads), 0, s, workspace,
-                     blocks, c, x, n, eps, momentum, running_mean, running_var, mean_invstd);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(pv2::grid_for(n * c, kThreads)), dim3(kThreads), 0, s,
-                     x, n * c, c, mean_invstd, weight, bias, residual, relu, y);
-  return pv2::check_launch("bn_forward");
+  return pv2_bn_forward_mixed(x, PV2_F32, n, c, weight, bias, residual, relu, eps, momentum,
+                              running_mean, running_var, workspace, mean_invstd, y, PV2_F32, stream);
 }
 
 int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     const float* mean_invstd, const float* weight, int64_t n, int c,
                     float* workspace, float* gsum, float* dx, float* dresidual_or_null,
                     pv2_stream_t stream) {
-  PV2_REQUIRE(n >= 1 && c >= 1, "pv2_bn_backward: empty input");
-  PV2_REQUIRE(c <= kMaxChannels, "pv2_bn_backward: at most 1024 channels");
-  hipStream_t s = (hipStream_t)stream;
-  int blocks;
-  int64_t rpb;
-  partial_geometry(n, c, &blocks, &rpb);
-  hipLaunchKernelGGL((col_partials_kernel<1>), dim3(blocks), dim3(kThreads), 0, s, dy, x, y_or_null,
-                     mean_invstd, n, c, rpb, workspace);
-  hipLaunchKernelGGL((col_combine_kernel<1>), dim3((c + 31) / 32), dim3(kThreads), 0, s, workspace,
-                     blocks, c, nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
-  hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(pv2::grid_for(n * c, kThreads)),
-                     dim3(kThreads), 0, s, dy, x, y_or_null, mean_invstd, weight, gsum, n, c, dx,
-                     dresidual_or_null);
-  return pv2::check_launch("bn_backward");
+  return pv2_bn_backward_mixed(dy, x, PV2_F32, y_or_null, PV2_F32, mean_invstd, weight, n, c,
+                               workspace, gsum, dx, dresidual_or_null, stream);
 }
 
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream) {

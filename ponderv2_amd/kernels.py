@@ -60,6 +60,11 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+# element type codes of the entry points that take 16-bit feature matrices (include/ponderv2_hip.h)
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+
 def zeros_by_kernel(shape, dtype, device):
     """torch.zeros, but cleared by a kernel launch on the current stream (see pv2_zero_fill)."""
     t = torch.empty(shape, dtype=dtype, device=device)
@@ -476,6 +481,98 @@ def spconv_grad_input(grad_out: torch.Tensor, weight_okc: torch.Tensor, rb: Rule
             rbt.n_out, _stream(grad_out)), "pv2_spconv_forward_wt")
         return out
     return spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(), rbt)
+
+
+# --------------------------------------------------------------------------------------------
+# 16-bit sparse conv (bf16 / fp16 features, fp32 master weights and accumulation)
+# --------------------------------------------------------------------------------------------
+def packed_weights(weight_okc: torch.Tensor, dtype: torch.dtype, cache: Optional[dict] = None):
+    """(forward, grad-input) copies of an fp32 master weight [c_out, K, c_in] in ``dtype`` and MFMA
+    fragment order (pv2_spconv16_pack_weights).  ``cache`` (a dict owned by the module that owns
+    the parameter) keeps them until the parameter changes - its version counter moves with every
+    in-place update - so they are packed once per optimiser step."""
+    stamp = (weight_okc._version, weight_okc.data_ptr(), tuple(weight_okc.shape), dtype)
+    if cache is not None and cache.get("stamp") == stamp:
+        return cache["fwd"], cache["bwd"]
+    L = _lib.lib()
+    w = weight_okc.detach().contiguous()
+    c_out, K, c_in = w.shape
+    fwd = torch.empty(int(L.pv2_spconv16_packed_elems(c_out, K, c_in)), dtype=dtype, device=w.device)
+    bwd = torch.empty(int(L.pv2_spconv16_packed_elems(c_in, K, c_out)), dtype=dtype, device=w.device)
+    _lib.check(L.pv2_spconv16_pack_weights(_ptr(w), c_out, K, c_in, DTYPE_CODE[dtype], _ptr(fwd),
+                                           _ptr(bwd), _stream(w)), "pv2_spconv16_pack_weights")
+    if cache is not None:
+        cache.update(stamp=stamp, fwd=fwd, bwd=bwd)
+    return fwd, bwd
+
+
+def spconv16_supported(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook) -> bool:
+    """The 16-bit kernels cover 16-bit device features with channel counts that are multiples of
+    8 on a rulebook that carries its gather tables (every rulebook the builders above make)."""
+    return (feats.is_cuda and feats.dtype in HALF_DTYPES and weight_okc.dtype == torch.float32
+            and weight_okc.shape[0] % 8 == 0 and weight_okc.shape[2] % 8 == 0
+            and rb.nbr is not None and rb._transposed_os is not None)
+
+
+def spconv16_forward(feats, packed, K, c_out, nbr, nbr_stride, perm, kflip, n_out,
+                     bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Output-stationary conv of 16-bit ``feats`` [n_in, c_in] with a packed weight."""
+    _require_device(feats, packed)
+    feats = feats.contiguous()
+    out = torch.empty((n_out, c_out), dtype=feats.dtype, device=feats.device)
+    _lib.check(_lib.lib().pv2_spconv16_os_forward(
+        _ptr(feats), feats.shape[0], feats.shape[1], _ptr(packed), K, c_out, DTYPE_CODE[feats.dtype],
+        _ptr(nbr), nbr_stride, _ptr(perm), kflip, _ptr(bias), _ptr(out), n_out, _stream(feats)),
+        "pv2_spconv16_os_forward")
+    return out
+
+
+def spconv16_backward_weight(feats, grad_out, rb: Rulebook, c_out: int) -> torch.Tensor:
+    """fp32 dW [c_out, K, c_in] from 16-bit features and output gradients."""
+    _require_device(feats, grad_out)
+    feats, grad_out = feats.contiguous(), grad_out.contiguous()
+    assert feats.dtype == grad_out.dtype and feats.dtype in HALF_DTYPES
+    c_in = feats.shape[1]
+    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
+    tile_start, n_tiles, _ = rb.tiles(WGRAD_TILE)
+    _lib.check(_lib.lib().pv2_spconv16_backward_weight(
+        _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, DTYPE_CODE[feats.dtype], rb.K,
+        _ptr(rb.pair_in), _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), WGRAD_TILE, n_tiles,
+        _ptr(dw), _stream(feats)), "pv2_spconv16_backward_weight")
+    return dw
+
+
+class SparseConv16Function(torch.autograd.Function):
+    """The sparse conv of ``SparseConvFunction`` on 16-bit features: fp32 master weight in, 16-bit
+    features out, fp32 weight gradient; forward and grad-input on the output-stationary kernel."""
+
+    @staticmethod
+    def forward(ctx, feats, weight_okc, rb: Rulebook, bias, cache=None):
+        c_out, K, c_in = weight_okc.shape
+        assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
+        fwd, ctx.packed_bwd = packed_weights(weight_okc, feats.dtype, cache)
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(feats, weight_okc)
+        return spconv16_forward(feats, fwd, K, c_out, rb.nbr, rb.nbr_stride, rb.perm, rb.kflip,
+                                rb.n_out, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, weight_okc = ctx.saved_tensors
+        rb = ctx.rb
+        c_out, K, c_in = weight_okc.shape
+        grad_out = grad_out.contiguous()
+        g_feats = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            nbr, stride, perm, kflip = rb._transposed_os
+            g_feats = spconv16_forward(grad_out, ctx.packed_bwd, K, c_in, nbr, stride, perm, kflip,
+                                       rb.n_in)
+        if ctx.needs_input_grad[1]:
+            g_w = spconv16_backward_weight(feats, grad_out, rb, c_out)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            g_b = grad_out.float().sum(0)
+        return g_feats, g_w, None, g_b, None
 
 
 class SparseConvFunction(torch.autograd.Function):

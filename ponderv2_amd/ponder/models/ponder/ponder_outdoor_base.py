@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ponderv2_amd import precision
 from ponderv2_amd.torch_scatter import scatter
 from ..builder import MODELS, build_model
 from ..utils import offset2batch
@@ -102,7 +103,10 @@ class PonderOutdoor(nn.Module):
             data_dict["feat"] = mask_blocks(
                 data_dict["grid_coord"], data_dict["feat"], data_dict["offset"], self.mask.size,
                 self.mask.ratio, self.mtoken, rand=data_dict.get("mask_rand"))
-        data_dict["sparse_backbone_feat"] = self.backbone(data_dict)
+        # the ambient reduced precision (enable_amp) reaches the sparse U-Net as 16-bit feature
+        # matrices between its layers (ponderv2_amd/precision.py); what comes out is fp32 again
+        with precision.sparse_activations(getattr(self, "_ambient_amp", None)):
+            data_dict["sparse_backbone_feat"] = self.backbone(data_dict).float()
         return data_dict
 
     # ------------------------------------------------------------------ rays (no grad)

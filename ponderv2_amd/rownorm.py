@@ -10,8 +10,8 @@ do not cover (eval mode, other dtypes, host tensors under the test doubles) take
 import torch
 import torch.nn.functional as F
 
-from . import _lib
-from .kernels import _ptr, _require_device, _stream
+from . import _lib, precision
+from .kernels import DTYPE_CODE, _ptr, _require_device, _stream
 
 
 _WORKSPACES = {}
@@ -46,40 +46,45 @@ def _bump_batches_tracked(bn):
 
 
 class _FusedBNFunction(torch.autograd.Function):
+    """x (fp32 or 16-bit) -> y in ``out_dtype``; the residual and the incoming gradient are in
+    ``out_dtype``, dx in x's dtype; parameters, statistics and their gradients fp32."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, relu, eps, momentum):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, relu, eps, momentum,
+                out_dtype):
         _require_device(x)
         x = x.contiguous()
         n, c = x.shape
         if residual is not None:
-            residual = residual.contiguous()
-        y = torch.empty_like(x)
+            residual = residual.to(out_dtype).contiguous()
+        y = torch.empty((n, c), dtype=out_dtype, device=x.device)
         sums = _workspace(x.device, c)
         mean_invstd = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().pv2_bn_forward(
-            _ptr(x), n, c, _ptr(weight), _ptr(bias), _ptr(residual), int(relu), float(eps),
-            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(sums), _ptr(mean_invstd),
-            _ptr(y), _stream(x)), "pv2_bn_forward")
+        _lib.check(_lib.lib().pv2_bn_forward_mixed(
+            _ptr(x), DTYPE_CODE[x.dtype], n, c, _ptr(weight), _ptr(bias), _ptr(residual), int(relu),
+            float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(sums),
+            _ptr(mean_invstd), _ptr(y), DTYPE_CODE[out_dtype], _stream(x)), "pv2_bn_forward")
         ctx.save_for_backward(x, y if relu else None, mean_invstd, weight)
         ctx.has_residual = residual is not None
         ctx.has_bias = bias is not None
+        ctx.out_dtype = out_dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean_invstd, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = dy.to(ctx.out_dtype).contiguous()
         n, c = x.shape
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_residual else None
+        dres = torch.empty_like(dy) if ctx.has_residual else None
         gsum = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().pv2_bn_backward(
-            _ptr(dy), _ptr(x), _ptr(y), _ptr(mean_invstd), _ptr(weight), n, c,
-            _ptr(_workspace(x.device, c)), _ptr(gsum), _ptr(dx), _ptr(dres), _stream(x)),
-            "pv2_bn_backward")
+        _lib.check(_lib.lib().pv2_bn_backward_mixed(
+            _ptr(dy), _ptr(x), DTYPE_CODE[x.dtype], _ptr(y), DTYPE_CODE[ctx.out_dtype],
+            _ptr(mean_invstd), _ptr(weight), n, c, _ptr(_workspace(x.device, c)), _ptr(gsum),
+            _ptr(dx), _ptr(dres), _stream(x)), "pv2_bn_backward")
         dweight = gsum[c:] if weight is not None else None
         dbias = gsum[:c] if ctx.has_bias else None
-        return dx, dweight, dbias, dres, None, None, None, None, None
+        return dx, dweight, dbias, dres, None, None, None, None, None, None
 
 
 def can_fuse(bn, x):
@@ -111,8 +116,10 @@ def fused_bn(bn, x, residual=None, relu=False, weight=None, bias=None):
     rv = bn.running_var if bn.track_running_stats else None
     w = bn.weight if weight is None else weight.float().contiguous()
     b = bn.bias if bias is None else bias.float().contiguous()
-    residual = None if residual is None else residual.float()
-    return _FusedBNFunction.apply(x.float(), w, b, residual, rm, rv, relu, bn.eps, bn.momentum)
+    # 16-bit feature matrices stay 16-bit; fp32 ones become 16-bit where the reduced-precision
+    # training mode says so (precision.sparse_dtype: the stem's output is the fp32 -> 16-bit edge)
+    out_dtype = x.dtype if x.dtype != torch.float32 else (precision.sparse_dtype() or torch.float32)
+    return _FusedBNFunction.apply(x, w, b, residual, rm, rv, relu, bn.eps, bn.momentum, out_dtype)
 
 
 class _ColSum(torch.autograd.Function):

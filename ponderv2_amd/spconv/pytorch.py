@@ -85,7 +85,12 @@ class _SparseConvBase(SparseModule):
 
     def _apply_conv(self, features, rb):
         w = self.weight.reshape(self.out_channels, -1, self.in_channels)
-        # fp32 kernels also inside autocast regions (widen whatever the region produced)
+        if K.spconv16_supported(features, w, rb):
+            # 16-bit feature matrices (the reduced-precision training mode, precision.py): the
+            # bf16 / fp16 MFMA kernels, fp32 accumulation, 16-bit result
+            cache = self.__dict__.setdefault("_pv2_packed", {})
+            return K.SparseConv16Function.apply(features, w, rb, self.bias, cache)
+        # fp32 kernels otherwise, also inside autocast regions (widen whatever the region produced)
         if features.dtype in (torch.bfloat16, torch.float16):
             features = features.float()
         out = K.SparseConvFunction.apply(features, w, rb)

@@ -10,6 +10,7 @@ from ponderv2_amd.ponder.utils.config import ConfigDict
 
 dev = torch.device("cuda:0")
 OUTDOOR = "--outdoor" in sys.argv
+AMP = torch.bfloat16 if "--amp" in sys.argv else None  # the scoped reduced-precision mode (bench.py --amp bf16)
 if OUTDOOR:
     model = build_model(ConfigDict(bench.outdoor_model_cfg())).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01)
@@ -19,12 +20,15 @@ else:
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4)
     batch = bench.make_batch(0, 2, 2, dev)
 def step():
-    out = model(bench.clone_batch(batch)); opt.zero_grad(set_to_none=True); out["loss"].backward(); opt.step(); return out
+    with torch.autocast("cuda", dtype=AMP or torch.bfloat16, enabled=AMP is not None):
+        out = model(bench.clone_batch(batch))
+    opt.zero_grad(set_to_none=True); out["loss"].backward(); opt.step(); return out
 for _ in range(4): step()
 torch.cuda.synchronize()
 # section timing on the host (enqueue only)
 import contextlib
 def sect():
+    model._ambient_amp = AMP
     d = bench.clone_batch(batch); t = [time.perf_counter()]
     d = model.extract_feature(d); t.append(time.perf_counter())
     if OUTDOOR:
