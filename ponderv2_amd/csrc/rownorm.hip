@@ -44,6 +44,49 @@ template <> __device__ __forceinline__ void st<H16>(unsigned short* p, int64_t i
   p[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
 }
 
+// Eight consecutive elements (i % 8 == 0, 16-byte aligned rows: c % 8 == 0) per thread: two 16-byte
+// loads for fp32, one for the 16-bit types.
+template <typename E> __device__ __forceinline__ void ld8(const typename E::type* p, int64_t i, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<F32>(const float* p, int64_t i, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p + i);
+  const float4 b = *reinterpret_cast<const float4*>(p + i + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<B16>(const unsigned short* p, int64_t i, float (&v)[8]) {
+  const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = __uint_as_float(w[j] << 16);
+    v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void ld8<H16>(const unsigned short* p, int64_t i, float (&v)[8]) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const h8 q = *reinterpret_cast<const h8*>(p + i);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+}
+template <typename E> __device__ __forceinline__ void st8(typename E::type* p, int64_t i, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<F32>(float* p, int64_t i, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<B16>(unsigned short* p, int64_t i, const float (&v)[8]) {
+  typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+  b8 q;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (__bf16)v[j];
+  *reinterpret_cast<b8*>(p + i) = q;
+}
+template <> __device__ __forceinline__ void st8<H16>(unsigned short* p, int64_t i, const float (&v)[8]) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 q;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (_Float16)v[j];
+  *reinterpret_cast<h8*>(p + i) = q;
+}
+
 // Statistics in two steps without atomics (bitwise reproducible, nothing to clear):
 //   1. col_partials_kernel: block b reduces its run of rows and writes partial[b][0..2C);
 //   2. col_combine_kernel: one block per 32 channels adds the partial rows in a FIXED order (double
@@ -108,6 +151,84 @@ __global__ __launch_bounds__(kThreads) void col_partials_kernel(
       partial[(int64_t)blockIdx.x * 2 * c + c + cb + tid] = t1;
     }
     __syncthreads();
+  }
+}
+
+// The same reduction for c % 8 == 0 (every layer of the backbone): a thread owns 8 consecutive
+// channels of every rpi-th row of the block's run - 16-byte loads, two rows in flight per thread.
+template <int MODE, typename EA, typename EX, typename EY>
+__global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
+    const typename EA::type* __restrict__ a, const typename EX::type* __restrict__ x,
+    const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd, int64_t n, int c,
+    int64_t rows_per_block, float* __restrict__ partial) {
+  __shared__ float s0[kThreads * 8];
+  __shared__ float s1[kThreads * 8];
+  const int tid = threadIdx.x;
+  const int cg = c >> 3;           // column groups of 8 (<= 128)
+  const int rpi = kThreads / cg;   // rows covered per iteration (>= 2)
+  const int rr = tid / cg, cc = (tid % cg) * 8;
+  const bool active = rr < rpi;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
+  float acc0[8], acc1[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc0[j] = acc1[j] = 0.f;
+  if (active) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mu[j] = mean_invstd[cc + j];
+        is[j] = mean_invstd[c + cc + j];
+      }
+    } else {
+      ld8<EA>(a, cc, mu);  // the shift: row 0 of these columns
+    }
+    auto one = [&](int64_t r) {
+      const int64_t idx = r * c + cc;
+      float va[8];
+      ld8<EA>(a, idx, va);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = va[j] - mu[j];
+          acc0[j] += v;
+          acc1[j] += v * v;
+        }
+      } else {
+        float vx[8], vy[8];
+        ld8<EX>(x, idx, vx);
+        if (y != nullptr) ld8<EY>(y, idx, vy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = (y != nullptr && !(vy[j] > 0.f)) ? 0.f : va[j];
+          acc0[j] += g;
+          acc1[j] += g * (vx[j] - mu[j]) * is[j];
+        }
+      }
+    };
+    int64_t r = r0 + rr;
+    for (; r + rpi < r1; r += 2 * rpi) {  // two rows per trip: their loads overlap
+      one(r);
+      one(r + rpi);
+    }
+    if (r < r1) one(r);
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s0[rr * c + cc + j] = acc0[j];
+      s1[rr * c + cc + j] = acc1[j];
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < c; t += kThreads) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < rpi; ++q) {
+      t0 += s0[q * c + t];
+      t1 += s1[q * c + t];
+    }
+    partial[(int64_t)blockIdx.x * 2 * c + t] = t0;
+    partial[(int64_t)blockIdx.x * 2 * c + c + t] = t1;
   }
 }
 
@@ -200,6 +321,65 @@ __global__ __launch_bounds__(kThreads) void bn_backward_apply_kernel(
   }
 }
 
+// 8 elements per thread (c % 8 == 0)
+template <typename EX, typename EY>
+__global__ __launch_bounds__(kThreads) void bn_apply_vec_kernel(
+    const typename EX::type* __restrict__ x, int64_t total, int c,
+    const float* __restrict__ mean_invstd, const float* __restrict__ w, const float* __restrict__ b,
+    const typename EY::type* __restrict__ residual, int relu, typename EY::type* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += stride) {
+    const int ch = (int)(i % c);
+    float v[8], rs[8], mu[8], is[8], wv[8], bv[8];
+    ld8<EX>(x, i, v);
+    if (residual) ld8<EY>(residual, i, rs);
+    ld8<F32>(mean_invstd, ch, mu);
+    ld8<F32>(mean_invstd, c + ch, is);
+    if (w) ld8<F32>(w, ch, wv);
+    if (b) ld8<F32>(b, ch, bv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = (v[j] - mu[j]) * is[j];
+      t = t * (w ? wv[j] : 1.f) + (b ? bv[j] : 0.f);
+      if (residual) t += rs[j];
+      if (relu && !(t > 0.f)) t = 0.f;
+      v[j] = t;
+    }
+    st8<EY>(y, i, v);
+  }
+}
+
+template <typename EX, typename EY>
+__global__ __launch_bounds__(kThreads) void bn_backward_apply_vec_kernel(
+    const typename EY::type* __restrict__ dy, const typename EX::type* __restrict__ x,
+    const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd,
+    const float* __restrict__ w, const float* __restrict__ gsum, int64_t n, int c,
+    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres) {
+  const int64_t total = n * c;
+  const float inv_n = 1.0f / (float)n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += stride) {
+    const int ch = (int)(i % c);
+    float g[8], vx[8], vy[8], o[8], mu[8], is[8], wv[8], s0[8], s1[8];
+    ld8<EY>(dy, i, g);
+    ld8<EX>(x, i, vx);
+    if (y != nullptr) ld8<EY>(y, i, vy);
+    ld8<F32>(mean_invstd, ch, mu);
+    ld8<F32>(mean_invstd, c + ch, is);
+    ld8<F32>(gsum, ch, s0);
+    ld8<F32>(gsum, c + ch, s1);
+    if (w) ld8<F32>(w, ch, wv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (y != nullptr && !(vy[j] > 0.f)) g[j] = 0.f;
+      const float xh = (vx[j] - mu[j]) * is[j];
+      o[j] = (w ? wv[j] : 1.f) * is[j] * (g[j] - s0[j] * inv_n - xh * s1[j] * inv_n);
+    }
+    st8<EX>(dx, i, o);
+    if (dres) st8<EY>(dres, i, g);
+  }
+}
+
 // out[c] += sum_r x[r, c]
 __global__ __launch_bounds__(kThreads) void col_sum_kernel(const float* __restrict__ x, int64_t n,
                                                            int c, int64_t rows_per_block,
@@ -278,15 +458,26 @@ int bn_forward_t(const void* x, int64_t n, int c, const float* weight, const flo
   int blocks;
   int64_t rpb;
   partial_geometry(n, c, &blocks, &rpb);
-  hipLaunchKernelGGL((col_partials_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
-                     (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
-                     workspace);
+  const bool vec = (c % 8) == 0;  // 16-byte pieces of rows
+  if (vec)
+    hipLaunchKernelGGL((col_partials_vec_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                       (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
+                       workspace);
+  else
+    hipLaunchKernelGGL((col_partials_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                       (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
+                       workspace);
   hipLaunchKernelGGL((col_combine_kernel<0, EX>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
                      workspace, blocks, c, (const TX*)x, n, eps, momentum, running_mean, running_var,
                      mean_invstd);
-  hipLaunchKernelGGL((bn_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
-                     dim3(kThreads), 0, s, (const TX*)x, n * c, c, mean_invstd, weight, bias,
-                     (const TY*)residual, relu, (TY*)y);
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_vec_kernel<EX, EY>), dim3(pv2::grid_for(n * c / 8, kThreads)),
+                       dim3(kThreads), 0, s, (const TX*)x, n * c, c, mean_invstd, weight, bias,
+                       (const TY*)residual, relu, (TY*)y);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, (const TX*)x, n * c, c, mean_invstd, weight, bias,
+                       (const TY*)residual, relu, (TY*)y);
   return pv2::check_launch("bn_forward");
 }
 
@@ -299,14 +490,26 @@ int bn_backward_t(const void* dy, const void* x, const void* y_or_null, const fl
   int blocks;
   int64_t rpb;
   partial_geometry(n, c, &blocks, &rpb);
-  hipLaunchKernelGGL((col_partials_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
-                     (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
-                     workspace);
+  const bool vec = (c % 8) == 0;
+  if (vec)
+    hipLaunchKernelGGL((col_partials_vec_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                       (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
+                       workspace);
+  else
+    hipLaunchKernelGGL((col_partials_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
+                       (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
+                       workspace);
   hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
                      workspace, blocks, c, (const float*)nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
-  hipLaunchKernelGGL((bn_backward_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
-                     dim3(kThreads), 0, s, (const TY*)dy, (const TX*)x, (const TY*)y_or_null,
-                     mean_invstd, weight, gsum, n, c, (TX*)dx, (TY*)dres);
+  if (vec)
+    hipLaunchKernelGGL((bn_backward_apply_vec_kernel<EX, EY>),
+                       dim3(pv2::grid_for(n * c / 8, kThreads)), dim3(kThreads), 0, s, (const TY*)dy,
+                       (const TX*)x, (const TY*)y_or_null, mean_invstd, weight, gsum, n, c, (TX*)dx,
+                       (TY*)dres);
+  else
+    hipLaunchKernelGGL((bn_backward_apply_kernel<EX, EY>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, (const TY*)dy, (const TX*)x, (const TY*)y_or_null,
+                       mean_invstd, weight, gsum, n, c, (TX*)dx, (TY*)dres);
   return pv2::check_launch("bn_backward");
 }
 
