@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--rays-per-camera", type=int, default=512, help="outdoor: RaySample.point_nsample")
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--rays-per-view", type=int, default=256)
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="build the sparse-conv geometry inside the step (one blocking read) "
+                         "instead of one batch ahead on the side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dense-dtype", default="float32", choices=["bfloat16", "float16", "float32"],
@@ -452,10 +455,25 @@ def main():
     amp_dtype = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
     scaler = torch.amp.GradScaler("cuda", enabled=amp_dtype == torch.float16)
 
+    # The trainer's one-batch lookahead (engines/train.py staged_batches): the NEXT step's batch is
+    # staged - here: cloned; in training: copied to the device and voxelised - and its sparse-conv
+    # geometry launched on the side stream before THIS step is enqueued.  Every step still builds
+    # one batch's geometry inside the timed region; it only no longer stalls the host.
+    raw_model = model.module if hasattr(model, "module") else model
+    lookahead = hasattr(raw_model, "prefetch") and not args.no_prefetch
+
+    def stage(i):
+        b = clone_batch(batches[i % len(batches)])
+        return raw_model.prefetch(b) if lookahead else b
+
+    staged = [stage(0)]
+
     def step():
-        with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
-            out = step_model(clone_batch(batches[counter[0] % len(batches)]))
+        cur = staged.pop()
         counter[0] += 1
+        staged.append(stage(counter[0]))
+        with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+            out = step_model(cur)
         opt.zero_grad(set_to_none=True)
         if scaler.is_enabled():   # engines/train.py:185-196 of the reference
             scaler.scale(out["loss"]).backward()

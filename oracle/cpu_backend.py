@@ -44,7 +44,7 @@ def build_downsample_rulebook(coords, stride, out_shape):
     return rb, torch.from_numpy(oc)
 
 
-def rulebook_from_table(tbl, K, n_in, n_out):
+def rulebook_from_table(tbl, K, n_in, n_out, n_rows_dev=None, bounded=False):
     t = tbl.numpy()
     pin, pout, ks = [], [], [0]
     for k in range(K):

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   const int64_t item = (int64_t)blockIdx.x * 4 + wave;
   if (item >= n_items) return;
   const int tile = (int)(item / n_groups), grp = (int)(item % n_groups);
+  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
   const int k = find_offset(tile_start, K, tile);
   const int p0 = kstart[k] + (tile - tile_start[k]) * PV2_PAIR_TILE;
   const int pend = kstart[k + 1];
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   const int tile = (int)(item / per_tile);
   const int sub = (int)(item % per_tile);
   const int nblk = sub / n_cgrp, cgrp = sub % n_cgrp;
+  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
   const int k = find_offset(tile_start, K, tile);
   const int p0 = kstart[k] + (tile - tile_start[k]) * PV2_WGRAD_TILE;
   const int pend = min(kstart[k + 1], p0 + PV2_WGRAD_TILE);
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
   int tile = blockIdx.x / n_groups + tile_base;
   if (tile >= skip_lo) tile += skip_len;  // the tiles of the centre offset ran in the store pass
   const int grp = blockIdx.x % n_groups;
+  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
   const int k = find_offset(tile_start, K, tile);
   const int p0 = kstart[k] + (tile - tile_start[k]) * kFwdTile;
   const int pend = kstart[k + 1];
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     cnt = min(K - p0, tile_pairs);
     for (int t = tid; t < tile_pairs; t += 256) s_in[t] = s_out[t] = t < cnt ? p0 + t : -1;
   } else {
+    if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
     k = find_offset(tile_start, K, tile);
     p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
     cnt = min(kstart[k + 1] - p0, tile_pairs);

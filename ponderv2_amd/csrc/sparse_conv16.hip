@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad16_kernel(
   const int per_tile = n_ntile * n_ctile;
   const int tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
   const int n0 = (sub / n_ctile) * TN, c0 = (sub % n_ctile) * TC;
+  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
   const int k = find_offset(tile_start, K, tile);
   const int p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
   const int cnt = min(kstart[k + 1] - p0, tile_pairs);

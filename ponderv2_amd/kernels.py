@@ -220,14 +220,35 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     return rb
 
 
-def rulebook_from_table(tbl: torch.Tensor, K: int, n_in: int, n_out: int) -> Rulebook:
+def rulebook_from_table(tbl: torch.Tensor, K: int, n_in: int, n_out: int,
+                        n_rows_dev: Optional[torch.Tensor] = None, bounded: bool = False) -> Rulebook:
     """tbl int32 [K, n_in]: the output row input row i feeds under offset k, or -1 -> rulebook in
     canonical (offset, input row) order.  Used for convolutions whose geometry is arithmetic (the
-    dense grid's first layer, models/ponder/sparse_input.py) rather than hashed."""
+    dense grid's first layer, models/ponder/sparse_input.py) rather than hashed.
+
+    ``bounded``: no device->host read.  The pair arrays are sized for the worst case (every row
+    pairs under every offset), the host-side counts are that upper bound - they only size launch
+    grids; the kernels take the true counts from the device copy of ``kstart`` and workgroups past
+    them return at once.  ``n_rows_dev`` (int32 [1] on the device): rows past it are padding."""
     _require_device(tbl)
     assert tbl.dtype == torch.int32 and tbl.shape == (K, n_in)
-    pair_out, pair_in, kstart, kstart_host = _compact(tbl.contiguous().reshape(-1), K, n_in, None)
-    return Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, kstart_host)
+    flat = tbl.contiguous().reshape(-1)
+    if not bounded:
+        pair_out, pair_in, kstart, kstart_host = _compact(flat, K, n_in, n_rows_dev)
+        return Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, kstart_host)
+    L = _lib.lib()
+    dev = tbl.device
+    nchunks = max(1, (n_in + SCAN_CHUNK - 1) // SCAN_CHUNK)
+    block_sums = torch.empty(K * nchunks, dtype=torch.int32, device=dev)
+    kstart = torch.empty(K + 1, dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_table_count(_ptr(flat), K, n_in, _ptr(n_rows_dev), _ptr(block_sums),
+                                 _ptr(kstart), _stream(tbl)), "pv2_table_count")
+    pair_out = torch.empty(K * n_in, dtype=torch.int32, device=dev)
+    pair_in = torch.empty(K * n_in, dtype=torch.int32, device=dev)
+    _lib.check(L.pv2_table_compact(_ptr(flat), K, n_in, _ptr(n_rows_dev), _ptr(block_sums),
+                                   _ptr(pair_out), _ptr(pair_in), _stream(tbl)), "pv2_table_compact")
+    bound = np.arange(K + 1, dtype=np.int64) * n_in
+    return Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, bound)
 
 
 def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List[int]):
@@ -270,7 +291,91 @@ def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List
 
 def prepare_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 4,
                           stem_ksize: int = 5, stem_key: str = "stem") -> dict:
-    """Every rulebook a SpUNet forward needs, built in ONE pass with ONE device->host read.
+    """Every rulebook a SpUNet forward needs, built in ONE pass with ONE device->host read
+    (``_launch_unet_geometry`` + a blocking copy + ``_finish_unet_geometry``; the non-blocking form
+    is ``prefetch_unet_geometry``)."""
+    launched = _launch_unet_geometry(indices, spatial_shape, n_levels, stem_ksize, stem_key)
+    if launched is None:
+        return {}
+    state, counts = launched
+    return _finish_unet_geometry(state, counts.cpu().numpy())
+
+
+class PendingGeometry:
+    """Rulebooks in flight on a side stream (``prefetch_unet_geometry``)."""
+
+    def __init__(self, state, counts_host, event, stream, n_rows):
+        self._state, self._host, self._event, self._stream = state, counts_host, event, stream
+        self.n_rows = n_rows
+        self._result = None
+
+    def result(self) -> dict:
+        """The ``indice_dict``; the host waits for the side stream's copy only (long done when
+        the geometry was launched a step ahead), the current stream for its kernels."""
+        if self._result is None:
+            if self._state is None:
+                self._result = {}
+            else:
+                self._event.synchronize()
+                cur = torch.cuda.current_stream(self._state["dev"])
+                cur.wait_event(self._event)
+                self._result = _finish_unet_geometry(self._state, self._host.numpy())
+                _record_stream(self._result, cur)   # allocated on the side stream, used on this one
+                self._state = None
+        return self._result
+
+
+def _record_stream(obj, stream, _seen=None):
+    seen = set() if _seen is None else _seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream, seen)
+    elif isinstance(obj, Rulebook):
+        _record_stream(list(vars(obj).values()), stream, seen)
+
+
+_GEOMETRY_STREAMS = {}
+
+
+def prefetch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 4,
+                           stem_ksize: int = 5, stem_key: str = "stem") -> PendingGeometry:
+    """``prepare_unet_geometry`` without stalling the host: the tables are built on a side stream
+    (after whatever the current stream has queued so far - so launch it BEFORE the training step
+    it should overlap with, i.e. one batch ahead) and their counts travel to pinned host memory
+    asynchronously.  The geometry depends on the batch's coordinates only, never on the model: this
+    is input-pipeline work, the counterpart of the reference's dataloader workers."""
+    _require_device(indices)
+    dev = indices.device
+    side = _GEOMETRY_STREAMS.get(dev.index)
+    if side is None:
+        side = _GEOMETRY_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        indices.record_stream(side)
+        launched = _launch_unet_geometry(indices, spatial_shape, n_levels, stem_ksize, stem_key)
+        if launched is None:
+            return PendingGeometry(None, None, None, side, 0)
+        state, counts = launched
+        host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(side)
+    return PendingGeometry(state, host, event, side, indices.shape[0])
+
+
+def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 4,
+                          stem_ksize: int = 5, stem_key: str = "stem"):
+    """Launches every table build of a SpUNet forward; returns (state, device tensor of all counts)
+    or None for an empty input.
 
     The lazy builders above read a count back per rulebook (to size its pair arrays) and the
     strided convs another one (the number of output voxels): ~14 blocking reads per forward, each
@@ -288,7 +393,7 @@ def prepare_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
     st = _stream(indices)
     cap = indices.shape[0]
     if cap == 0:
-        return {}
+        return None
     coords = [indices.contiguous()]
     n_dev = [None]                      # device-side valid count of each level (None: all rows)
     shapes = [[int(v) for v in spatial_shape]]
@@ -357,8 +462,18 @@ def prepare_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
             subms.append(dict(key=key, ksize=ksize, level=level, K=K, nbr=nbr, pair_in=pair_in,
                               pair_out=pair_out, kstart=kstart,
                               perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None))
-    # ---- the one device->host read
-    host = torch.cat([t.reshape(-1) for t in readback + n_dev[1:]]).cpu().numpy().astype(np.int64)
+    state = dict(cap=cap, n_levels=n_levels, coords=coords, shapes=shapes, downs=downs, subms=subms,
+                 readback=readback, dev=dev)
+    return state, torch.cat([t.reshape(-1) for t in readback + n_dev[1:]])
+
+
+def _finish_unet_geometry(state, host) -> dict:
+    """Rulebooks from the launched tables and the host copy of their counts."""
+    cap, n_levels, coords, shapes = state["cap"], state["n_levels"], state["coords"], state["shapes"]
+    downs, subms, readback, dev = state["downs"], state["subms"], state["readback"], state["dev"]
+    st = _stream(coords[0])  # (the caller's stream: the tables may have been built on another)
+    L = _lib.lib()
+    host = np.asarray(host).astype(np.int64)
     pos = 0
     hosts = []
     for t in readback:

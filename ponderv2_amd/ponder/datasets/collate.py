@@ -73,6 +73,7 @@ def _mix_offsets(batch, mix_prob):
         batch["offset"] = torch.cat([offset[1:-1:2], offset[-1:]], dim=0)
         if "offset_host" in batch:
             batch["offset_host"] = [int(v) for v in batch["offset"]]
+        batch.pop("extent_host", None)  # per-scene hints of the unmixed scenes
     return batch
 
 

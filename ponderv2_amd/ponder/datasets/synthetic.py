@@ -169,6 +169,9 @@ def collate_fn(samples):
                 feat=torch.from_numpy(feat.astype(np.float32)), segment=cat("segment", np.int64),
                 offset=torch.tensor(np.cumsum(counts), dtype=torch.int64),
                 offset_host=[int(v) for v in np.cumsum(counts)],
+                # largest side of every scene's bounding box: lets the model skip a device read
+                # when no scene is anywhere near the "smaller than the dense grid" case
+                extent_host=[float((s["coord"].max(0) - s["coord"].min(0)).max()) for s in samples],
                 condition=[s["condition"] for s in samples], rgb=stack("rgb"), depth=stack("depth"),
                 semantic=stack("semantic"), extrinsic=stack("extrinsic"), intrinsic=stack("intrinsic"),
                 depth_scale=torch.tensor([s["depth_scale"] for s in samples], dtype=torch.float32))

@@ -80,7 +80,7 @@ class TrainerBase:
         for self.epoch in range(self.start_epoch, self.max_epoch):
             self.before_epoch()
             self._call("before_epoch")
-            for it, batch in enumerate(self.train_loader):
+            for it, batch in enumerate(self.staged_batches(self.train_loader)):
                 self.comm_info.update(iter=it, input_dict=batch,
                                       global_iter=self.epoch * len(self.train_loader) + it)
                 self._call("before_step")
@@ -94,6 +94,11 @@ class TrainerBase:
 
     def before_epoch(self):
         pass
+
+    def staged_batches(self, loader):
+        """Hook for input-pipeline work that overlaps the previous step; the base trainer passes
+        the loader's batches through."""
+        return loader
 
     def run_step(self):
         raise NotImplementedError
@@ -156,14 +161,39 @@ class Trainer(TrainerBase):
             self.train_loader.sampler.set_epoch(self.epoch)
         self.model.train()
 
-    def run_step(self):
-        batch = self.comm_info["input_dict"]
+    def stage(self, batch):
+        """A loader batch -> device-resident model input: the copy, the optional device-side
+        GridSample, and the launch of its sparse-conv geometry on the side stream."""
         batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
                  for k, v in batch.items()}
         if self.cfg.get("device_voxelize"):
             # GridSample on the device: the loader streamed raw points (SURVEY 8(f) F3); the voxel
             # set and its order equal the host transform's (datasets/voxelize.py)
             batch = device_grid_sample(batch, **self.cfg.device_voxelize)
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        if hasattr(model, "prefetch") and self.device.type == "cuda":
+            batch = model.prefetch(batch)
+        batch["_staged"] = True
+        return batch
+
+    def staged_batches(self, loader):
+        """One batch of lookahead: batch i+1 is staged (``stage``) BEFORE step i is enqueued, so its
+        geometry builds overlap step i on the device and step i+1 starts without a host stall -
+        the counterpart of the reference's dataloader workers for the device-side input work."""
+        it = iter(loader)
+        nxt = next(it, None)
+        nxt = self.stage(nxt) if nxt is not None else None
+        while nxt is not None:
+            cur, nxt = nxt, next(it, None)
+            if nxt is not None:
+                nxt = self.stage(nxt)
+            yield cur
+
+    def run_step(self):
+        batch = self.comm_info["input_dict"]
+        if not batch.pop("_staged", False):
+            batch = self.stage(batch)
+            batch.pop("_staged", None)
         with torch.autocast(self.device.type, dtype=self.amp_dtype, enabled=bool(self.cfg.enable_amp)):
             out = self.model(batch)
             loss = out["loss"]

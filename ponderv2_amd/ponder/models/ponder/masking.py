@@ -18,7 +18,7 @@ def mask_blocks(grid_coord, feat, offset, size, ratio, mtoken, rand=None):
     ``round(n_blocks * (1 - ratio))`` - the same set the reference keeps when ``rand`` carries its
     draws (blocks in lexicographic (scene, bx, by, bz) order, which is the order ``unique(dim=0)``
     returns on every backend)."""
-    batch = offset2batch(offset)
+    batch = offset2batch(offset, grid_coord.shape[0])
     block = torch.cat([batch[:, None], torch.div(grid_coord, size).int()], dim=-1)
     block, inverse = block.unique(sorted=True, return_inverse=True, dim=0)
     scene = block[:, 0].long()

@@ -32,6 +32,7 @@ from ..losses import build_criteria
 from ..utils import offset2batch, offsets_host
 from .masking import mask_blocks
 from .render_utils import RayBundle, build_renderer
+from .render_utils.rays import device_constant
 
 
 def stub_text_embeddings(num_classes, dim=512, seed=0):
@@ -40,6 +41,12 @@ def stub_text_embeddings(num_classes, dim=512, seed=0):
     g = torch.Generator().manual_seed(seed)
     e = torch.randn(num_classes, dim, generator=g)
     return e / e.norm(dim=-1, keepdim=True)
+
+
+def _inv(a):
+    """torch.linalg.inv without its error check: that check reads a status word back from the
+    device, i.e. stalls the host once per call (camera matrices are invertible by construction)."""
+    return torch.linalg.inv_ex(a, check_errors=False).inverse
 
 
 @MODELS.register_module("PonderIndoor-v2")
@@ -136,7 +143,8 @@ class PonderIndoor(nn.Module):
         if self.mask is not None:
             data_dict["feat"] = self._mask_blocks(data_dict)
         if "condition" in data_dict:
-            idx = torch.tensor([self._condition_index(data_dict)], device=data_dict["coord"].device)
+            idx = device_constant((self._condition_index(data_dict),), data_dict["coord"].device,
+                                  torch.int64)
             data_dict["context"] = self.embedding_table(idx)
         # the ambient reduced precision (enable_amp) reaches the sparse U-Net as 16-bit feature
         # matrices between its layers (ponderv2_amd/precision.py); what comes out is fp32 again
@@ -157,7 +165,7 @@ class PonderIndoor(nn.Module):
         coords = data_dict["coord"]
         offset = data_dict["offset"]
         B = offset.numel()
-        batch = offset2batch(offset)
+        batch = offset2batch(offset, coords.shape[0])
         edges = [0] + offsets_host(data_dict)
 
         def seg_minmax(x):  # per-scene min/max over contiguous row ranges (B is small)
@@ -187,7 +195,7 @@ class PonderIndoor(nn.Module):
 
         pose = data_dict["extrinsic"].clone().float()  # (B,V,4,4)
         pose[:, :, 3, 3] = 1
-        data_dict["extrinsic"] = pose @ torch.linalg.inv(S.float())[:, None]
+        data_dict["extrinsic"] = pose @ _inv(S.float())[:, None]
         data_dict["depth_scale"] = scale * data_dict["depth_scale"]
         data_dict["pc_scale"] = extent.to(data_dict["depth_scale"].dtype)
         lo2, hi2 = seg_minmax(new)
@@ -204,8 +212,8 @@ class PonderIndoor(nn.Module):
         d = torch.where((d < 1e-5) & (d > -1e-10), torch.full_like(d, 1e-5), d)
         d = torch.where((d > -1e-5) & (d < 1e-10), torch.full_like(d, -1e-5), d)
         inv = (1.0 / d).double()
-        lo = torch.tensor(self.bounds[0], dtype=torch.float64, device=d.device)
-        hi = torch.tensor(self.bounds[1], dtype=torch.float64, device=d.device)
+        lo = device_constant(self.bounds[0], d.device, torch.float64)  # (uploaded once: a host->device
+        hi = device_constant(self.bounds[1], d.device, torch.float64)  #  copy per step stalls the host)
         o = ray_o.double()[..., None, :]
         ta, tb = (lo - o) * inv, (hi - o) * inv
         near = torch.minimum(ta, tb).max(dim=-1).values.clamp(min=0.1)
@@ -255,9 +263,9 @@ class PonderIndoor(nn.Module):
         RT = torch.zeros((B, V, 4, 4), device=dev)
         RT[..., :3, :4] = extr[..., :3, :4]
         RT[..., 3, 3] = 1
-        pose = torch.linalg.inv(RT)
+        pose = _inv(RT)
         p = torch.stack([px.float(), py.float(), torch.ones_like(px, dtype=torch.float32)], -1)
-        p = (torch.linalg.inv(Kmat)[:, :, None] @ p[..., None]).squeeze(-1)       # (B,V,n,3)
+        p = (_inv(Kmat)[:, :, None] @ p[..., None]).squeeze(-1)       # (B,V,n,3)
         v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
         v = (pose[:, :, None, :3, :3] @ v[..., None]).squeeze(-1)
         ray_d = F.normalize(v, dim=-1)
@@ -271,8 +279,8 @@ class PonderIndoor(nn.Module):
         color = pick(colors)
         depth = pick(depths * (depths > 0).float()) * dscale[:, None, None]
         # plane-to-plane depth -> distance along the ray
-        cam2world = torch.linalg.inv(extr)
-        ez = torch.tensor([0.0, 0.0, 1.0, 1.0], device=dev)
+        cam2world = _inv(extr)
+        ez = device_constant((0.0, 0.0, 1.0, 1.0), dev)
         plane = (cam2world @ ez)[..., :3] - ray_o[:, :, 0]
         plane = plane / torch.linalg.norm(plane, dim=-1, keepdim=True)
         depth = depth / (ray_d * plane[:, :, None]).sum(-1)
@@ -310,6 +318,13 @@ class PonderIndoor(nn.Module):
         settings): the reference up-samples those instead of pooling them (:218-247).  One host
         read per batch, cached in the dict."""
         if "small_scenes" not in data_dict:
+            # the collates pass every scene's coordinate extent on the host: far from the
+            # threshold the answer needs no read (the bound allows for the voxel rounding of
+            # ``resolution`` and a device-side GridSample that trims the cloud by a voxel or two)
+            ext = data_dict.get("extent_host")
+            if ext is not None and all(e / self.grid_size - 4 >= min(self.grid_shape) for e in ext):
+                data_dict["small_scenes"] = []
+                return data_dict["small_scenes"]
             res = data_dict["resolution"] + 1
             data_dict["small_scenes"] = torch.nonzero(res < min(self.grid_shape)).flatten().tolist()
         return data_dict["small_scenes"]
@@ -317,11 +332,11 @@ class PonderIndoor(nn.Module):
     def _dense_rows(self, data_dict):
         """Row of every voxel in the (B, Z, Y, X) channels-last (or (B, X, Y, Z)) dense grid for
         the pooling branch of the reference (:199-216, scene resolution >= grid)."""
-        batch = offset2batch(data_dict["offset"])
+        batch = offset2batch(data_dict["offset"], data_dict["coord"].shape[0])
         G0, G1, G2 = self.grid_shape
         voxel = (data_dict["coord"] // self.grid_size).int()
         res = (data_dict["resolution"] + 1).to(torch.float32)  # current_resolution, (B,)
-        shape = torch.tensor(self.grid_shape, dtype=torch.float32, device=voxel.device)
+        shape = device_constant(self.grid_shape, voxel.device)
         cell = res[:, None] / shape[None, :]            # (B,3) anisotropic bin size in voxels
         g = (voxel // cell[batch]).long()
         if self.dense_channels_last:
@@ -357,7 +372,7 @@ class PonderIndoor(nn.Module):
         lin = self._dense_rows(data_dict)
         small = self._small_scenes(data_dict)
         if small:
-            batch = offset2batch(data_dict["offset"])
+            batch = offset2batch(data_dict["offset"], data_dict["coord"].shape[0])
             pooled = torch.ones_like(batch, dtype=torch.bool)
             for i in small:
                 pooled &= batch != i
@@ -439,6 +454,12 @@ class PonderIndoor(nn.Module):
         if self.proj_autocast is not None and device.type == "cuda":
             return getattr(torch, self.proj_autocast)
         return getattr(self, "_ambient_amp", None)
+
+    def prefetch(self, data_dict):
+        """Input-pipeline hook: launch the sparse backbone's geometry for this (device-resident)
+        batch on the side stream (SpUNet.prefetch_geometry); trainers call it one batch ahead."""
+        fn = getattr(self.backbone, "prefetch_geometry", None)
+        return fn(data_dict) if fn is not None else data_dict
 
     def forward(self, data_dict):
         """Under an ambient autocast region (the reference's ``enable_amp=True``) the reduced

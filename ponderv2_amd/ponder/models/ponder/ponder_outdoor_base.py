@@ -141,7 +141,7 @@ class PonderOutdoor(nn.Module):
         box = self._const("scene_bbox", idx, coord.device, coord.dtype)
         size = self._const("grid_size", idx, coord.device, coord.dtype)
         G0, G1, G2 = self.grid_shape[idx]
-        batch = offset2batch(offset)
+        batch = offset2batch(offset, coord.shape[0])
         g = ((coord - box[:3]) / size).long()
         if self.dense_channels_last:
             lin = (g[:, 2] * G1 + g[:, 1]) * G0 + g[:, 0]  # memory order (Z,Y,X), channels last
@@ -230,6 +230,12 @@ class PonderOutdoor(nn.Module):
         if self.proj_autocast is not None and device.type == "cuda":
             return getattr(torch, self.proj_autocast)
         return getattr(self, "_ambient_amp", None)
+
+    def prefetch(self, data_dict):
+        """Input-pipeline hook: launch the sparse backbone's geometry for this (device-resident)
+        batch on the side stream (SpUNet.prefetch_geometry); trainers call it one batch ahead."""
+        fn = getattr(self.backbone, "prefetch_geometry", None)
+        return fn(data_dict) if fn is not None else data_dict
 
     def forward(self, data_dict):
         """Under an ambient autocast region (the reference's ``enable_amp=True``) the reduced

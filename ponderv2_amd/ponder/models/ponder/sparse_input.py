@@ -47,25 +47,28 @@ class DenseCells:
 
     def rulebook(self):
         if self._rulebook is None:
+            # (sized by upper bounds on device tensors, padding rows skipped: no host read)
             self._rulebook = K.rulebook_from_table(_tap_table(self), 27, self.lin.shape[0],
-                                                   self.n_rows)
+                                                   self.n_rows, bounded=self.lin.is_cuda)
         return self._rulebook
 
 
 def cells_from_voxels(feat, lin, batch, dims, reduce="mean"):
     """Pool per-voxel rows into their dense cells WITHOUT building the dense grid: a flag grid and
-    its prefix sum number the occupied cells (one host read for their count)."""
+    its prefix sum number the occupied cells.  No device->host read: the cell arrays are sized for
+    the worst case (one cell per voxel); rows past the true cell count are padding (``lin`` -1,
+    zero features), which every consumer skips."""
     z, y, x = dims
     total = batch * z * y * x
+    cap = lin.shape[0]
     flags = torch.zeros(total, dtype=torch.int32, device=feat.device)
     flags.index_fill_(0, lin, 1)
     cell_id = torch.cumsum(flags, 0, dtype=torch.int32)
-    n_cells = int(cell_id[-1])
     cell_of_voxel = cell_id[lin].long() - 1
-    cell_lin = torch.empty(n_cells, dtype=torch.int64, device=feat.device)
+    cell_lin = torch.full((cap,), -1, dtype=torch.int64, device=feat.device)
     cell_lin[cell_of_voxel] = lin  # duplicates write the same value
     pooled = scatter(feat, cell_of_voxel[:, None], dim=0, reduce=reduce,
-                     out=feat.new_zeros((n_cells, feat.shape[1])))
+                     out=feat.new_zeros((cap, feat.shape[1])))
     return DenseCells(pooled, cell_lin, batch, (z, y, x))
 
 
@@ -82,7 +85,7 @@ def _tap_table(cells):
     pz = z[None] - (torch.div(k, 9, rounding_mode="floor") - 1)
     py = y[None] - (torch.div(k, 3, rounding_mode="floor") % 3 - 1)
     px = x[None] - (k % 3 - 1)
-    ok = (pz >= 0) & (pz < zs) & (py >= 0) & (py < ys) & (px >= 0) & (px < xs)
+    ok = (pz >= 0) & (pz < zs) & (py >= 0) & (py < ys) & (px >= 0) & (px < xs) & (lin >= 0)[None]
     row = base[None] + (pz * ys + py) * xs + px
     return torch.where(ok, row, torch.full_like(row, -1)).to(torch.int32).contiguous()
 

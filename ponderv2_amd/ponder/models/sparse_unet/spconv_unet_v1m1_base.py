@@ -115,19 +115,40 @@ class SpUNetBase(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
-    def _geometry(self, feat, batch, grid_coord, sparse_shape):
+    def _geometry(self, feat, batch, grid_coord, sparse_shape, pending=None):
         """All ten rulebooks of the U-Net with ONE device->host read (kernels.prepare_unet_geometry)
-        instead of one or two per rulebook; host tensors (the CPU test doubles) build lazily."""
-        if not feat.is_cuda or self.cls_mode:
+        instead of one or two per rulebook - or none at all when the batch carries the handle of a
+        build launched a step ahead (``prefetch_geometry``); host tensors (the CPU test doubles)
+        build lazily."""
+        if not feat.is_cuda or getattr(self, "cls_mode", False):
             return None
         from ponderv2_amd import kernels as K
 
+        if isinstance(pending, K.PendingGeometry) and pending.n_rows == grid_coord.shape[0]:
+            return pending.result()
         indices = torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous()
         return K.prepare_unet_geometry(indices, sparse_shape, n_levels=self.num_stages)
 
+    def prefetch_geometry(self, input_dict):
+        """Launch this batch's rulebook builds on the geometry side stream and leave the handle
+        in ``input_dict["geometry"]`` (kernels.prefetch_unet_geometry).  Input-pipeline work: call
+        it for batch i+1 before step i is enqueued, and step i+1 starts without a host stall.
+        Needs ``sparse_shape`` in the batch (the collates provide it)."""
+        grid_coord = input_dict["grid_coord"]
+        if (not grid_coord.is_cuda or getattr(self, "cls_mode", False)
+                or input_dict.get("sparse_shape") is None):
+            return input_dict
+        from ponderv2_amd import kernels as K
+
+        batch = offset2batch(input_dict["offset"], grid_coord.shape[0])
+        indices = torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous()
+        input_dict["geometry"] = K.prefetch_unet_geometry(indices, input_dict["sparse_shape"],
+                                                          n_levels=self.num_stages)
+        return input_dict
+
     def forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
-        batch = offset2batch(offset)
+        batch = offset2batch(offset, grid_coord.shape[0])
         sparse_shape = input_dict.get("sparse_shape")
         if sparse_shape is None:  # one device->host read, as the reference's .tolist() (:248)
             sparse_shape = torch.add(torch.max(grid_coord, dim=0).values, 96).tolist()
@@ -135,7 +156,8 @@ class SpUNetBase(nn.Module):
             features=feat,
             indices=torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous(),
             spatial_shape=sparse_shape, batch_size=offset.numel(),
-            indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape))
+            indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape,
+                                       input_dict.get("geometry")))
         x = self.conv_input(x)
         skips = [x]
         for s in range(self.num_stages):

@@ -3,11 +3,14 @@ loop over scenes and no host round trip."""
 import torch
 
 
-def offset2batch(offset: torch.Tensor) -> torch.Tensor:
-    """(B,) cumulative point counts -> (N,) int64 scene index of every point."""
+def offset2batch(offset: torch.Tensor, n: int = None) -> torch.Tensor:
+    """(B,) cumulative point counts -> (N,) int64 scene index of every point.  ``n`` = the point
+    count when the caller knows it (the row count of the point tensors): without it
+    ``repeat_interleave`` reads the output size back from the device - a host stall."""
     offset = offset.long()
     counts = torch.diff(offset, prepend=offset.new_zeros(1))
-    return torch.repeat_interleave(torch.arange(offset.numel(), device=offset.device), counts)
+    return torch.repeat_interleave(torch.arange(offset.numel(), device=offset.device), counts,
+                                   output_size=n)
 
 
 def batch2offset(batch: torch.Tensor) -> torch.Tensor:

@@ -634,3 +634,38 @@ def test_one_read_geometry_prepass_equals_the_lazy_builders(device, seed, batch,
         g = torch.randn(got.n_out, 48, device=device)
         assert torch.equal(K.spconv_grad_input(g, w, got), K.spconv_grad_input(g, w, ref))
         level = oc
+
+
+def test_prefetched_geometry_equals_the_blocking_build(device, monkeypatch):
+    """kernels.prefetch_unet_geometry (side stream, asynchronous copy of the counts) hands the
+    backbone the same rulebooks as the blocking build, and a step that uses tensors allocated on
+    the side stream computes the same bits - also while the main stream is busy."""
+    from golden_cases import FULL_BACKBONE
+    from ponderv2_amd import kernels as K
+    from ponderv2_amd.ponder.models import build_model
+
+    monkeypatch.setattr(K, "USE_OS", True)  # deterministic forward: bitwise comparison
+    torch.manual_seed(0)
+    model = build_model(dict(FULL_BACKBONE)).to(device).train()
+    coords = random_voxels(31, batch=2, n_per_batch=5000)
+    counts = np.bincount(coords[:, 0], minlength=2)
+    shape = [int(v) + 96 for v in coords[:, 1:].max(0)]
+    data = dict(grid_coord=torch.from_numpy(coords[:, 1:]).to(device),
+                feat=torch.randn(len(coords), 6, device=device),
+                offset=torch.from_numpy(np.cumsum(counts)).to(device), sparse_shape=shape)
+    ref = model(dict(data))
+    busy = torch.randn(4096, 4096, device=device)
+    for _ in range(3):
+        ahead = model.prefetch_geometry(dict(data))
+        assert isinstance(ahead["geometry"], K.PendingGeometry)
+        for _ in range(4):
+            busy = busy @ busy * 1e-3   # keep the main stream busy while the tables are built
+        out = model(ahead)
+        assert torch.equal(out, ref)
+    geo_a = K.prepare_unet_geometry(torch.from_numpy(coords).to(device), shape)
+    geo_b = ahead["geometry"].result()
+    assert set(geo_a) == set(geo_b)
+    for key in geo_a:
+        a, b = geo_a[key]["rulebook"], geo_b[key]["rulebook"]
+        assert np.array_equal(a.kstart_host, b.kstart_host)
+        assert torch.equal(a.pair_in, b.pair_in) and torch.equal(a.pair_out, b.pair_out)

@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r2m; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "prefetch or prepass" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt | cut -c1-300
+for mode in "" "--amp bf16"; do
+for pf in "" "--no-prefetch"; do
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $mode $pf > $O/bench.json 2> $O/bench.err; echo "[$mode $pf] rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench.json) $(grep -o '"host_enqueue_ms_per_step": [0-9.]*' $O/bench.json) $(grep -o '"final_loss": [0-9.e-]*' $O/bench.json)"
+done; done

@@ -19,9 +19,13 @@ else:
     model = build_model(ConfigDict(bench.model_cfg(256, "float32"))).to(dev).train()
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4)
     batch = bench.make_batch(0, 2, 2, dev)
+PREFETCH = "--prefetch" in sys.argv
+staged = [model.prefetch(bench.clone_batch(batch)) if PREFETCH else bench.clone_batch(batch)]
 def step():
+    cur = staged.pop()
+    staged.append(model.prefetch(bench.clone_batch(batch)) if PREFETCH else bench.clone_batch(batch))
     with torch.autocast("cuda", dtype=AMP or torch.bfloat16, enabled=AMP is not None):
-        out = model(bench.clone_batch(batch))
+        out = model(cur)
     opt.zero_grad(set_to_none=True); out["loss"].backward(); opt.step(); return out
 for _ in range(4): step()
 torch.cuda.synchronize()
@@ -48,6 +52,10 @@ def sect():
     names = ["backbone_fwd", "prepare_ray", "prepare_volume", "render", "losses", "backward", "opt", "drain"]
     print(" | ".join("%s %.2f" % (n, 1e3 * (b - a)) for n, a, b in zip(names, t[:-1], t[1:])), flush=True)
 for _ in range(3): sect()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("10 steps: host %.2f ms/step, wall %.2f ms/step" % ((t1 - t0) * 100, (t2 - t0) * 100), flush=True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
