@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -165,6 +166,8 @@ class KernelTimer:
         self.records = {}   # family -> list of (start, end, flops, bytes)
         self._orig, self._orig_c, self._handle = {}, {}, None
         self.l2_bytes = {}
+        self.peaks = {}     # family -> dense MFMA peak of its operand type (TFLOP/s)
+        self._depth = 0     # > 0 inside a wrapped call: nested wrapped calls are not recorded twice
 
     def _add(self, fam, s, e, flops, nbytes, shape=None):
         self.records.setdefault(fam, []).append((s, e, flops, nbytes, shape))
@@ -174,15 +177,22 @@ class KernelTimer:
 
         timer = self
 
-        def wrap(name, fam, cost):
+        def wrap(name, fam, cost, peak=F32_MFMA_PEAK_TFLOPS):
             orig = getattr(K, name)
             self._orig[name] = orig
+            self.peaks[fam] = peak
 
             def fn(*a, **k):
+                if timer._depth > 0:
+                    return orig(*a, **k)
                 s = torch.cuda.Event(enable_timing=True)
                 e = torch.cuda.Event(enable_timing=True)
                 s.record()
-                out = orig(*a, **k)
+                timer._depth += 1
+                try:
+                    out = orig(*a, **k)
+                finally:
+                    timer._depth -= 1
                 e.record()
                 c = cost(*a, **k)
                 timer._add(fam, s, e, c[0], c[1], c[2] if len(c) > 2 else None)
@@ -202,6 +212,24 @@ class KernelTimer:
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
                     4.0 * (rb.n_in * c_in + rb.n_out * c_out + rb.K * c_in * c_out) + 8.0 * p,
+                    (c_in, c_out, rb.K, p))
+
+        def dgrad_cost(gout, w, rb):
+            return conv_cost(gout, w.permute(2, 1, 0), rb.transposed())
+
+        # 16-bit kernels (csrc/sparse_conv16.hip): same algorithmic flops, 2-byte features and
+        # weights, fp32 dW; the gather table instead of pair lists on the output-stationary pass
+        def conv16_cost(feats, packed, kk, c_out, nbr, stride, perm, kflip, n_out, bias=None, n_pairs=0):
+            n_in, c_in = feats.shape
+            return (2.0 * n_pairs * c_in * c_out,
+                    2.0 * (n_in * c_in + n_out * c_out + kk * c_in * c_out) + 4.0 * kk * n_out,
+                    (c_in, c_out, kk, n_pairs))
+
+        def wgrad16_cost(feats, gout, rb, c_out):
+            c_in = feats.shape[1]
+            p = rb.n_pairs
+            return (2.0 * p * c_in * c_out,
+                    2.0 * (rb.n_in * c_in + rb.n_out * c_out) + 4.0 * rb.K * c_in * c_out + 8.0 * p,
                     (c_in, c_out, rb.K, p))
 
         def tri_cost_factory(mult):
@@ -268,7 +296,11 @@ class KernelTimer:
         wrap_c("pv2_neus_field_backward", "field_bwd_kernel + volume_scatter_kernel", field_bwd_cost)
         wrap_c("pv2_neus_coarse_sample", "coarse_sample_kernel", coarse_cost)
         wrap("spconv_forward", "spconv_fwd_kernel (fwd+dgrad)", conv_cost)
+        wrap("spconv_grad_input", "spconv_fwd_kernel (fwd+dgrad)", dgrad_cost)
         wrap("spconv_backward_weight", "spconv_wgrad_kernel", wgrad_cost)
+        wrap("spconv16_forward", "spconv_os16_kernel (fwd+dgrad, 16-bit)", conv16_cost, BF16_MFMA_PEAK_TFLOPS)
+        wrap("spconv16_backward_weight", "spconv_wgrad16_kernel (16-bit)", wgrad16_cost,
+             BF16_MFMA_PEAK_TFLOPS)
         wrap("trilinear_forward", "tri_fwd_kernel", tri_cost_factory(1))
         wrap("trilinear_backward", "tri_bwd_kernel", tri_cost_factory(2))
         wrap("trilinear_backward_backward", "tri_bwdbwd_kernel", tri_cost_factory(3))
@@ -297,7 +329,10 @@ class KernelTimer:
                             tflops=flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                             alg_gbs=nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                             alg_flops_per_launch=flops / max(len(recs), 1),
-                            alg_bytes_per_launch=nbytes / max(len(recs), 1)))
+                            alg_bytes_per_launch=nbytes / max(len(recs), 1),
+                            mfma_peak_tflops=self.peaks.get(fam, F32_MFMA_PEAK_TFLOPS)))
+            out[-1]["frac_of_mfma_peak"] = out[-1]["tflops"] / out[-1]["mfma_peak_tflops"]
+            out[-1]["frac_of_hbm_peak"] = out[-1]["alg_gbs"] / HBM_PEAK_GBS
             if fam in self.l2_bytes:
                 out[-1]["l2_gather_gbs"] = self.l2_bytes[fam] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 out[-1]["frac_of_f32_mfma_peak"] = out[-1]["tflops"] / F32_MFMA_PEAK_TFLOPS
@@ -579,10 +614,14 @@ def main():
             dom = kernels[0]
             if dom["alg_flops_per_launch"] > 0:
                 result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma",
-                                      "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
-                                      "traffic": pmc_traffic("spconv_fwd_lds_kernel<4>")[0],
-                                      "traffic_source": pmc_traffic("spconv_fwd_lds_kernel<4>")[1],
+                                      "achieved": dom["tflops"], "peak": dom["mfma_peak_tflops"],
+                                      "unit": "TFLOP/s", "frac": dom["tflops"] / dom["mfma_peak_tflops"],
+                                      "hbm_frac_of_alg_bytes": dom["frac_of_hbm_peak"],
+                                      "traffic": (pmc_traffic("spconv_fwd_lds_kernel<4>")[0]
+                                                  if dom["kernel"].startswith("spconv_fwd_kernel") else None),
+                                      "traffic_source": (pmc_traffic("spconv_fwd_lds_kernel<4>")[1]
+                                                         if dom["kernel"].startswith("spconv_fwd_kernel")
+                                                         else "no PMC pass for this kernel yet"),
                                       "traffic_note": "HBM-side bytes/launch of "
                                                       "spconv_fwd_lds_kernel<4> (the family's main "
                                                       "instantiation); algorithmic bytes/launch = "

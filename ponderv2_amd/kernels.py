@@ -56,7 +56,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor):
+    """The current stream of ``t``'s device as a hipStream_t (the raw handle: this is called once
+    per kernel launch, a few hundred times per training step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(t.device.index if t.device.index is not None
+                                           else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -630,8 +638,9 @@ def spconv16_supported(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebo
 
 
 def spconv16_forward(feats, packed, K, c_out, nbr, nbr_stride, perm, kflip, n_out,
-                     bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Output-stationary conv of 16-bit ``feats`` [n_in, c_in] with a packed weight."""
+                     bias: Optional[torch.Tensor] = None, n_pairs: int = 0) -> torch.Tensor:
+    """Output-stationary conv of 16-bit ``feats`` [n_in, c_in] with a packed weight.  (``n_pairs``:
+    the rulebook's pair count, for flop accounting by instrumentation only.)"""
     _require_device(feats, packed)
     feats = feats.contiguous()
     out = torch.empty((n_out, c_out), dtype=feats.dtype, device=feats.device)
@@ -670,7 +679,7 @@ class SparseConv16Function(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.save_for_backward(feats, weight_okc)
         return spconv16_forward(feats, fwd, K, c_out, rb.nbr, rb.nbr_stride, rb.perm, rb.kflip,
-                                rb.n_out, bias)
+                                rb.n_out, bias, n_pairs=rb.n_pairs)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -682,7 +691,7 @@ class SparseConv16Function(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nbr, stride, perm, kflip = rb._transposed_os
             g_feats = spconv16_forward(grad_out, ctx.packed_bwd, K, c_in, nbr, stride, perm, kflip,
-                                       rb.n_in)
+                                       rb.n_in, n_pairs=rb.n_pairs)
         if ctx.needs_input_grad[1]:
             g_w = spconv16_backward_weight(feats, grad_out, rb, c_out)
         if ctx.has_bias and ctx.needs_input_grad[3]:

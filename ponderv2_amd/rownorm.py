@@ -15,12 +15,19 @@ from .kernels import DTYPE_CODE, _ptr, _require_device, _stream
 
 
 _WORKSPACES = {}
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_of(device):
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _workspace(device, channels):
     """The statistics kernels' scratch (per-block partial sums, csrc/rownorm.hip): launches on one
     stream are ordered, so ONE buffer per stream serves every layer.  Grown on demand."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_of(device))
     need = int(_lib.lib().pv2_bn_workspace_floats(channels))
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:

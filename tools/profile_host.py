@@ -60,3 +60,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats("repo/", 60); print(s.getvalue()[:12000])
