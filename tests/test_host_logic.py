@@ -379,3 +379,49 @@ def test_device_voxelisation_of_a_raw_batch_equals_host_gridsample():
         assert np.array_equal(cell - cell.min(0), g)                  # representative lies in its voxel
         assert out["feat"].shape[0] == out["coord"].shape[0] == out["segment"].shape[0]
     assert out["rgb"] is raw["rgb"]                                     # everything else passes through
+
+
+def test_trainer_lookahead_stages_the_next_batch_before_yielding_the_current():
+    """Trainer.staged_batches: every loader batch comes out once, in order, already staged - and
+    batch i+1 is staged BEFORE batch i is handed to the step (so that its device-side geometry
+    overlaps step i)."""
+    from types import SimpleNamespace
+
+    from ponderv2_amd.ponder.engines.train import Trainer
+
+    events = []
+
+    def stage(b):
+        events.append(("stage", b["i"]))
+        return dict(b, _staged=True)
+
+    fake = SimpleNamespace(stage=stage)
+    seen = []
+    for b in Trainer.staged_batches(fake, [dict(i=i) for i in range(4)]):
+        events.append(("step", b["i"]))
+        seen.append(b)
+    assert [b["i"] for b in seen] == [0, 1, 2, 3] and all(b["_staged"] for b in seen)
+    assert events == [("stage", 0), ("stage", 1), ("step", 0), ("stage", 2), ("step", 1), ("stage", 3),
+                      ("step", 2), ("step", 3)]
+    assert list(Trainer.staged_batches(fake, [])) == []
+
+
+def test_small_scene_hint_and_sync_free_helpers():
+    """The host-side scene extents answer "is any scene smaller than the dense grid" without a
+    device read when no scene is near the threshold, and fall back to the exact test otherwise;
+    offset2batch with a known row count and the unchecked inverse equal the plain forms."""
+    from ponderv2_amd.ponder.models.ponder import ponder_indoor_base as pib
+    from ponderv2_amd.ponder.models.utils import offset2batch
+
+    model = type("M", (), {})()
+    model.grid_size, model.grid_shape = 0.02, (128, 128, 32)
+    fn = pib.PonderIndoor._small_scenes
+    assert fn(model, dict(extent_host=[5.3, 4.1])) == []            # no "resolution" needed at all
+    near = dict(extent_host=[5.3, 0.66], resolution=torch.tensor([264, 30]))
+    assert fn(model, near) == [1]                                     # exact test on the doubtful scene
+    assert fn(model, dict(resolution=torch.tensor([264, 30]))) == [1]  # no hint: exact test
+
+    offset = torch.tensor([3, 3, 7, 12])
+    assert torch.equal(offset2batch(offset), offset2batch(offset, 12))
+    a = torch.randn(3, 4, 4, dtype=torch.float64) + 4 * torch.eye(4, dtype=torch.float64)
+    assert torch.equal(pib._inv(a), torch.linalg.inv(a))
