@@ -442,8 +442,14 @@ def main():
                          "there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # PV2_BENCH_FORCE_DIST=1: take the multi-process path (RCCL process group, DDP wrapper, barriers,
+    # max-over-ranks timing) also with a single rank - the way to exercise it on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("PV2_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
     from ponderv2_amd import fused_head
@@ -460,9 +466,15 @@ def main():
     full = load_config(args.workload, args.config)
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
-    if world > 1:
+    if dist_on:
+        # find_unused_parameters: the ppt head is reported, never trained (quirk Q10), and the
+        # multi-dataset model trains a different condition's BatchNorms per step.  static_graph
+        # (PV2_DDP_MODE=static) is rejected by DDP for this model ("graph has changed", measured on
+        # MI355X).  Gradients live in the buckets (no copy into them: -1.9 ms per step).
+        ddp_mode = os.environ.get("PV2_DDP_MODE", "find_unused")
         step_model = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local_rank], broadcast_buffers=False, find_unused_parameters=True)
+            model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
+            find_unused_parameters=ddp_mode == "find_unused", static_graph=ddp_mode == "static")
     # optimiser + scheduler from the config's own sections, stepped every iteration as the
     # reference's run_step does (engines/train.py:185-203); the lr follows the config's rule
     # lr = base * total_batch / config_batch
@@ -523,7 +535,7 @@ def main():
         return out
 
     def timed_pass(n_steps):
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -531,11 +543,11 @@ def main():
         for _ in range(n_steps):
             out = step()
         t_cpu = time.perf_counter() - t0       # host done enqueuing (device may still be busy)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
@@ -641,7 +653,7 @@ def main():
             result["ms_per_step_with_event_instrumentation"] = 1e3 * elapsed_instr / args.steps
         if world == 1 and not args.no_cpu_baseline and args.workload == "indoor":
             result["cpu_baseline"] = cpu_baseline(args)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

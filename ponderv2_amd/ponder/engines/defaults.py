@@ -20,6 +20,7 @@ def create_ddp_model(model, *, fp16_compression=False, **kwargs):
     if "device_ids" not in kwargs and next(model.parameters()).is_cuda:
         kwargs["device_ids"] = [torch.cuda.current_device()]
         kwargs.setdefault("output_device", torch.cuda.current_device())
+    kwargs.setdefault("gradient_as_bucket_view", True)  # gradients live in the buckets: no copy
     ddp = DistributedDataParallel(model, **kwargs)
     if fp16_compression:
         from torch.distributed.algorithms.ddp_comm_hooks import default as comm_hooks
