@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--rays-per-camera", type=int, default=512, help="outdoor: RaySample.point_nsample")
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--rays-per-view", type=int, default=256)
+    ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",
+                    help="multi-GPU gradient averaging: one flat RCCL all-reduce after backward "
+                         "(utils/grad_sync.py) or torch DistributedDataParallel")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build the sparse-conv geometry inside the step (one blocking read) "
                          "instead of one batch ahead on the side stream")
@@ -466,7 +469,13 @@ def main():
     full = load_config(args.workload, args.config)
     model = build_model(ConfigDict(cfg)).to(device).train()
     step_model = model
-    if dist_on:
+    gsync = None
+    if dist_on and args.grad_sync == "flat":
+        # one flat all-reduce after backward instead of DDP's per-parameter hooks (utils/grad_sync.py)
+        from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
+
+        gsync = FlatGradSync(model.parameters(), uniform_usage=not ppt)
+    elif dist_on:
         # find_unused_parameters: the ppt head is reported, never trained (quirk Q10), and the
         # multi-dataset model trains a different condition's BatchNorms per step.  static_graph
         # (PV2_DDP_MODE=static) is rejected by DDP for this model ("graph has changed", measured on
@@ -524,10 +533,14 @@ def main():
         opt.zero_grad(set_to_none=True)
         if scaler.is_enabled():   # engines/train.py:185-196 of the reference
             scaler.scale(out["loss"]).backward()
+            if gsync is not None:
+                gsync.sync()
             scaler.step(opt)
             scaler.update()
         else:
             out["loss"].backward()
+            if gsync is not None:
+                gsync.sync()
             opt.step()
         sched.step()
         if args.print_losses and rank == 0:

@@ -136,7 +136,19 @@ class Trainer(TrainerBase):
             model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
         n = sum(p.numel() for p in model.parameters() if p.requires_grad)
         self.logger.info(f"Num params: {n}")
-        return create_ddp_model(model.to(self.device), broadcast_buffers=False,
+        model = model.to(self.device)
+        self.grad_sync = None
+        if self.cfg.get("grad_sync", "ddp") == "flat" and comm.get_world_size() > 1:
+            # one flat all-reduce after backward instead of the DDP wrapper (utils/grad_sync.py);
+            # ranks start from the same weights: broadcast rank 0's, as DDP's constructor does
+            from ..utils.grad_sync import FlatGradSync
+
+            for t in list(model.parameters()) + list(model.buffers()):
+                torch.distributed.broadcast(t.data, src=0)
+            self.grad_sync = FlatGradSync(model.parameters(),
+                                          uniform_usage=not self.cfg.find_unused_parameters)
+            return model
+        return create_ddp_model(model, broadcast_buffers=False,
                                 find_unused_parameters=self.cfg.find_unused_parameters)
 
     def build_train_loader(self):
@@ -200,6 +212,8 @@ class Trainer(TrainerBase):
         self.optimizer.zero_grad(set_to_none=True)
         if self.scaler is not None and self.scaler.is_enabled():
             self.scaler.scale(loss).backward()
+            if self.grad_sync is not None:
+                self.grad_sync.sync()
             self.scaler.step(self.optimizer)
             before = self.scaler.get_scale()
             self.scaler.update()
@@ -207,6 +221,8 @@ class Trainer(TrainerBase):
                 self.scheduler.step()
         else:
             loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync.sync()
             self.optimizer.step()
             self.scheduler.step()
         self.comm_info["model_output_dict"] = out

@@ -62,7 +62,37 @@ def grad_sync_worker(rank, world, port, out_dir):
             dist.all_reduce(avg)
             avg /= world
             worst = max(worst, (avg - g_ddp[n]).abs().max().item() / (avg.abs().max().item() + 1e-12))
-        torch.save(dict(rank=rank, worst=worst, loss=float(out["loss"]), n_grads=len(g_ddp)),
+        # the DDP-free reduction (utils/grad_sync.py) averages the same local gradients to the
+        # same result - with every rank using the same parameters ...
+        from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
+
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+        def local_backward():
+            torch.manual_seed(7)
+            model.zero_grad(set_to_none=True)
+            model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})["loss"].backward()
+
+        local_backward()
+        FlatGradSync(model.parameters(), slice_mb=0.05).sync()
+        worst_flat = max((dict(model.named_parameters())[n].grad - g_ddp[n]).abs().max().item()
+                         / (g_ddp[n].abs().max().item() + 1e-12) for n in g_ddp)
+        unused_stay_none = all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp)
+        # ... and with rank 1 skipping one parameter that rank 0 trains (the multi-dataset case):
+        # both ranks end with half of rank 0's gradient; parameters unused everywhere stay None
+        local_backward()
+        victim = dict(model.named_parameters())[sorted(g_ddp)[0]]
+        mine = victim.grad.clone()
+        if rank == 1:
+            victim.grad = None
+        FlatGradSync(model.parameters(), uniform_usage=False).sync()
+        ref0 = mine.clone()
+        dist.broadcast(ref0, src=0)
+        skip_ok = bool(victim.grad is not None and torch.allclose(victim.grad, ref0 / world, atol=1e-7)
+                       and all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp))
+        torch.save(dict(rank=rank, worst=worst, loss=float(out["loss"]), n_grads=len(g_ddp),
+                        worst_flat=worst_flat, unused_stay_none=unused_stay_none, skip_ok=skip_ok,
+                        n_params=len(names)),
                    os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

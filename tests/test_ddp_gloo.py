@@ -25,6 +25,11 @@ def test_ddp_gradients_are_rank_means(tmp_path):
     assert all(r["worst"] < 1e-5 for r in res), res
     assert res[0]["loss"] != res[1]["loss"]  # different scenes per rank (sharded, not replicated)
     assert res[0]["n_grads"] == res[1]["n_grads"] > 100
+    # the DDP-free flat reduction: same averages, unused parameters keep grad None, a parameter
+    # only one rank trains gets that rank's gradient / world on both
+    assert all(r["worst_flat"] < 1e-5 for r in res), res
+    assert all(r["unused_stay_none"] and r["skip_ok"] for r in res), res
+    assert res[0]["n_params"] > res[0]["n_grads"]   # (the model does have unused parameters)
 
 
 @pytest.mark.timeout(900)
@@ -69,6 +74,9 @@ def test_multi_dataset_trainer_outdoor_two_ranks(tmp_path):
         weight=None, resume=False, evaluate=False, seed=5, save_path=str(tmp_path), num_worker=0,
         batch_size=2, epoch=1, eval_epoch=1, sync_bn=False, enable_amp=False, empty_cache=False,
         find_unused_parameters=True, mix_prob=0, param_dicts=None,
+        # gradients averaged by ONE flat all-reduce after backward (utils/grad_sync.py) instead of
+        # the DDP wrapper; with find_unused_parameters it also exchanges the per-parameter usage
+        grad_sync="flat",
         hooks=[dict(type="CheckpointLoader"), dict(type="IterationTimer", warmup_iter=0),
                dict(type="InformationWriter"), dict(type="CheckpointSaver", save_freq=None)],
         train=dict(type="MultiDatasetTrainer"), model=model,
