@@ -236,10 +236,30 @@ __global__ __launch_bounds__(64 * NW) void spconv_os16_kernel(
 // global -> registers -> LDS, double buffered.  Waves form a WN x WC x WK grid: each owns a 64x64
 // sub-block and every WK-th 16-pair chunk of the step.  The MFMA wants 8 consecutive PAIRS of one
 // channel per lane, i.e. the transpose of how rows arrive: the fragment is assembled from eight
-// 2-byte LDS reads (consecutive lanes read consecutive channels: conflict-free).
+// 2-byte LDS reads (consecutive lanes read consecutive channels: conflict-free) - or, TR = true, by
+// gfx950's transposing read: ds_read_b64_tr_b16 hands lane c of a 16-lane group column c of the
+// 4 x 16 block whose 16 8-byte pieces the group's lanes point at (lane t: row t / 4, columns
+// 4 (t % 4) ..), i.e. four consecutive pairs of one channel in ONE LDS instruction where the scalar
+// form needs four reads and two packs.  Rows are padded by 32 bytes so that the four rows of a
+// block fall into different banks.
 constexpr int kMaxWgradTile16 = 512;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int WN, int WC>
+__device__ __forceinline__ u16x8 tr_fragment(const unsigned short* p, int row_stride) {
+  // p: this lane's piece of pairs +0..3; the second read takes pairs +4..7
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * row_stride));
+  u16x8 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = (unsigned short)lo[j];
+    v[4 + j] = (unsigned short)hi[j];
+  }
+  return v;
+}
+
+template <typename T, int WN, int WC, bool TR>
 __global__ __launch_bounds__(256) void spconv_wgrad16_kernel(
     const unsigned short* __restrict__ X, int c_in, const unsigned short* __restrict__ dY, int c_out,
     int K, const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
@@ -250,8 +270,9 @@ __global__ __launch_bounds__(256) void spconv_wgrad16_kernel(
   constexpr int CW = kStep / 16 / WK;           // 16-pair chunks per wave per step
   constexpr int TN = 64 * WN, TC = 64 * WC;
   constexpr int UA = kStep * TN / 8 / 256, UB = kStep * TC / 8 / 256;  // 16-byte pieces per thread
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][kStep * TN];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][kStep * TC];
+  constexpr int LDA = TN + (TR ? 16 : 0), LDB = TC + (TR ? 16 : 0);     // LDS row strides
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][kStep * LDA];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][kStep * LDB];
   __shared__ int s_in[kMaxWgradTile16];
   __shared__ int s_out[kMaxWgradTile16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -299,11 +320,15 @@ __global__ __launch_bounds__(256) void spconv_wgrad16_kernel(
   };
   auto store_step = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < UA; ++u)
-      *reinterpret_cast<u16x8*>(&sA[buf][(tid + 256 * u) * 8]) = ra[u];
+    for (int u = 0; u < UA; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<u16x8*>(&sA[buf][(q / (TN / 8)) * LDA + (q % (TN / 8)) * 8]) = ra[u];
+    }
 #pragma unroll
-    for (int u = 0; u < UB; ++u)
-      *reinterpret_cast<u16x8*>(&sB[buf][(tid + 256 * u) * 8]) = rb[u];
+    for (int u = 0; u < UB; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<u16x8*>(&sB[buf][(q / (TC / 8)) * LDB + (q % (TC / 8)) * 8]) = rb[u];
+    }
   };
 
   const int nsteps = (cnt + kStep - 1) / kStep;
@@ -316,16 +341,30 @@ __global__ __launch_bounds__(256) void spconv_wgrad16_kernel(
     if (more) load_step(s + 1);
 #pragma unroll
     for (int cw = 0; cw < CW; ++cw) {
-      const int pr = (wk + WK * cw) * 16 + 8 * h;  // first of this lane's 8 pairs
-      const unsigned short* A = &sA[buf][pr * TN + wn * 64 + i];
-      const unsigned short* B = &sB[buf][pr * TC + wc * 64 + i];
       u16x8 a0, a1, b0, b1;
+      if (TR) {
+        // 16-lane group g: channels 16 (g & 1) .., pairs 8 (g >> 1) ..; lane t of the group points
+        // at row t / 4, columns 4 (t % 4) .. of the group's 4 x 16 block
+        const int g = lane >> 4, t = lane & 15;
+        const int prow = (wk + WK * cw) * 16 + 8 * (g >> 1) + (t >> 2);
+        const int pcol = 16 * (g & 1) + 4 * (t & 3);
+        const unsigned short* A = &sA[buf][prow * LDA + wn * 64 + pcol];
+        const unsigned short* B = &sB[buf][prow * LDB + wc * 64 + pcol];
+        a0 = tr_fragment(A, LDA);
+        a1 = tr_fragment(A + 32, LDA);
+        b0 = tr_fragment(B, LDB);
+        b1 = tr_fragment(B + 32, LDB);
+      } else {
+        const int pr = (wk + WK * cw) * 16 + 8 * h;  // first of this lane's 8 pairs
+        const unsigned short* A = &sA[buf][pr * LDA + wn * 64 + i];
+        const unsigned short* B = &sB[buf][pr * LDB + wc * 64 + i];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        a0[j] = A[j * TN];
-        a1[j] = A[j * TN + 32];
-        b0[j] = B[j * TC];
-        b1[j] = B[j * TC + 32];
+        for (int j = 0; j < 8; ++j) {
+          a0[j] = A[j * LDA];
+          a1[j] = A[j * LDA + 32];
+          b0[j] = B[j * LDB];
+          b1[j] = B[j * LDB + 32];
+        }
       }
       acc[0][0] = T::mfma(a0, b0, acc[0][0]);
       acc[0][1] = T::mfma(a0, b1, acc[0][1]);
@@ -415,18 +454,23 @@ int launch_wgrad16(const unsigned short* X, int c_in, const unsigned short* dY, 
     pv2::set_error("pv2_spconv16_backward_weight: grid too large");
     return PV2_E_BADARG;
   }
-  if (small)
-    hipLaunchKernelGGL((spconv_wgrad16_kernel<T, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, X,
-                       c_in, dY, c_out, K, pi, po, ks, ts, tile_pairs, n_ntile, n_ctile, dW);
-  else
-    hipLaunchKernelGGL((spconv_wgrad16_kernel<T, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, X,
-                       c_in, dY, c_out, K, pi, po, ks, ts, tile_pairs, n_ntile, n_ctile, dW);
+  const bool tr = (os16_variant() & 8) == 0;  // knob bit 3: the scalar-read form
+#define PV2_WGRAD16(WN_, WC_, TR_)                                                               \
+  hipLaunchKernelGGL((spconv_wgrad16_kernel<T, WN_, WC_, TR_>), dim3((unsigned)blocks), dim3(256), \
+                     0, s, X, c_in, dY, c_out, K, pi, po, ks, ts, tile_pairs, n_ntile, n_ctile, dW)
+  if (small) {
+    if (tr) PV2_WGRAD16(1, 1, true); else PV2_WGRAD16(1, 1, false);
+  } else {
+    if (tr) PV2_WGRAD16(2, 2, true); else PV2_WGRAD16(2, 2, false);
+  }
+#undef PV2_WGRAD16
   return pv2::check_launch("spconv16_backward_weight");
 }
 
 }  // namespace
 
-// Tuning knob (tools/bench_spconv16.py): bit 0 = 64-row tiles, bit 1 = 8 waves per workgroup.
+// Tuning knob (tools/bench_spconv16.py): bit 0 = 64-row tiles, bit 1 = 8 waves per workgroup,
+// bit 3 = weight-gradient fragments by scalar LDS reads instead of ds_read_b64_tr_b16.
 static int g_os16_variant = 0;
 namespace {
 int os16_variant() { return g_os16_variant; }

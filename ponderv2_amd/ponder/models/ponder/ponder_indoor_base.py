@@ -189,8 +189,12 @@ class PonderIndoor(nn.Module):
         S_loc2[:, 2, 3] = -z_min + z_level
         S = S_loc2 @ S_scale @ S_loc  # (B,4,4)
 
-        Sp = S[batch]
-        new = (Sp[:, :3, :3] @ coords[:, :, None]).squeeze(-1) + Sp[:, :3, 3]
+        # S is a per-scene scale + translation: its 3x3 block is diagonal, so the per-point
+        # matrix-vector product (a 46 k-batch bmm of 3x3 blocks, 0.4 ms) is an elementwise
+        # multiply-add with the SAME entries - the dropped terms are exact zeros, the result is
+        # bit-identical
+        diag = torch.diagonal(S[:, :3, :3], dim1=1, dim2=2)
+        new = coords * diag[batch] + S[:, :3, 3][batch]
         new = torch.clip(new, min=-0.5 + 1e-5, max=0.5 - 1e-5).float()
 
         pose = data_dict["extrinsic"].clone().float()  # (B,V,4,4)

@@ -19,9 +19,11 @@ PERM = "--perm" in sys.argv
 if PERM:
     K.USE_OS = True
 geo = K.prepare_unet_geometry(idx, shape)
-LAYERS = [("subm0", 32, 32), ("subm1", 64, 64), ("subm2", 128, 128), ("subm3", 256, 256), ("subm4", 256, 256),
-          ("subm3", 384, 256), ("subm2", 192, 128), ("subm1", 128, 96), ("subm0", 128, 96), ("subm0", 96, 96),
-          ("spconv1", 32, 32), ("spconv2", 64, 64), ("spconv3", 128, 128), ("spconv4", 256, 256)]
+# the layer shapes of SpUNet-v1m1 (32,64,128,256,256,128,96,96) on the five levels of the bench batch
+LAYERS = [("subm1", 32, 32), ("subm2", 64, 64), ("subm3", 128, 128), ("subm4", 256, 256), ("subm3", 384, 256),
+          ("subm3", 256, 256), ("subm2", 192, 128), ("subm2", 128, 128), ("subm1", 128, 96), ("subm1", 96, 96),
+          ("subm0", 128, 96), ("subm0", 96, 96), ("spconv1", 32, 32), ("spconv2", 32, 64), ("spconv3", 64, 128),
+          ("spconv4", 128, 256)]
 dt = torch.bfloat16
 L = _lib.lib()
 
@@ -36,8 +38,8 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-variants = [0, 1, 2, 3]
-print("%-9s %4s %4s %7s %8s | " % ("layer", "cin", "cout", "rows", "pairs") + " ".join("v%d fwd/dgrad us" % v for v in variants) + " | wgrad us | weights MB(32-row)")
+variants = [0]
+print("%-9s %4s %4s %7s %8s | " % ("layer", "cin", "cout", "rows", "pairs") + " ".join("v%d fwd/dgrad us" % v for v in variants) + " | wgrad us scalar / tr | weights MB(32-row)")
 for key, c_in, c_out in LAYERS:
     rb = geo[key]["rulebook"]
     x = torch.randn(rb.n_in, c_in, device=dev).to(dt)
@@ -51,7 +53,9 @@ for key, c_in, c_out in LAYERS:
         t_f = timeit(lambda: K.spconv16_forward(x, fwd, rb.K, c_out, rb.nbr, rb.nbr_stride, rb.perm, rb.kflip, rb.n_out))
         t_b = timeit(lambda: K.spconv16_forward(g, bwd, rb.K, c_in, tn, ts, tp, tk, rb.n_in))
         cells.append("%6.1f/%6.1f" % (t_f, t_b))
-    L.pv2_debug_set_os16_variant(0)
+    L.pv2_debug_set_os16_variant(8)   # weight gradient with scalar LDS reads
+    t_w0 = timeit(lambda: K.spconv16_backward_weight(x, g, rb, c_out))
+    L.pv2_debug_set_os16_variant(0)   # ... with ds_read_b64_tr_b16
     t_w = timeit(lambda: K.spconv16_backward_weight(x, g, rb, c_out))
     mb = (rb.n_out + 31) // 32 * rb.K * c_in * c_out * 2 / 1e6
-    print("%-9s %4d %4d %7d %8d | " % (key, c_in, c_out, rb.n_out, rb.n_pairs) + "   ".join(cells) + " | %7.1f | %7.1f" % (t_w, mb))
+    print("%-9s %4d %4d %7d %8d | " % (key, c_in, c_out, rb.n_out, rb.n_pairs) + "   ".join(cells) + " | %7.1f / %7.1f | %7.1f" % (t_w0, t_w, mb))
