@@ -203,7 +203,7 @@ class KernelTimer:
 
             setattr(K, name, fn)
 
-        def conv_cost(feats, w, rb, out=None, bias=None):
+        def conv_cost(feats, w, rb, out=None, bias=None, pool=None):
             c_out, kk, c_in = w.shape
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
@@ -481,6 +481,8 @@ def main():
         # (PV2_DDP_MODE=static) is rejected by DDP for this model ("graph has changed", measured on
         # MI355X).  Gradients live in the buckets (no copy into them: -1.9 ms per step).
         ddp_mode = os.environ.get("PV2_DDP_MODE", "find_unused")
+        from ponderv2_amd import sidestream
+        sidestream.disable("DistributedDataParallel reads gradients during the backward pass")
         step_model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
             find_unused_parameters=ddp_mode == "find_unused", static_graph=ddp_mode == "static")
@@ -578,11 +580,20 @@ def main():
     # a training step that is fast but computes garbage is not a measurement: say so in the line
     loss_sane = bool(loss == loss and abs(loss) < 50.0 * max(abs(first_loss), 1.0))
     # pass 2: the SAME K steps again with HIP events around every hand-written kernel launch
+    # (weight gradients back on the main stream for this pass: an event pair around a launch that
+    # shares the GPU with another stream's kernels would time the sharing, not the kernel)
+    from ponderv2_amd import sidestream
+    side_state = sidestream.status()
     timer, elapsed_instr = None, None
     if not args.no_kernel_timing:
         timer = KernelTimer()
         timer.install()
-        elapsed_instr, _, _ = timed_pass(args.steps)
+        was_on = sidestream.ENABLED
+        sidestream.ENABLED = False
+        try:
+            elapsed_instr, _, _ = timed_pass(args.steps)
+        finally:
+            sidestream.ENABLED = was_on
 
     kernels = timer.summary() if timer else []
     if timer:
@@ -632,6 +643,7 @@ def main():
                        "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
+            "backward_side_stream": side_state,
             "render_head": ("fused ray-march kernels (csrc/raymarch_fused.hip)"
                             if fused_head.ENABLED and not outdoor else "modular (torch ops + kernels)"),
         }

@@ -21,6 +21,10 @@ def create_ddp_model(model, *, fp16_compression=False, **kwargs):
         kwargs["device_ids"] = [torch.cuda.current_device()]
         kwargs.setdefault("output_device", torch.cuda.current_device())
     kwargs.setdefault("gradient_as_bucket_view", True)  # gradients live in the buckets: no copy
+    # DDP's hooks read every gradient the moment autograd produces it: weight gradients must then
+    # be complete on the main stream, not in flight on the backward side stream
+    from ponderv2_amd import sidestream
+    sidestream.disable("DistributedDataParallel reads gradients during the backward pass")
     ddp = DistributedDataParallel(model, **kwargs)
     if fp16_compression:
         from torch.distributed.algorithms.ddp_comm_hooks import default as comm_hooks

@@ -12,7 +12,74 @@ final 1x1 conv.  These are stock dense convolutions: they go to MIOpen through P
 import torch
 import torch.nn as nn
 
+from ponderv2_amd import sidestream
 from ..builder import MODELS
+
+
+class _SplitBackwardConv(torch.autograd.Function):
+    """``nn.Conv3d`` / ``nn.ConvTranspose3d`` (the library convolution, forward unchanged) whose
+    backward is issued as its two halves: grad-input on the current stream - the next layer down
+    waits for it - and grad-weight (+ grad-bias) on the backward side stream (sidestream.py),
+    where it overlaps with the rest of the chain; stock autograd runs the two back to back on one
+    stream.  Under autocast the operands are cast here exactly as the autocast dispatch would
+    (16-bit input, weight and output; the weight gradient returns to the master weight's type)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
+        amp = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+        w, b = weight, bias
+        if amp is not None:
+            x, w = x.to(amp), weight.to(amp)
+            b = None if bias is None else bias.to(amp)
+        ctx.geom = (stride, padding, dilation, transposed, output_padding, groups)
+        ctx.bias_sizes = None if bias is None else [bias.shape[0]]
+        ctx.leaf = weight
+        ctx.save_for_backward(x, w)
+        with torch.autocast("cuda", enabled=False):
+            return torch.ops.aten.convolution(x, w, b, stride, padding, dilation, transposed,
+                                              output_padding, groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        leaf, bias_sizes = ctx.leaf, ctx.bias_sizes
+        want_b = bias_sizes is not None and ctx.needs_input_grad[2]
+        gx = gw = gb = None
+
+        def weight_half():
+            _, g_w, g_b = torch.ops.aten.convolution_backward(
+                gy, x, w, bias_sizes, *ctx.geom, [False, ctx.needs_input_grad[1], want_b])
+            if g_w is not None and g_w.dtype != leaf.dtype:
+                g_w = g_w.to(leaf.dtype)
+            if g_b is not None and g_b.dtype != leaf.dtype:
+                g_b = g_b.to(leaf.dtype)
+            return g_w, g_b
+
+        if ctx.needs_input_grad[1] or want_b:
+            if sidestream.active(gy) and sidestream.safe_leaf(leaf):
+                gw, gb = sidestream.fork(weight_half, (gy, x, w))
+            else:
+                gw, gb = weight_half()
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.geom,
+                                                     [True, False, False])[0]
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def library_conv(module, x, output_size=None):
+    """``module(x)`` for an ``nn.Conv3d`` / ``nn.ConvTranspose3d`` with its weight gradient routed
+    to the backward side stream when that applies (device tensors, training, zero padding)."""
+    if not (sidestream.ENABLED and x.is_cuda and torch.is_grad_enabled()
+            and module.weight.requires_grad and getattr(module, "padding_mode", "zeros") == "zeros"):
+        return module(x) if output_size is None else module(x, output_size)
+    transposed = isinstance(module, nn.ConvTranspose3d)
+    out_pad = (0, 0, 0)
+    if transposed:
+        out_pad = tuple(module._output_padding(x, output_size, module.stride, module.padding,
+                                               module.kernel_size, 3, module.dilation))
+    return _SplitBackwardConv.apply(x, module.weight, module.bias, tuple(module.stride),
+                                    tuple(module.padding), tuple(module.dilation), transposed,
+                                    out_pad, module.groups)
 
 
 @MODELS.register_module("SimpleConv3D-v1m1")
@@ -68,6 +135,11 @@ class SingleConv(nn.Sequential):
             else:
                 raise ValueError(f"unsupported layer type {op!r} in order {order!r}")
 
+    def forward(self, x):
+        for module in self:
+            x = library_conv(module, x) if isinstance(module, nn.Conv3d) else module(x)
+        return x
+
 
 class Encoder(nn.Module):
     def __init__(self, in_channels, out_channels, apply_pooling=True, order="bcr", num_groups=8):
@@ -89,7 +161,7 @@ class Upsampling(nn.Module):
                                            stride=scale_factor, padding=1)
 
     def forward(self, encoder_features, x):
-        return self.upsample(x, encoder_features.size()[2:])
+        return library_conv(self.upsample, x, list(encoder_features.size()[2:]))
 
 
 class Decoder(nn.Module):
@@ -156,7 +228,7 @@ class UNet3Dv1m2(nn.Module):
             skips.insert(0, x)
         for decoder, skip in zip(self.decoders, skips[1:]):
             x = decoder(skip, x)
-        x = self.final_conv(x)
+        x = library_conv(self.final_conv, x)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x)
         return x

@@ -1,0 +1,113 @@
+"""Weight gradients off the critical path: a second HIP stream for the backward pass.
+
+In the backward of a convolution the gradient of the input feeds the next layer down the chain,
+the gradient of the WEIGHT feeds nothing until the optimizer (or the gradient all-reduce) runs
+after the whole backward.  The reference leaves both on one stream (autograd's default); here the
+weight-gradient launches of the sparse convs (kernels.py) and of the dense projection network
+(models/ponder/unet3d.py) go to a per-device side stream:
+
+    main stream   ... BN backward -> grad-input(l) -> BN backward -> grad-input(l-1) -> ...
+    side stream          wgrad(l) ------------> wgrad(l-1) ---------------> ...
+
+Most kernels of the path do not fill 256 CUs on their own (a few hundred workgroups, long tails,
+atomics-bound scatter phases), so the two chains overlap instead of adding up.  One event makes
+the side stream wait for the producer of its operands (``fork``); ONE join at the end of the
+backward pass (an autograd-engine final callback) makes the caller's stream wait for the side
+stream, so everything that runs after ``loss.backward()`` returns - GradScaler, gradient clipping,
+FlatGradSync, the optimizer - sees finished gradients.
+
+What must NOT be combined with it: consumers that read a gradient WHILE the backward is still
+running, i.e. ``DistributedDataParallel`` (its per-parameter hooks copy gradients into buckets as
+autograd produces them).  ``ponder.engines.defaults.create_ddp_model`` and ``bench.py --grad-sync
+ddp`` therefore call ``disable()``; the flat gradient sync (utils/grad_sync.py) reduces after the
+backward and keeps it on.  Gradients that autograd would ACCUMULATE on the spot (``param.grad``
+already set: gradient accumulation over micro-batches) are computed on the main stream as before
+(``safe_leaf``).  ``PV2_WGRAD_STREAM=0`` switches the side stream off altogether.
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get("PV2_WGRAD_STREAM", "1") != "0"
+_DISABLED_BECAUSE = None
+_STREAMS = {}
+_JOIN_QUEUED = {}   # device index -> id of the graph task whose final callback joins the stream
+
+
+def disable(reason="disabled by the caller"):
+    """Keep every weight gradient on the main stream from now on (e.g. under DDP)."""
+    global ENABLED, _DISABLED_BECAUSE
+    ENABLED, _DISABLED_BECAUSE = False, reason
+
+
+def enable():
+    global ENABLED, _DISABLED_BECAUSE
+    ENABLED, _DISABLED_BECAUSE = os.environ.get("PV2_WGRAD_STREAM", "1") != "0", None
+
+
+def status():
+    return "on" if ENABLED else f"off ({_DISABLED_BECAUSE or 'PV2_WGRAD_STREAM=0'})"
+
+
+def stream(device):
+    s = _STREAMS.get(device.index)
+    if s is None:
+        # PV2_WGRAD_PRIORITY: 0 = the main stream's priority (default), 1 = lower (the hardware
+        # queues then prefer the critical chain whenever both have workgroups ready)
+        prio = int(os.environ.get("PV2_WGRAD_PRIORITY", "0"))
+        s = _STREAMS[device.index] = torch.cuda.Stream(device=device, priority=prio)
+    return s
+
+
+def _graph_task_id():
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return fn() if fn is not None else -1
+
+
+def active(t):
+    """True inside an autograd backward pass on a device tensor while the side stream is on."""
+    return ENABLED and t.is_cuda and _graph_task_id() != -1
+
+
+def safe_leaf(param_view):
+    """The gradient handed to autograd for this tensor will only be STORED as ``.grad`` of a leaf -
+    no kernel of the main stream touches it before the join: the tensor is a parameter or a plain
+    view of one (a copy, e.g. ``permute().contiguous()``, sends its gradient through further
+    autograd kernels), and that parameter has no ``.grad`` yet to be added to."""
+    base = param_view._base if param_view._base is not None else param_view
+    return base.is_leaf and base.grad is None
+
+
+def _queue_join(device, side):
+    task = _graph_task_id()
+    if _JOIN_QUEUED.get(device.index) == task:
+        return
+    _JOIN_QUEUED[device.index] = task
+
+    def join():
+        # final callbacks run under the stream that surrounded the call to backward()
+        _JOIN_QUEUED.pop(device.index, None)
+        torch.cuda.current_stream(device).wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def fork(fn, reads):
+    """Run ``fn()`` (which launches kernels and returns a tensor or a tuple of tensors) on the
+    side stream, after everything the current stream has queued so far; ``reads``: the tensors it
+    reads that the current stream produced or may free.  The caller's stream joins at the end of
+    the running backward pass."""
+    device = reads[0].device
+    cur = torch.cuda.current_stream(device)
+    side = stream(device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for t in reads:
+            if t is not None:
+                t.record_stream(side)     # freed by the main stream's owner, still read over here
+        out = fn()
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        if torch.is_tensor(t):
+            t.record_stream(cur)          # allocated over there, consumed after the join over here
+    _queue_join(device, side)
+    return out

@@ -166,24 +166,31 @@ def run_neus(device, return_values=False):
     return errs
 
 
-def run_ponder_indoor(device):
+def small_indoor(device):
+    """The miniature PonderIndoor of the ``ponder_indoor_small`` fixture (deterministic weights) and
+    its two-scene batch, without the fixture's recorded random draws."""
     from ponderv2_amd.ponder.datasets import collate_fn, make_scene
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    g = np.load(os.path.join(GOLDEN, "ponder_indoor_small.npz"))
     cfg = indoor_model_cfg(dict(SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
                            grid_shape=(32, 32, 8), ray_nsample=20)
     cfg["template"] = ("a", "b")  # any template list: the stub embeddings do not depend on it
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()
-    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
-    model.renderer.sampler.initial_sampler.rand = replay
-    model.renderer.sampler.pdf_sampler.rand = replay
     kw = dict(n_raw=16000, num_views=2, image_hw=(48, 64))
     batch = collate_fn([make_scene(100, **kw), make_scene(101, **kw)])
     batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return model, batch
+
+
+def run_ponder_indoor(device):
+    g = np.load(os.path.join(GOLDEN, "ponder_indoor_small.npz"))
+    model, batch = small_indoor(device)
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
     batch["ray_pixels"] = torch.from_numpy(g["ray_pixels"])
     out = model(batch)
     out["loss"].backward()

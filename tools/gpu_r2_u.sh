@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-2 trip U: GPU test suite + A/B of the backward side stream and the zero arenas.
+set -u
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/u_pytest.txt 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/u_pytest.txt
+ab() {  # tag, env..., -- bench args
+  tag=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 200 python bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 "$@" \
+      > gpurun_out/u_ab_$tag.json 2> gpurun_out/u_ab_$tag.err
+  python - "$tag" <<'PY'
+import json,sys
+tag=sys.argv[1]
+try:
+    d=json.loads(open(f"gpurun_out/u_ab_{tag}.json").read().strip().splitlines()[-1])
+    print(f"{tag:28s} {d['ms_per_step']:7.2f} ms/step  host {d['host_enqueue_ms_per_step']:6.2f}  loss {d['final_loss']:.4f}  side={d.get('backward_side_stream')}")
+except Exception as e:
+    print(tag, "FAILED", e); print(open(f"gpurun_out/u_ab_{tag}.err").read()[-600:])
+PY
+}
+ab f32_off_off   PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 --
+ab f32_side      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 --
+ab f32_arena     PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 --
+ab f32_both      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 --
+ab f32_both_lowp PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_WGRAD_PRIORITY=1 --
+ab bf16_off_off  PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 -- --amp bf16
+ab bf16_both     PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 -- --amp bf16
