@@ -1256,7 +1256,9 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
   const bool big_n = k1 > 64, big_c = k2 > 64;
   const int n_ntile = (k1 + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
   const int n_ctile = (k2 + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
-  const int tile_pairs = PV2_WGRAD_TILE;
+  // every workgroup ends with one atomic add per element of its block of C: very tall operands
+  // (the 1x1x1 convolution over a million grid cells) take the longest run the kernel supports
+  const int tile_pairs = m >= (int64_t)PV2_WGRAD_TILE * 1024 ? kMaxWgradTile : PV2_WGRAD_TILE;
   const int64_t blocks = ((m + tile_pairs - 1) / tile_pairs) * n_ntile * n_ctile;
   hipStream_t s = (hipStream_t)stream;
 #define PV2_LAUNCH_TN(WN, WC, WK)                                                                \

@@ -9,6 +9,8 @@ ConvTranspose3d(k3, s2, p1, output_size=skip size) + summation joining in the de
 final 1x1 conv.  These are stock dense convolutions: they go to MIOpen through PyTorch-ROCm
 (north_star names no custom kernel for them); parameter names match the reference.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -66,9 +68,94 @@ class _SplitBackwardConv(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _PointwiseConv(torch.autograd.Function):
+    """1x1x1 convolution of a channels-last volume = ONE tall GEMM over its rows (cells x C_in) .
+    W^T + bias, on the MFMA kernels of ponderv2_amd.linear (``pv2_gemm_nt`` / ``pv2_gemm_tn``).
+    The U-Net's ``final_conv`` maps 32 -> 128 channels on every one of the 128x128x32 cells: a
+    bandwidth-bound pass over 134 MB in and 537 MB out.  Through the convolution library it was a
+    GEMM in the other layout plus a separate bias pass plus a 537 MB layout conversion on the way
+    to the channels-last sampler, and a 0.64 ms skinny BLAS reduction for the weight gradient
+    (1.9 ms per step in all, profiles/r02_rocprofv3_kernel_stats_v7_f32.csv); here the result is
+    written once, bias included, in the layout the ray march gathers from.  fp32 out whatever
+    the input type (autocast would hand the ray march a 16-bit volume to widen again)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from ponderv2_amd import _lib
+        from ponderv2_amd.kernels import _ptr, _stream
+
+        b, c, z, y, xx = x.shape
+        n = weight.shape[0]
+        rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c)          # a view of a channels-last volume
+        rows = rows.float().contiguous()
+        w2 = weight.reshape(n, c).float().contiguous()
+        bias32 = None if bias is None else bias.float().contiguous()
+        out = torch.empty((rows.shape[0], n), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().pv2_gemm_nt(_ptr(rows), rows.shape[0], c, _ptr(w2), n, _ptr(bias32),
+                                          _ptr(out), _stream(rows)), "pv2_gemm_nt")
+        ctx.save_for_backward(rows, w2)
+        ctx.leaf, ctx.has_bias, ctx.x_dtype, ctx.w_shape = weight, bias is not None, x.dtype, weight.shape
+        return out.view(b, z, y, xx, n).permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ponderv2_amd import _lib
+        from ponderv2_amd.kernels import _ptr, _stream
+
+        rows, w2 = ctx.saved_tensors
+        n, c = w2.shape
+        b, _, z, y, xx = gy.shape
+        g = gy.permute(0, 2, 3, 4, 1).reshape(-1, n).float().contiguous()
+        m = g.shape[0]
+        L = _lib.lib()
+        gx = gw = gb = None
+
+        def weight_half():
+            g_w = g_b = None
+            if ctx.needs_input_grad[1]:
+                g_w = torch.empty((n, c), dtype=torch.float32, device=g.device)
+                _lib.check(L.pv2_zero_fill(_ptr(g_w), g_w.numel() * 4, _stream(g)), "pv2_zero_fill")
+                _lib.check(L.pv2_gemm_tn(_ptr(g), _ptr(rows), m, n, c, _ptr(g_w), _stream(g)),
+                           "pv2_gemm_tn")
+                g_w = g_w.view(ctx.w_shape)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                g_b = torch.empty(n, dtype=torch.float32, device=g.device)
+                _lib.check(L.pv2_col_sum(_ptr(g), m, n, _ptr(g_b), _stream(g)), "pv2_col_sum")
+            return g_w, g_b
+
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if sidestream.active(g) and sidestream.safe_leaf(ctx.leaf):
+                gw, gb = sidestream.fork(weight_half, (g, rows))
+            else:
+                gw, gb = weight_half()
+        if ctx.needs_input_grad[0]:
+            wt = w2.t().contiguous()                               # [c, n]: grad-input = g . W
+            gx = torch.empty((m, c), dtype=torch.float32, device=g.device)
+            _lib.check(L.pv2_gemm_nt(_ptr(g), m, n, _ptr(wt), c, None, _ptr(gx), _stream(g)),
+                       "pv2_gemm_nt")
+            gx = gx.view(b, z, y, xx, c).permute(0, 4, 1, 2, 3)
+            if ctx.x_dtype != torch.float32:
+                gx = gx.to(ctx.x_dtype)
+        return gx, gw, gb
+
+
+def pointwise_conv_supported(module, x):
+    """``module`` is a 1x1x1 / stride 1 / unpadded ``nn.Conv3d`` and ``x`` a device volume whose
+    channel counts the tall GEMM kernels take (C_in % 8 == 0, C_out % 4 == 0)."""
+    return (isinstance(module, nn.Conv3d) and x.is_cuda and x.dim() == 5
+            and tuple(module.kernel_size) == (1, 1, 1) and tuple(module.stride) == (1, 1, 1)
+            and tuple(module.padding) == (0, 0, 0) and tuple(module.dilation) == (1, 1, 1)
+            and module.groups == 1 and module.weight.dtype == torch.float32
+            and module.in_channels % 8 == 0 and module.out_channels % 4 == 0
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and os.environ.get("PV2_POINTWISE_CONV", "1") != "0")
+
+
 def library_conv(module, x, output_size=None):
     """``module(x)`` for an ``nn.Conv3d`` / ``nn.ConvTranspose3d`` with its weight gradient routed
     to the backward side stream when that applies (device tensors, training, zero padding)."""
+    if output_size is None and pointwise_conv_supported(module, x):
+        return _PointwiseConv.apply(x, module.weight, module.bias)
     if not (sidestream.ENABLED and x.is_cuda and torch.is_grad_enabled()
             and module.weight.requires_grad and getattr(module, "padding_mode", "zeros") == "zeros"):
         return module(x) if output_size is None else module(x, output_size)

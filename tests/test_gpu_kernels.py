@@ -669,3 +669,41 @@ def test_prefetched_geometry_equals_the_blocking_build(device, monkeypatch):
         a, b = geo_a[key]["rulebook"], geo_b[key]["rulebook"]
         assert np.array_equal(a.kstart_host, b.kstart_host)
         assert torch.equal(a.pair_in, b.pair_in) and torch.equal(a.pair_out, b.pair_out)
+
+
+@pytest.mark.parametrize("shape,c_in,c_out,bias", [((2, 16, 32, 32), 32, 128, True),
+                                                   ((1, 32, 128, 128), 32, 128, True),   # >= 512 k rows: the long-run reduction
+                                                   ((1, 8, 24, 20), 64, 36, False)])
+def test_pointwise_conv_equals_the_library_conv(device, shape, c_in, c_out, bias):
+    """UNet3D's final 1x1x1 convolution as one tall GEMM over the channels-last rows
+    (unet3d._PointwiseConv on pv2_gemm_nt / pv2_gemm_tn / pv2_col_sum) against ``F.conv3d`` in
+    float64: output, grad-input, grad-weight, grad-bias."""
+    import torch.nn as nn
+
+    from ponderv2_amd.ponder.models.ponder import unet3d as U
+
+    torch.manual_seed(0)
+    b, z, y, x = shape
+    conv = nn.Conv3d(c_in, c_out, 1, bias=bias).to(device)
+    inp = torch.randn(b, c_in, z, y, x, device=device).contiguous(memory_format=torch.channels_last_3d)
+    inp.requires_grad_(True)
+    assert U.pointwise_conv_supported(conv, inp)
+    out = U.library_conv(conv, inp)
+    assert out.is_contiguous(memory_format=torch.channels_last_3d) and out.dtype == torch.float32
+    g = torch.randn(b, z, y, x, c_out, device=device).permute(0, 4, 1, 2, 3)   # as the ray march hands it back
+    out.backward(g)
+    torch.cuda.synchronize()
+    conv64 = nn.Conv3d(c_in, c_out, 1, bias=bias).to(device).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    inp64 = inp.detach().double().requires_grad_(True)
+    ref = conv64(inp64)
+    ref.backward(g.double())
+
+    def rel(a, b_):
+        return float((a.double() - b_).abs().max() / b_.abs().max())
+
+    assert rel(out, ref) < 1e-5
+    assert rel(inp.grad, inp64.grad) < 1e-5
+    assert rel(conv.weight.grad, conv64.weight.grad) < 2e-5     # sums over up to 524 288 rows
+    if bias:
+        assert rel(conv.bias.grad, conv64.bias.grad) < 2e-5

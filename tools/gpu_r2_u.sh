@@ -2,7 +2,7 @@
 # Round-2 trip U: GPU test suite + A/B of the backward side stream and the zero arenas.
 set -u
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/u_pytest.txt 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/u_pytest.txt
+timeout 600 python -m pytest tests -m gpu -q > gpurun_out/u_pytest.txt 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/u_pytest.txt | tail -15
 ab() {  # tag, env..., -- bench args
   tag=$1; shift
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
@@ -18,10 +18,12 @@ except Exception as e:
     print(tag, "FAILED", e); print(open(f"gpurun_out/u_ab_{tag}.err").read()[-600:])
 PY
 }
-ab f32_off_off   PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 --
-ab f32_side      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 --
-ab f32_arena     PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 --
-ab f32_both      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 --
-ab f32_both_lowp PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_WGRAD_PRIORITY=1 --
-ab bf16_off_off  PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 -- --amp bf16
-ab bf16_both     PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 -- --amp bf16
+OFF="PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0"
+ab f32_base      $OFF --
+ab f32_pointwise PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=1 --
+ab f32_side      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0 --
+ab f32_arena     PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=0 --
+ab f32_all       PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 --
+ab f32_all_lowp  PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 PV2_WGRAD_PRIORITY=1 --
+ab bf16_base     $OFF -- --amp bf16
+ab bf16_all      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 -- --amp bf16
