@@ -580,6 +580,16 @@ def _finish_unet_geometry(state, host) -> dict:
 # --------------------------------------------------------------------------------------------
 # Sparse conv arithmetic
 # --------------------------------------------------------------------------------------------
+_FWD_TILE = {}
+
+
+def _forward_tile(c_in: int, c_out: int) -> int:
+    t = _FWD_TILE.get((c_in, c_out))
+    if t is None:
+        t = _FWD_TILE[(c_in, c_out)] = int(_lib.lib().pv2_spconv_forward_tile(c_in, c_out))
+    return t
+
+
 def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
                    out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
                    pool: str = "act") -> torch.Tensor:
@@ -608,7 +618,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
             "pv2_spconv_os_forward")
         return out
     assert bias is None or out is None, "bias is fused only by the output-stationary path"
-    tile = L.pv2_spconv_forward_tile(c_in, c_out)
+    tile = _forward_tile(c_in, c_out)
     tile_start, n_tiles, tile_host = rb.tiles(tile)
     c_lo = c_hi = 0
     if out is None:
@@ -815,9 +825,11 @@ class SparseConvIntoFunction(torch.autograd.Function):
         rb = ctx.rb
         grad_out = grad_out.contiguous()
         g_feats = g_w = None
-        if ctx.needs_input_grad[1]:   # first: it leaves for the side stream (sidestream.py)
-            g_w = _weight_grad(lambda: spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0]),
-                               weight_okc, grad_out, feats)
+        # (on the current stream: the one caller, sparse_input.conv3d_on_cells, uses its weight a
+        # second time for the constant part - autograd ADDS the two weight gradients on the main
+        # stream the moment both exist, so this one must be complete there, not in flight)
+        if ctx.needs_input_grad[1]:
+            g_w = spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0])
         if ctx.needs_input_grad[0]:
             g_feats = spconv_grad_input(grad_out, weight_okc, rb)
         return g_feats, g_w, None, grad_out

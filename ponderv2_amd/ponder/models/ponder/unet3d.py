@@ -141,12 +141,13 @@ class _PointwiseConv(torch.autograd.Function):
 
 def pointwise_conv_supported(module, x):
     """``module`` is a 1x1x1 / stride 1 / unpadded ``nn.Conv3d`` and ``x`` a device volume whose
-    channel counts the tall GEMM kernels take (C_in % 8 == 0, C_out % 4 == 0)."""
+    channel counts the tall GEMM kernels take (both multiples of 8: each is the reduction width of
+    one of the two passes)."""
     return (isinstance(module, nn.Conv3d) and x.is_cuda and x.dim() == 5
             and tuple(module.kernel_size) == (1, 1, 1) and tuple(module.stride) == (1, 1, 1)
             and tuple(module.padding) == (0, 0, 0) and tuple(module.dilation) == (1, 1, 1)
             and module.groups == 1 and module.weight.dtype == torch.float32
-            and module.in_channels % 8 == 0 and module.out_channels % 4 == 0
+            and module.in_channels % 8 == 0 and module.out_channels % 8 == 0
             and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
             and os.environ.get("PV2_POINTWISE_CONV", "1") != "0")
 

@@ -15,6 +15,7 @@ from .kernels import DTYPE_CODE, _ptr, _require_device, _stream
 
 
 _WORKSPACES = {}
+_WS_FLOATS = {}
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -28,7 +29,9 @@ def _workspace(device, channels):
     """The statistics kernels' scratch (per-block partial sums, csrc/rownorm.hip): launches on one
     stream are ordered, so ONE buffer per stream serves every layer.  Grown on demand."""
     key = (device.index, _stream_of(device))
-    need = int(_lib.lib().pv2_bn_workspace_floats(channels))
+    need = _WS_FLOATS.get(channels)
+    if need is None:
+        need = _WS_FLOATS[channels] = int(_lib.lib().pv2_bn_workspace_floats(channels))
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 64 * 2 * 256), dtype=torch.float32, device=device)

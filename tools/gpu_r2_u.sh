@@ -20,10 +20,9 @@ PY
 }
 OFF="PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0"
 ab f32_base      $OFF --
-ab f32_pointwise PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=1 --
-ab f32_side      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0 --
-ab f32_arena     PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=0 --
 ab f32_all       PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 --
-ab f32_all_lowp  PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 PV2_WGRAD_PRIORITY=1 --
 ab bf16_base     $OFF -- --amp bf16
+ab bf16_side     PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0 -- --amp bf16
+ab bf16_arena    PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=0 -- --amp bf16
+ab bf16_pointwise PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=1 -- --amp bf16
 ab bf16_all      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 -- --amp bf16
