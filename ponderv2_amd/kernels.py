@@ -80,66 +80,14 @@ def _zero_fill(t):
     return t
 
 
-# Zero arenas.  The scatter-add kernels accumulate onto cleared buffers: ~160 of them per training
-# step (conv outputs, grad-input outputs, weight gradients), each cleared by its own 5 us launch
-# behind its own host call.  ``begin_zero_arenas`` (called once per step, by the backbone's
-# forward) clears ONE buffer per pool instead, sized by what the previous step asked for, and
-# ``zeros_by_kernel(..., pool=...)`` hands out 256-byte aligned slices of it; whatever does not
-# fit (first step, a larger batch) is cleared individually as before.  A slice is handed out once,
-# so "cleared" holds; the pools are separate allocations because their lifetimes differ
-# (activations and input gradients die with the backward pass, weight gradients live on as
-# ``param.grad`` until the next zero_grad).  PV2_ZERO_ARENA=0 switches the arenas off.
-USE_ZERO_ARENA = os.environ.get("PV2_ZERO_ARENA", "1") != "0"
-ZERO_POOLS = ("act", "dgrad", "dw")
-_ARENA_MAX_FLOATS = 1 << 29   # 2 GiB per pool
+def zeros_by_kernel(shape, dtype, device):
+    """torch.zeros, but cleared by a kernel launch on the current stream (see pv2_zero_fill).
 
-
-class _ZeroArena:
-    __slots__ = ("buf", "used", "asked", "streams")
-
-    def __init__(self):
-        self.buf, self.used, self.asked, self.streams = None, 0, 0, ()
-
-
-_ARENAS = {}   # (device index, pool) -> _ZeroArena
-
-
-def begin_zero_arenas(device, with_backward=True):
-    """Start a step: one cleared fp32 buffer per pool on the current stream of ``device``."""
-    if not USE_ZERO_ARENA or device.type != "cuda":
-        return
-    for pool in ZERO_POOLS:
-        a = _ARENAS.get((device.index, pool))
-        if a is None:
-            a = _ARENAS[(device.index, pool)] = _ZeroArena()
-        # previous step's demand + 6 % head-room; nothing on the first step (sizes unknown)
-        want = min((int(a.asked * 1.0625) + 64) & ~63, _ARENA_MAX_FLOATS) if a.asked else 0
-        a.asked, a.used, a.buf, a.streams = 0, 0, None, ()
-        if want and (pool == "act" or with_backward):
-            a.buf = _zero_fill(torch.empty(want, dtype=torch.float32, device=device))
-            a.streams = (_stream(a.buf).value,)
-
-
-def zeros_by_kernel(shape, dtype, device, pool=None):
-    """torch.zeros, but cleared by a kernel launch on the current stream (see pv2_zero_fill), or -
-    for fp32 tensors asked for with a ``pool`` while a step's arenas are open - a slice of that
-    pool's arena, cleared at the start of the step."""
-    if pool is not None and dtype == torch.float32 and USE_ZERO_ARENA and device.type == "cuda":
-        a = _ARENAS.get((device.index, pool))
-        if a is not None:
-            n = 1
-            for d in shape:
-                n *= int(d)
-            span = (n + 63) & ~63
-            a.asked += span
-            if a.buf is not None and a.used + span <= a.buf.numel():
-                t = a.buf[a.used:a.used + n].view(shape)
-                a.used += span
-                st = _stream(t).value
-                if st not in a.streams:   # cleared on one stream, consumed on another (side stream)
-                    a.streams += (st,)
-                    a.buf.record_stream(torch.cuda.current_stream(device))
-                return t
+    Each scatter-add target is cleared by its own launch RIGHT BEFORE the kernel that accumulates
+    onto it.  Clearing all ~160 targets of a step from one arena at the start of the step was tried
+    (one fill per arena instead of 160 launches) and measured on MI355X: neutral in fp32 (32.9 vs
+    33.0 ms per step), 6.5 ms SLOWER under --amp bf16 (31.8 vs 25.3 ms) - the atomics then land on
+    lines that have long left the L2 / Infinity Cache instead of lines the fill has just written."""
     return _zero_fill(torch.empty(shape, dtype=dtype, device=device))
 
 
@@ -591,8 +539,7 @@ def _forward_tile(c_in: int, c_out: int) -> int:
 
 
 def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
-                   out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-                   pool: str = "act") -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[pair_out] += W[k] . feats[pair_in].  weight_okc: fp32 [c_out, K, c_in] contiguous.
     With a gather table on the rulebook (and no tensor to accumulate onto) the output-stationary
     kernel computes ``bias + conv`` and writes every element once."""
@@ -627,7 +574,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
             c_lo, c_hi = int(tile_host[rb.center_k]), int(tile_host[rb.center_k + 1])
             out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
         else:
-            out = zeros_by_kernel((rb.n_out, c_out), torch.float32, feats.device, pool)
+            out = zeros_by_kernel((rb.n_out, c_out), torch.float32, feats.device)
     _lib.check(L.pv2_spconv_forward(
         _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(rb.pair_in),
         _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, c_lo, c_hi, _ptr(out),
@@ -643,7 +590,7 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     grad_out = grad_out.contiguous()
     c_in = feats.shape[1]
     assert grad_out.shape == (rb.n_out, c_out) and feats.shape[0] == rb.n_in
-    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device, "dw")
+    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
     L = _lib.lib()
     if tile is None:
         tile = L.pv2_spconv_wgrad_tile(c_in, c_out, rb.n_pairs, rb.K)
@@ -669,13 +616,13 @@ def spconv_grad_input(grad_out: torch.Tensor, weight_okc: torch.Tensor, rb: Rule
         weight_okc = weight_okc.contiguous()
         L = _lib.lib()
         tile_start, n_tiles, _ = rbt.tiles(FWD_LDS_TILE)
-        out = zeros_by_kernel((rbt.n_out, c_in), torch.float32, grad_out.device, "dgrad")
+        out = zeros_by_kernel((rbt.n_out, c_in), torch.float32, grad_out.device)
         _lib.check(L.pv2_spconv_forward_wt(
             _ptr(grad_out), rbt.n_in, c_out, _ptr(weight_okc), K, c_in, _ptr(rbt.pair_in),
             _ptr(rbt.pair_out), _ptr(rbt.kstart), _ptr(tile_start), FWD_LDS_TILE, n_tiles, _ptr(out),
             rbt.n_out, _stream(grad_out)), "pv2_spconv_forward_wt")
         return out
-    return spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(), rbt, pool="dgrad")
+    return spconv_forward(grad_out, weight_okc.permute(2, 1, 0).contiguous(), rbt)
 
 
 # --------------------------------------------------------------------------------------------
@@ -729,7 +676,7 @@ def spconv16_backward_weight(feats, grad_out, rb: Rulebook, c_out: int) -> torch
     feats, grad_out = feats.contiguous(), grad_out.contiguous()
     assert feats.dtype == grad_out.dtype and feats.dtype in HALF_DTYPES
     c_in = feats.shape[1]
-    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device, "dw")
+    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
     tile_start, n_tiles, _ = rb.tiles(WGRAD_TILE)
     _lib.check(_lib.lib().pv2_spconv16_backward_weight(
         _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, DTYPE_CODE[feats.dtype], rb.K,

@@ -76,8 +76,7 @@ class _PointwiseConv(torch.autograd.Function):
     GEMM in the other layout plus a separate bias pass plus a 537 MB layout conversion on the way
     to the channels-last sampler, and a 0.64 ms skinny BLAS reduction for the weight gradient
     (1.9 ms per step in all, profiles/r02_rocprofv3_kernel_stats_v7_f32.csv); here the result is
-    written once, bias included, in the layout the ray march gathers from.  fp32 out whatever
-    the input type (autocast would hand the ray march a 16-bit volume to widen again)."""
+    written once, bias included, in the layout the ray march gathers from.  fp32 volumes only."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -148,7 +147,8 @@ def pointwise_conv_supported(module, x):
             and tuple(module.padding) == (0, 0, 0) and tuple(module.dilation) == (1, 1, 1)
             and module.groups == 1 and module.weight.dtype == torch.float32
             and module.in_channels % 8 == 0 and module.out_channels % 8 == 0
-            and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and x.dtype == torch.float32    # (16-bit volumes: the library's 16-bit GEMM moves half
+                                             #  the bytes - measured 0.45 ms per step faster there)
             and os.environ.get("PV2_POINTWISE_CONV", "1") != "0")
 
 

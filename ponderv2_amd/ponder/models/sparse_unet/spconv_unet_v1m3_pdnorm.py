@@ -301,9 +301,6 @@ class SpUNetBase(nn.Module):
             spatial_shape=sparse_shape, batch_size=offset.numel(),
             indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape,
                                        input_dict.get("geometry")))
-        if feat.is_cuda:   # one cleared buffer per pool for this step's scatter-add targets
-            from ponderv2_amd import kernels as K
-            K.begin_zero_arenas(feat.device, with_backward=torch.is_grad_enabled())
         x = self.conv_input([x, condition, context])
         skips = [x]
         for s in range(self.num_stages):

@@ -18,11 +18,13 @@ except Exception as e:
     print(tag, "FAILED", e); print(open(f"gpurun_out/u_ab_{tag}.err").read()[-600:])
 PY
 }
-OFF="PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0"
-ab f32_base      $OFF --
-ab f32_all       PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 --
-ab bf16_base     $OFF -- --amp bf16
-ab bf16_side     PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=0 -- --amp bf16
-ab bf16_arena    PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=0 -- --amp bf16
-ab bf16_pointwise PV2_WGRAD_STREAM=0 PV2_ZERO_ARENA=0 PV2_POINTWISE_CONV=1 -- --amp bf16
-ab bf16_all      PV2_WGRAD_STREAM=1 PV2_ZERO_ARENA=1 PV2_POINTWISE_CONV=1 -- --amp bf16
+OLD="PV2_WGRAD_STREAM=0 PV2_POINTWISE_CONV=0 PV2_PREFETCH_RAYS=0"
+ab f32_old        $OLD -- --no-stage-thread
+ab f32_side_pw    PV2_PREFETCH_RAYS=0 -- --no-stage-thread
+ab f32_thread     PV2_PREFETCH_RAYS=0 --
+ab f32_rays       PV2_PREFETCH_RAYS=1 -- --no-stage-thread
+ab f32_thread_rays PV2_PREFETCH_RAYS=1 --
+ab bf16_old       $OLD -- --no-stage-thread --amp bf16
+ab bf16_side      PV2_PREFETCH_RAYS=0 -- --no-stage-thread --amp bf16
+ab bf16_thread    PV2_PREFETCH_RAYS=0 -- --amp bf16
+ab bf16_thread_rays PV2_PREFETCH_RAYS=1 -- --amp bf16
