@@ -80,8 +80,6 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build the sparse-conv geometry inside the step (one blocking read) "
                          "instead of one batch ahead on the side stream")
-    ap.add_argument("--no-stage-thread", action="store_true",
-                    help="stage the next batch on the training thread (no second host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dense-dtype", default="float32", choices=["bfloat16", "float16", "float32"],
@@ -526,17 +524,12 @@ def main():
         b = clone_batch(batches[i % len(batches)])
         return raw_model.prefetch(b) if lookahead else b
 
-    # ... and the staging itself runs on a second host thread (utils/staging.py): its ~250 launches
-    # per batch no longer queue up behind the step's own ~2000 on the training thread
-    from ponderv2_amd.ponder.utils.staging import BackgroundStager
-
-    stager = BackgroundStager(stage, device, enabled=lookahead and not args.no_stage_thread)
-    staged = [stager.submit(0)]
+    staged = [stage(0)]
 
     def step():
-        cur = staged.pop().result()
+        cur = staged.pop()
         counter[0] += 1
-        staged.append(stager.submit(counter[0]))
+        staged.append(stage(counter[0]))
         with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
             out = step_model(cur)
         opt.zero_grad(set_to_none=True)
@@ -651,7 +644,6 @@ def main():
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
             "backward_side_stream": side_state,
-            "input_staging": ("second host thread" if stager.threaded else "training thread"),
             "render_head": ("fused ray-march kernels (csrc/raymarch_fused.hip)"
                             if fused_head.ENABLED and not outdoor else "modular (torch ops + kernels)"),
         }

@@ -192,22 +192,14 @@ class Trainer(TrainerBase):
         """One batch of lookahead: batch i+1 is staged (``stage``) BEFORE step i is enqueued, so its
         geometry builds overlap step i on the device and step i+1 starts without a host stall -
         the counterpart of the reference's dataloader workers for the device-side input work."""
-        # ``stage`` itself runs on a second host thread (utils/staging.py; config ``stage_thread``,
-        # default on): its launches overlap the training thread's instead of queueing behind them
-        from ..utils.staging import BackgroundStager
-
-        stager = BackgroundStager(self.stage, self.device, enabled=self.cfg.get("stage_thread", True))
-        try:
-            it = iter(loader)
-            nxt = next(it, None)
-            nxt = stager.submit(nxt) if nxt is not None else None
-            while nxt is not None:
-                cur, nxt = nxt, next(it, None)
-                if nxt is not None:
-                    nxt = stager.submit(nxt)
-                yield cur.result()
-        finally:
-            stager.shutdown()
+        it = iter(loader)
+        nxt = next(it, None)
+        nxt = self.stage(nxt) if nxt is not None else None
+        while nxt is not None:
+            cur, nxt = nxt, next(it, None)
+            if nxt is not None:
+                nxt = self.stage(nxt)
+            yield cur
 
     def run_step(self):
         batch = self.comm_info["input_dict"]

@@ -19,8 +19,6 @@ reported but not added to ``loss`` (:699-704, Q10).
 import math
 from collections.abc import Sequence
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -59,7 +57,7 @@ class PonderIndoor(nn.Module):
                  template=None, clip_model=None, class_name=None, valid_index=None,
                  ppt_loss_weight=1.0, ppt_criteria=None, dense_channels_last=True,
                  proj_autocast=None, batched_render=True,
-                 sparse_dense_input=True, prefetch_rays=True):
+                 sparse_dense_input=True):
         super().__init__()
         self.grid_shape = tuple(grid_shape) if isinstance(grid_shape, Sequence) else (grid_shape,) * 3
         self.grid_size, self.pool_type = grid_size, pool_type
@@ -73,8 +71,6 @@ class PonderIndoor(nn.Module):
         # evaluate the projection network's first conv from the occupied cells only (the dense
         # 96-channel grid is never built, sparse_input.py); False = the reference's dense path
         self.sparse_dense_input = sparse_dense_input
-        # ``prefetch`` also prepares the batch's rays (PV2_PREFETCH_RAYS=0: inside the step, for A/B runs)
-        self.prefetch_rays = prefetch_rays and os.environ.get("PV2_PREFETCH_RAYS", "1") != "0"
         h = 0.5 + padding / 2
         self.bounds = [[-h, -h, -h], [h, h, h]]
         if mask is not None:
@@ -229,11 +225,11 @@ class PonderIndoor(nn.Module):
         return near < far
 
     @torch.no_grad()
-    def _choose_pixels(self, valid, n, generator=None):
+    def _choose_pixels(self, valid, n):
         """valid (B,V,H,W) bool -> flat pixel ids (B,V,n): a uniform random subset of the valid
         pixels of every view (device-side replacement of randperm on the host)."""
         B, V, H, W = valid.shape
-        key = torch.rand((B, V, H * W), device=valid.device, generator=generator)
+        key = torch.rand((B, V, H * W), device=valid.device)
         key = torch.where(valid.reshape(B, V, -1), key, torch.full_like(key, 2.0))
         return torch.topk(key, n, dim=-1, largest=False).indices
 
@@ -262,7 +258,7 @@ class PonderIndoor(nn.Module):
 
         pix = data_dict.get("ray_pixels")  # optional (B,V,n,2) [y,x] from the caller
         if pix is None:
-            flat = self._choose_pixels(depths > 0, n, data_dict.get("_ray_generator"))
+            flat = self._choose_pixels(depths > 0, n)
         else:
             flat = (pix[..., 0].long() * W + pix[..., 1].long()).to(dev)
         py, px = flat // W, flat % W
@@ -467,22 +463,7 @@ class PonderIndoor(nn.Module):
         """Input-pipeline hook: launch the sparse backbone's geometry for this (device-resident)
         batch on the side stream (SpUNet.prefetch_geometry); trainers call it one batch ahead."""
         fn = getattr(self.backbone, "prefetch_geometry", None)
-        data_dict = fn(data_dict) if fn is not None else data_dict
-        if self.prefetch_rays and self.training and data_dict["coord"].is_cuda:
-            # the rays of the batch (unit-cube transform, pixel choice, ray generation, target
-            # lookup: ~150 small launches) depend on the batch alone, never on a parameter:
-            # input-pipeline work too.  Its random pixel choice draws from a generator of its own,
-            # so the order in which two host threads reach the device generator cannot matter.
-            dev = data_dict["coord"].device
-            gen = self.__dict__.get("_stage_generator")
-            if gen is None or gen.device != dev:
-                gen = self.__dict__["_stage_generator"] = torch.Generator(device=dev)
-                gen.manual_seed(torch.initial_seed() + 0x5EED)
-            data_dict["_ray_generator"] = gen
-            ray_dict, data_dict = self.prepare_ray(data_dict)
-            data_dict.pop("_ray_generator", None)
-            data_dict["_ray_dict"] = ray_dict
-        return data_dict
+        return fn(data_dict) if fn is not None else data_dict
 
     def forward(self, data_dict):
         """Under an ambient autocast region (the reference's ``enable_amp=True``) the reduced
@@ -498,9 +479,7 @@ class PonderIndoor(nn.Module):
 
     def _forward(self, data_dict):
         data_dict = self.extract_feature(data_dict)
-        ray_dict = data_dict.pop("_ray_dict", None)   # built a batch ahead by ``prefetch``
-        if ray_dict is None:
-            ray_dict, data_dict = self.prepare_ray(data_dict)
+        ray_dict, data_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
         render_out = self.render_func(ray_dict, volume_feature)
         loss, loss_dict = self.render_loss(render_out, ray_dict)

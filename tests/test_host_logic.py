@@ -395,7 +395,7 @@ def test_trainer_lookahead_stages_the_next_batch_before_yielding_the_current():
         events.append(("stage", b["i"]))
         return dict(b, _staged=True)
 
-    fake = SimpleNamespace(stage=stage, device=torch.device("cpu"), cfg={})
+    fake = SimpleNamespace(stage=stage)
     seen = []
     for b in Trainer.staged_batches(fake, [dict(i=i) for i in range(4)]):
         events.append(("step", b["i"]))
@@ -404,40 +404,6 @@ def test_trainer_lookahead_stages_the_next_batch_before_yielding_the_current():
     assert events == [("stage", 0), ("stage", 1), ("step", 0), ("stage", 2), ("step", 1), ("stage", 3),
                       ("step", 2), ("step", 3)]
     assert list(Trainer.staged_batches(fake, [])) == []
-
-
-def test_background_stager_hands_batches_over_in_order_and_reraises():
-    """utils/staging.BackgroundStager: synchronous on the host (no device), a worker thread
-    otherwise; either way ``submit(x).result()`` is ``stage(x)`` and exceptions surface at
-    ``result()``.  The threaded form is exercised here with the device check bypassed."""
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
-    from ponderv2_amd.ponder.utils.staging import BackgroundStager
-
-    where = []
-
-    def stage(i):
-        where.append(threading.current_thread().name)
-        if i == 3:
-            raise ValueError("bad batch")
-        return i * 10
-
-    sync = BackgroundStager(stage, "cpu")
-    assert not sync.threaded and [sync.submit(i).result() for i in range(3)] == [0, 10, 20]
-    assert set(where) == {threading.current_thread().name}
-
-    threaded = BackgroundStager(stage, "cpu")
-    threaded._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="pv2-stage")
-    threaded._run = stage                       # (no device to select on the host)
-    del where[:]
-    pending = [threaded.submit(i) for i in range(4)]
-    assert [f.result() for f in pending[:3]] == [0, 10, 20]
-    with pytest.raises(ValueError):
-        pending[3].result()
-    assert all(name.startswith("pv2-stage") for name in where)
-    threaded.shutdown()
-    assert not threaded.threaded
 
 
 def test_small_scene_hint_and_sync_free_helpers():
