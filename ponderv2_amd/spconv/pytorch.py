@@ -26,6 +26,10 @@ from .. import kernels as K
 from ..rownorm import fused_bn
 
 
+MAX_SPATIAL_DIM = 65519   # x + 16 must fit 16 bits
+MAX_BATCH_SIZE = 65535
+
+
 class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, indice_dict=None):
         assert features.dim() == 2 and indices.dim() == 2 and indices.shape[1] == 4
@@ -34,6 +38,12 @@ class SparseConvTensor:
         self.indices = indices
         self.spatial_shape = [int(s) for s in spatial_shape]
         self.batch_size = int(batch_size)
+        # the rulebook kernels pack (b, x+16, y+16, z+16) into four 16-bit fields of one 64-bit key
+        # (csrc/rulebook.hip pack_key): larger grids would alias distinct voxels silently
+        if max(self.spatial_shape) > MAX_SPATIAL_DIM or self.batch_size > MAX_BATCH_SIZE:
+            raise ValueError(
+                f"SparseConvTensor: spatial_shape {self.spatial_shape} / batch_size {self.batch_size} "
+                f"exceed the rulebook key range (dims <= {MAX_SPATIAL_DIM}, batch <= {MAX_BATCH_SIZE})")
         self.indice_dict = {} if indice_dict is None else indice_dict
 
     def replace_feature(self, feature):

@@ -101,6 +101,19 @@ def test_synthetic_batch_contract():
     assert world.min() > -0.01 and (world.max(0) < np.array([6.01, 5.01, 2.61])).all()
 
 
+def test_sparse_tensor_rejects_grids_beyond_the_rulebook_key_range():
+    """the rulebook kernels pack (b, x+16, y+16, z+16) into 16-bit fields; a larger
+    grid or batch must fail loudly on the host instead of aliasing voxels in the hash."""
+    from ponderv2_amd.spconv.pytorch import MAX_BATCH_SIZE, MAX_SPATIAL_DIM, SparseConvTensor
+
+    feat, idx = torch.zeros(2, 4), torch.zeros(2, 4, dtype=torch.int32)
+    SparseConvTensor(feat, idx, [MAX_SPATIAL_DIM, 10, 10], MAX_BATCH_SIZE)
+    with pytest.raises(ValueError):
+        SparseConvTensor(feat, idx, [10, MAX_SPATIAL_DIM + 1, 10], 1)
+    with pytest.raises(ValueError):
+        SparseConvTensor(feat, idx, [10, 10, 10], MAX_BATCH_SIZE + 1)
+
+
 def test_offset2batch():
     from ponderv2_amd.ponder.models.utils import batch2offset, offset2batch
 
