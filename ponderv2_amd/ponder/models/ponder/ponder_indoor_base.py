@@ -478,13 +478,8 @@ class PonderIndoor(nn.Module):
             return self._forward(data_dict)
 
     def _forward(self, data_dict):
-        # The rays depend on the batch alone (unit-cube transform, pixel choice, ray generation,
-        # target lookup: ~200 tiny launches, no parameter, no gradient) and touch nothing the
-        # backbone reads: they are queued first, on the side stream, and overlap the backbone.
-        from ponderv2_amd import sidestream
-        rays = sidestream.run_ahead(lambda: self.prepare_ray(data_dict), data_dict["coord"].device)
         data_dict = self.extract_feature(data_dict)
-        ray_dict, data_dict = rays.get()
+        ray_dict, data_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
         render_out = self.render_func(ray_dict, volume_feature)
         loss, loss_dict = self.render_loss(render_out, ray_dict)

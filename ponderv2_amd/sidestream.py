@@ -140,49 +140,3 @@ def fork(fn, reads):
     _queue_join(device, side)
     return out
 
-
-# --------------------------------------------------------------------------------------------
-# Forward-pass use of the same stream: work that does not depend on the model (the batch's rays)
-# --------------------------------------------------------------------------------------------
-RAYS_ENABLED = os.environ.get("PV2_RAYS_STREAM", "1") != "0"
-
-
-class Ahead:
-    """Result of ``run_ahead``: ``get()`` makes the current stream wait for the side stream's work
-    and returns what the function returned."""
-
-    def __init__(self, value, event, device):
-        self._value, self._event, self._device = value, event, device
-
-    def get(self):
-        if self._event is not None:
-            torch.cuda.current_stream(self._device).wait_event(self._event)
-            self._event = None
-        return self._value
-
-
-def run_ahead(fn, device):
-    """``fn()`` on the side stream, after whatever the current stream has queued; its kernels then
-    overlap the work the caller queues next on the current stream.  For parameter-free, no-grad
-    preparation (PonderIndoor's ray set-up: ~200 tiny launches that would otherwise sit between
-    the backbone and the projection network on the critical stream).  Memory: results are
-    allocated from the side stream's pool and consumed on the current stream after ``get()``; they
-    die with the step, and the side stream's next allocation is behind its next wait on the
-    current stream (``fork`` / ``run_ahead`` both start with one), so no ``record_stream`` is
-    needed - see ``fork``."""
-    if not (RAYS_ENABLED and device.type == "cuda"):
-        return Ahead(fn(), None, device)
-    cur = torch.cuda.current_stream(device)
-    side = stream(device)
-    ev = _fork_event(device)
-    ev.record(cur)
-    side.wait_event(ev)
-    set_stream = torch._C._cuda_setStream
-    set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
-    try:
-        value = fn()
-        done = torch.cuda.Event()
-        done.record(side)
-    finally:
-        set_stream(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
-    return Ahead(value, done, device)
