@@ -51,10 +51,14 @@ def pmc_traffic(kernel_key):
     try:
         with open(path) as f:
             doc = json.load(f)
-        rec = doc["kernels"][kernel_key]
-        return (1024.0 * (2.0 * rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]),
-                f"{PMC_FILE} (static; measured at commit {doc.get('commit', '?')}, "
-                f"{rec.get('launches', '?')} launches)")
+        # every instantiation whose name starts with the key (e.g. "<4, false>" and "<4, true>":
+        # forward and grad-input), weighted by launches
+        recs = [r for k, r in doc["kernels"].items() if k.startswith(kernel_key)]
+        n = sum(r.get("launches", 1) for r in recs)
+        kb = sum((2.0 * r["fetch_kb_per_launch"] + r["write_kb_per_launch"]) * r.get("launches", 1)
+                 for r in recs) / n
+        return (1024.0 * kb,
+                f"{PMC_FILE} (static; measured at commit {doc.get('commit', '?')}, {n} launches)")
     except Exception as e:  # noqa: BLE001
         return None, f"{PMC_FILE} unavailable ({type(e).__name__})"
 
@@ -198,27 +202,46 @@ class KernelTimer:
                     timer._depth -= 1
                 e.record()
                 c = cost(*a, **k)
-                timer._add(fam, s, e, c[0], c[1], c[2] if len(c) > 2 else None)
+                name_ = c[3] if len(c) > 3 else fam     # the instantiation this call ran on
+                timer.peaks.setdefault(name_, peak)
+                timer._add(name_, s, e, c[0], c[1], c[2] if len(c) > 2 else None)
                 return out
 
             setattr(K, name, fn)
+
+        def conv_family(c_in, c_out, rb, out):
+            """Which kernel kernels.spconv_forward runs this call on (same rules as over there)."""
+            if out is None and K._use_os(rb):
+                return "spconv_os_kernel (fwd+dgrad: strided / inverse convs)"
+            if c_in % 32 == 0:
+                nb = min(4, (c_out + 31) // 32)
+                return "spconv_fwd_lds_kernel<%d> (fwd+dgrad, %s output channels per workgroup)" % (
+                    nb, {1: "32", 2: "64", 3: "96", 4: "128"}[nb])
+            return "spconv_fwd_kernel (fwd: stem, any channel count)"
 
         def conv_cost(feats, w, rb, out=None, bias=None):
             c_out, kk, c_in = w.shape
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
                     4.0 * (rb.n_in * c_in + rb.n_out * c_out + kk * c_in * c_out) + 8.0 * p,
-                    (c_in, c_out, kk, p))
+                    (c_in, c_out, kk, p), conv_family(c_in, c_out, rb, out))
 
         def wgrad_cost(feats, gout, rb, c_out):
             c_in = feats.shape[1]
             p = rb.n_pairs
             return (2.0 * p * c_in * c_out,
                     4.0 * (rb.n_in * c_in + rb.n_out * c_out + rb.K * c_in * c_out) + 8.0 * p,
-                    (c_in, c_out, rb.K, p))
+                    (c_in, c_out, rb.K, p), wgrad_family(c_in, c_out))
 
         def dgrad_cost(gout, w, rb):
             return conv_cost(gout, w.permute(2, 1, 0), rb.transposed())
+
+        def wgrad_family(c_in, c_out):
+            if c_in % 4 or c_out % 4:
+                return "spconv_wgrad_kernel (stem, any channel count)"
+            big_n, big_c = c_out > 64, c_in > 64
+            return "spconv_wgrad_lds_kernel<%s>" % ("2, 2, 1" if big_n and big_c else "2, 1, 2" if big_n
+                                                    else "1, 2, 2" if big_c else "1, 1, 4")
 
         # 16-bit kernels (csrc/sparse_conv16.hip): same algorithmic flops, 2-byte features and
         # weights, fp32 dW; the gather table instead of pair lists on the output-stationary pass
@@ -654,14 +677,11 @@ def main():
                                       "achieved": dom["tflops"], "peak": dom["mfma_peak_tflops"],
                                       "unit": "TFLOP/s", "frac": dom["tflops"] / dom["mfma_peak_tflops"],
                                       "hbm_frac_of_alg_bytes": dom["frac_of_hbm_peak"],
-                                      "traffic": (pmc_traffic("spconv_fwd_lds_kernel<4>")[0]
-                                                  if dom["kernel"].startswith("spconv_fwd_kernel") else None),
-                                      "traffic_source": (pmc_traffic("spconv_fwd_lds_kernel<4>")[1]
-                                                         if dom["kernel"].startswith("spconv_fwd_kernel")
-                                                         else "no PMC pass for this kernel yet"),
-                                      "traffic_note": "HBM-side bytes/launch of "
-                                                      "spconv_fwd_lds_kernel<4> (the family's main "
-                                                      "instantiation); algorithmic bytes/launch = "
+                                      "traffic": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[0],
+                                      "traffic_source": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[1],
+                                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + "
+                                                      "WRITE_SIZE) of this kernel's instantiations in "
+                                                      "the PMC passes; algorithmic bytes per launch = "
                                                       "alg_bytes_per_launch",
                                       "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
                                       "alg_flops_per_launch": dom["alg_flops_per_launch"],
