@@ -175,9 +175,17 @@ class KernelTimer:
         self.l2_bytes = {}
         self.peaks = {}     # family -> dense MFMA peak of its operand type (TFLOP/s)
         self._depth = 0     # > 0 inside a wrapped call: nested wrapped calls are not recorded twice
+        self._excl = None   # event pairs of the zero-fill launches inside the call being timed
 
-    def _add(self, fam, s, e, flops, nbytes, shape=None):
-        self.records.setdefault(fam, []).append((s, e, flops, nbytes, shape))
+    def _add(self, fam, s, e, flops, nbytes, shape=None, excl=()):
+        self.records.setdefault(fam, []).append((s, e, flops, nbytes, shape, tuple(excl)))
+
+    @staticmethod
+    def _ms(rec):
+        """Duration of the bracketed launch itself: the bracket minus the zero-fill launches that
+        ran inside it (the scatter-add kernels' targets are cleared right before them; the fills
+        are a kernel of their own in the rocprofv3 statistics and a family of their own here)."""
+        return rec[0].elapsed_time(rec[1]) - sum(a.elapsed_time(b) for a, b in rec[5])
 
     def install(self):
         import ponderv2_amd.kernels as K
@@ -196,18 +204,37 @@ class KernelTimer:
                 e = torch.cuda.Event(enable_timing=True)
                 s.record()
                 timer._depth += 1
+                timer._excl = excl = []
                 try:
                     out = orig(*a, **k)
                 finally:
                     timer._depth -= 1
+                    timer._excl = None
                 e.record()
                 c = cost(*a, **k)
                 name_ = c[3] if len(c) > 3 else fam     # the instantiation this call ran on
                 timer.peaks.setdefault(name_, peak)
-                timer._add(name_, s, e, c[0], c[1], c[2] if len(c) > 2 else None)
+                timer._add(name_, s, e, c[0], c[1], c[2] if len(c) > 2 else None, excl)
                 return out
 
             setattr(K, name, fn)
+
+        orig_fill = K._zero_fill
+        self._orig["_zero_fill"] = orig_fill
+
+        def timed_fill(t):
+            if timer._excl is None:
+                return orig_fill(t)
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            orig_fill(t)
+            b_.record()
+            timer._excl.append((a_, b_))
+            timer._add("zero_words_kernel (clears of the scatter-add targets)", a_, b_, 0.0,
+                       float(t.numel() * t.element_size()))
+            return t
+
+        K._zero_fill = timed_fill
 
         def conv_family(c_in, c_out, rb, out):
             """Which kernel kernels.spconv_forward runs this call on (same rules as over there)."""
@@ -318,6 +345,47 @@ class KernelTimer:
             return (n * 2.0 * (2 * H_ * F_), min(vol_bytes(a) / 2, n * 8.0 * F_ * 4)
                     + a[10] * 4.0 * 3 * (a[11] + a[12] + 1), n * 8.0 * F_ * 4)
 
+        # the same head with the final 1x1x1 convolution folded in (fused_head.FoldedVolume): the
+        # field kernels read per-sample rows, a 32-channel gather / scatter pair does the sampling
+        X_, XP_ = 32, 40
+
+        def vol32_bytes(b, z, y, x):
+            return 4.0 * b * z * y * x * X_
+
+        def field_fwd_rows_cost(*a):
+            n = a[6] * a[7]
+            return (n * 2.0 * (2 * H_ * F_ + G_ * H_ + F_ * H_),
+                    n * 4.0 * (NV_ + F_ + 2 * H_ + F_ + 2) + n * 4.0 * (C_ + 3 * F_), 0.0)
+
+        def field_bwd_rows_cost(*a):
+            n = a[5] * a[6]
+            wrote = n * 4.0 * (C_ + 4 + 2 * H_ + H_ + F_ + 68 + 4)
+            read = n * 4.0 * (NV_ + H_ + 3 * F_ + 8)
+            return (n * 2.0 * (F_ * H_ + G_ * H_ + 2 * H_ * F_), wrote + read, 0.0)
+
+        def fold_gather_cost(*a):
+            n = a[9] * a[10]
+            gather = n * 8.0 * X_ * 4
+            return (0.0, n * 4.0 * 4 * XP_ + min(vol32_bytes(*a[1:5]), gather), gather)
+
+        def fold_scatter_cost(*a):
+            n = a[8] * a[9]
+            scatter = n * 8.0 * X_ * 4
+            return (0.0, n * 4.0 * (2 * X_ + 4) + min(2 * vol32_bytes(*a[0:4]), 2 * scatter), 2 * scatter)
+
+        def coarse_folded_cost(*a):
+            n = a[11] * a[12]
+            return (n * 2.0 * (2 * H_ * F_ + F_ * XP_), min(vol32_bytes(*a[1:5]), n * 8.0 * X_ * 4)
+                    + a[11] * 4.0 * 3 * (a[12] + a[13] + 1), n * 8.0 * X_ * 4)
+
+        wrap_c("pv2_neus_field_forward_rows", "field_fwd_kernel (rows mode: folded final conv)",
+               field_fwd_rows_cost)
+        wrap_c("pv2_neus_field_backward_rows", "field_bwd_kernel (rows mode: folded final conv)",
+               field_bwd_rows_cost)
+        wrap_c("pv2_neus_fold_gather", "fold_gather_kernel", fold_gather_cost)
+        wrap_c("pv2_neus_fold_scatter", "fold_scatter_kernel", fold_scatter_cost)
+        wrap_c("pv2_neus_coarse_sample_folded", "coarse_sample_kernel (folded final conv)",
+               coarse_folded_cost)
         wrap_c("pv2_neus_field_forward", "field_fwd_kernel", field_fwd_cost)
         wrap_c("pv2_neus_field_backward", "field_bwd_kernel + volume_scatter_kernel", field_bwd_cost)
         wrap_c("pv2_neus_coarse_sample", "coarse_sample_kernel", coarse_cost)
@@ -347,7 +415,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = []
         for fam, recs in self.records.items():
-            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            ms = sum(self._ms(r) for r in recs)
             flops = sum(r[2] for r in recs)
             nbytes = sum(r[3] for r in recs)
             out.append(dict(kernel=fam, launches=len(recs), total_ms=ms,
@@ -376,7 +444,7 @@ class KernelTimer:
                 key = (fam,) + tuple(r[4])
                 acc = rows.setdefault(key, [0, 0.0, 0.0])
                 acc[0] += 1
-                acc[1] += r[0].elapsed_time(r[1])
+                acc[1] += self._ms(r)
                 acc[2] += r[2]
         lines = ["%-32s %5s %5s %4s %9s %7s %9s %8s %8s" % ("kernel", "c_in", "c_out", "K", "pairs",
                  "n/step", "us/launch", "TFLOP/s", "ms/step")]
@@ -488,6 +556,7 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
     outdoor = args.workload == "outdoor"
     ppt = args.workload == "ppt"
+    ppt_modular = False
     cfg = model_cfg(args.rays_per_view, args.dense_dtype, args.workload, args.config)
     full = load_config(args.workload, args.config)
     model = build_model(ConfigDict(cfg)).to(device).train()
@@ -667,7 +736,9 @@ def main():
                        "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
             "backward_side_stream": side_state,
-            "render_head": ("fused ray-march kernels (csrc/raymarch_fused.hip)"
+            "render_head": (("fused ray-march kernels (csrc/raymarch_fused.hip)"
+                             + (", UNet3D's final 1x1x1 convolution folded in per sample"
+                                if fused_head.FOLD_ENABLED and not ppt_modular else ""))
                             if fused_head.ENABLED and not outdoor else "modular (torch ops + kernels)"),
         }
         if kernels:

@@ -382,6 +382,64 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
                             float* gq, float* gh, float* gy, float* sums, float* grad_volume,
                             pv2_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same head with the projection network's final 1x1x1 convolution FOLDED into it.
+ * ponder/models/ponder/unet3d.py:637-641,703 (``final_conv = nn.Conv3d(f_maps[0], out_channels,
+ * 1)``) writes V = Wf X + bf on every grid cell and ponder/models/ponder/render_utils/fields/
+ * sdf_field.py:122-146 then samples V trilinearly.  Sampling is linear in the volume, so
+ *     f(p) = Wf xt(p) + bf s(p),   xt = sum_c w_c X_c,   s = sum_c w_c   (in-bounds corners c)
+ * and the 128-channel volume (537 MB at the ScanNet grid, as much again for its gradient) need not
+ * exist.  volume: the pre-convolution activations X, channels-last [B, Z, Y, X, C] with C and the
+ * row width reported by pv2_neus_fold_dims (32 and 40).
+ *   fold_gather: per sample (main pass: sample n = ray * n_samples + k at distance starts[n])
+ *     gval [N, 40] = [xt(32), s, 0 x 7] and gder [N, 3, 40] = the same of d/dp_a.  Two tall GEMMs
+ *     (pv2_gemm_nt) with [Wf | bf | 0] give frows [N, 128] = f and, with its first 64 rows,
+ *     jrows [N, 3, 64] = d f_sdf / d p.
+ *   field_forward_rows / field_backward_rows: pv2_neus_field_forward / _backward reading those
+ *     rows instead of gathering from a volume (no grad_volume: see fold_scatter).
+ *   fold_scatter: grad_volume[corner c] += w_c gx + D_c qx with gx = gfeat . Wf [N, 32],
+ *     qx = save_q . Wf_sdf [N, 32], D_c = sum_a gvec_a dw_c/dp_a; grad_volume ZERO-initialised.
+ *   coarse_sample_folded: pv2_neus_coarse_sample on X with wfs [64, 40] = [Wf_sdf | bf_sdf | 0].
+ * ------------------------------------------------------------------------------------------ */
+int pv2_neus_fold_dims(int* channels, int* row_width);
+int pv2_neus_fold_gather(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                         const float* origins, const float* dirs, const float* starts,
+                         int64_t n_rays, int n_samples, int norm_pts, float norm_div, float* gval,
+                         float* gder, pv2_stream_t stream);
+int pv2_neus_fold_scatter(int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                          const float* origins, const float* dirs, const float* starts,
+                          int64_t n_rays, int n_samples, int norm_pts, float norm_div,
+                          const float* gx, const float* gvec, const float* qx, float* grad_volume,
+                          pv2_stream_t stream);
+int pv2_neus_coarse_sample_folded(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                                  int vol_c, const float* wfs, const float* origins,
+                                  const float* dirs, const float* nears, const float* fars,
+                                  int64_t n_rays, int n_coarse, int n_importance,
+                                  const float* lin_bins, const float* t_rand, int t_rand_cols,
+                                  const float* lin_u, const float* u_rand, int u_rand_cols,
+                                  const float* mw, const float* c0, const float* bc1, const float* w1,
+                                  const float* b1, float base_inv_s, float* bins_out,
+                                  float* starts_out, float* deltas_out, int32_t* dbg_idx,
+                                  float* dbg_sdf, float* dbg_w, pv2_stream_t stream);
+int pv2_neus_field_forward_rows(const float* frows, const float* jrows, const float* origins,
+                                const float* dirs, const float* starts, const float* deltas,
+                                int64_t n_rays, int n_samples, const float* mw, const float* c0,
+                                const float* bc1, const float* w1, const float* b1, const float* m_t,
+                                const float* q0, const float* a_rgb, const float* b_rgb,
+                                const float* inv_s, int norm_pts, float norm_div, float* sdf,
+                                float* alpha, float* values, float* save_f, float* save_h0,
+                                float* save_a1, float* save_q, pv2_stream_t stream);
+int pv2_neus_field_backward_rows(const float* jrows, const float* origins, const float* dirs,
+                                 const float* starts, const float* deltas, int64_t n_rays,
+                                 int n_samples, const float* mw, const float* w1, const float* m_t,
+                                 const float* w1g_t, const float* wc1_t, const float* a_rgb,
+                                 const float* inv_s, int norm_pts, float norm_div, const float* sdf,
+                                 const float* values, const float* save_h0, const float* weights,
+                                 const float* g_alpha, const float* g_sdf, const float* g_grad,
+                                 const float* g_comp, float* gfeat, float* gvec, float* gz,
+                                 float* tmat, float* gq, float* gh, float* gy, float* sums,
+                                 pv2_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Dense-grid scatter (to_dense).  Replaces torch_scatter.scatter(src, index, dim=0,

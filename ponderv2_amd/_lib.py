@@ -27,7 +27,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -95,6 +95,22 @@ SIGNATURES = {
     "pv2_neus_field_backward": (
         c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int] + [_P] * 7
         + [c_int, c_float] + [_P] * 9 + [_P] * 9 + [_P]),
+    "pv2_neus_fold_dims": (c_int, [POINTER(c_int)] * 2),
+    "pv2_neus_fold_gather": (
+        c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int64, c_int, c_int, c_float, _P,
+                _P, _P]),
+    "pv2_neus_fold_scatter": (
+        c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P,
+                _P, _P, _P]),
+    "pv2_neus_coarse_sample_folded": (
+        c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P,
+                _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pv2_neus_field_forward_rows": (
+        c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int] + [_P] * 10 + [c_int, c_float] + [_P] * 7
+        + [_P]),
+    "pv2_neus_field_backward_rows": (
+        c_int, [_P, _P, _P, _P, _P, c_int64, c_int] + [_P] * 7 + [c_int, c_float] + [_P] * 8
+        + [_P] * 8 + [_P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

@@ -112,10 +112,10 @@ __device__ __forceinline__ Axes make_axes(float px, float py, float pz, const Vo
   return a;
 }
 
-// corner c (bit0 = x, bit1 = y, bit2 = z): in-bounds flag, element offset of its channel 0, weight
-// and d weight / d p (0 when out of bounds)
-__device__ __forceinline__ bool corner(const Axes& a, const Vol& v, int scene, int c, int64_t* off,
-                                       float* w, float* dx, float* dy, float* dz) {
+// corner c (bit0 = x, bit1 = y, bit2 = z) of a channels-last volume with nch channels: in-bounds
+// flag, element offset of its channel 0, weight and d weight / d p (0 when out of bounds)
+__device__ __forceinline__ bool corner(const Axes& a, const Vol& v, int scene, int c, int nch,
+                                       int64_t* off, float* w, float* dx, float* dy, float* dz) {
   const int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
   const int x = a.ix + bx, y = a.iy + by, z = a.iz + bz;
   const bool ok = x >= 0 && x < v.X && y >= 0 && y < v.Y && z >= 0 && z < v.Z;
@@ -123,7 +123,7 @@ __device__ __forceinline__ bool corner(const Axes& a, const Vol& v, int scene, i
   const float sx = (bx ? 1.f : -1.f) * (float)(v.X - 1);
   const float sy = (by ? 1.f : -1.f) * (float)(v.Y - 1);
   const float sz = (bz ? 1.f : -1.f) * (float)(v.Z - 1);
-  *off = ok ? ((((int64_t)scene * v.Z + z) * v.Y + y) * v.X + x) * kC : 0;
+  *off = ok ? ((((int64_t)scene * v.Z + z) * v.Y + y) * v.X + x) * nch : 0;
   *w = ok ? wx * wy * wz : 0.f;
   *dx = ok ? sx * wy * wz : 0.f;
   *dy = ok ? wx * sy * wz : 0.f;
@@ -272,7 +272,10 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
     const float* __restrict__ starts, const float* __restrict__ deltas, int64_t n_total, int S,
     int norm_pts, float norm_div, float* __restrict__ sdf_out, float* __restrict__ alpha_out,
     float* __restrict__ vals, float* __restrict__ save_f, float* __restrict__ save_h0,
-    float* __restrict__ save_a1, float* __restrict__ save_q) {
+    float* __restrict__ save_a1, float* __restrict__ save_q, const float* __restrict__ frows,
+    const float* __restrict__ jrows) {
+  // frows / jrows != NULL: the FOLDED head (see "Folded final convolution" below) - the features and
+  // their spatial derivatives arrive as per-sample rows instead of being gathered from a volume
   __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
   __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
   __shared__ float s_pt[32 * 4];
@@ -307,16 +310,20 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
       const int scene = (int)s_pt[s * 4 + 3];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n < n_total) {
+        if (frows != nullptr) {
+          acc = ldg4(frows + n * kC + 4 * cq);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int64_t off;
-          float w, dx, dy, dz;
-          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
-            const float4 v = ldg4(vol.p + off + 4 * cq);
-            acc.x += w * v.x;
-            acc.y += w * v.y;
-            acc.z += w * v.z;
-            acc.w += w * v.w;
+          for (int c = 0; c < 8; ++c) {
+            int64_t off;
+            float w, dx, dy, dz;
+            if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) {
+              const float4 v = ldg4(vol.p + off + 4 * cq);
+              acc.x += w * v.x;
+              acc.y += w * v.y;
+              acc.z += w * v.z;
+              acc.w += w * v.w;
+            }
           }
         }
         if (cq < kF / 4) *reinterpret_cast<float4*>(save_f + n * kF + 4 * cq) = acc;
@@ -394,15 +401,25 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
       const int scene = (int)s_pt[s * 4 + 3];
       const float4 qv = *reinterpret_cast<const float4*>(&bufB[s * kLd + 4 * cq]);
       float gx = 0.f, gy = 0.f, gz = 0.f;
+      if (jrows != nullptr) {   // g_a = <d f_sdf / d p_a, q> from the per-sample Jacobian rows
+        const int64_t n = base + s;
+        if (n < n_total) {
+          const float* jr = jrows + n * 3 * kF + 4 * cq;
+          gx = dot4(ldg4(jr), qv);
+          gy = dot4(ldg4(jr + kF), qv);
+          gz = dot4(ldg4(jr + 2 * kF), qv);
+        }
+      } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        int64_t off;
-        float w, dx, dy, dz;
-        float d = 0.f;
-        if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) d = dot4(ldg4(vol.p + off + 4 * cq), qv);
-        gx += dx * d;
-        gy += dy * d;
-        gz += dz * d;
+        for (int c = 0; c < 8; ++c) {
+          int64_t off;
+          float w, dx, dy, dz;
+          float d = 0.f;
+          if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) d = dot4(ldg4(vol.p + off + 4 * cq), qv);
+          gx += dx * d;
+          gy += dy * d;
+          gz += dz * d;
+        }
       }
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
@@ -495,7 +512,7 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
     const float* __restrict__ g_grad_up, const float* __restrict__ g_comp,
     float* __restrict__ gfeat, float* __restrict__ gvec, float* __restrict__ gz,
     float* __restrict__ tmat, float* __restrict__ gq, float* __restrict__ gh,
-    float* __restrict__ gy_out, float* __restrict__ sums) {
+    float* __restrict__ gy_out, float* __restrict__ sums, const float* __restrict__ jrows) {
   __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
   __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
   __shared__ float s_pt[32 * 4];
@@ -647,17 +664,26 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
       const float a0 = s_gg[s * 4 + 0], a1 = s_gg[s * 4 + 1], a2 = s_gg[s * 4 + 2];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n < n_total) {
+        if (jrows != nullptr) {   // gq = sum_a gg_a d f_sdf / d p_a from the Jacobian rows
+          const float* jr = jrows + n * 3 * kF + 4 * cq;
+          const float4 j0 = ldg4(jr), j1 = ldg4(jr + kF), j2 = ldg4(jr + 2 * kF);
+          acc.x = a0 * j0.x + a1 * j1.x + a2 * j2.x;
+          acc.y = a0 * j0.y + a1 * j1.y + a2 * j2.y;
+          acc.z = a0 * j0.z + a1 * j1.z + a2 * j2.z;
+          acc.w = a0 * j0.w + a1 * j1.w + a2 * j2.w;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int64_t off;
-          float w, dx, dy, dz;
-          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
-            const float D = a0 * dx + a1 * dy + a2 * dz;
-            const float4 v = ldg4(vol.p + off + 4 * cq);
-            acc.x += D * v.x;
-            acc.y += D * v.y;
-            acc.z += D * v.z;
-            acc.w += D * v.w;
+          for (int c = 0; c < 8; ++c) {
+            int64_t off;
+            float w, dx, dy, dz;
+            if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) {
+              const float D = a0 * dx + a1 * dy + a2 * dz;
+              const float4 v = ldg4(vol.p + off + 4 * cq);
+              acc.x += D * v.x;
+              acc.y += D * v.y;
+              acc.z += D * v.z;
+              acc.w += D * v.w;
+            }
           }
         }
         *reinterpret_cast<float4*>(gq + n * kF + 4 * cq) = acc;
@@ -769,10 +795,103 @@ __global__ __launch_bounds__(256) void volume_scatter_kernel(
     for (int c = 0; c < 8; ++c) {
       int64_t off;
       float w, dx, dy, dz;
-      if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
+      if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) {
         const float D = a0 * dx + a1 * dy + a2 * dz;
         unsafeAtomicAdd(gvol + off + lane, w * glo + D * qv);
         unsafeAtomicAdd(gvol + off + 64 + lane, w * ghi);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Folded final convolution.  The projection network ends in a 1x1x1 convolution V = Wf X + bf
+// (32 -> 128 channels on every one of the 128x128x32 cells: 537 MB written, 537 MB of gradient
+// cleared, scattered into and read back, per step).  Trilinear sampling is linear in the volume,
+// so the same features come from sampling the 32-channel X and applying the convolution per
+// SAMPLE:   f = sum_c w_c (Wf X_c + bf) = Wf xt + bf s,   xt = sum_c w_c X_c,  s = sum_c w_c
+// (s = 1 inside the volume, < 1 where zero padding drops corners), and likewise
+//           d f / d p_a = Wf (sum_c dw_c/dp_a X_c) + bf (sum_c dw_c/dp_a).
+// fold_gather_kernel writes the rows [xt(32), s, 0 x 7] and, per axis a, [d xt / d p_a, d s / d p_a,
+// 0 x 7] (width kXP = 40: a multiple of 8, the reduction width of pv2_gemm_nt); two tall GEMMs with
+// [Wf | bf | 0] turn them into the feature rows f [N,128] and the Jacobian rows d f_sdf / d p
+// [N,3,64] that field_fwd / field_bwd read in place of their gathers (frows / jrows).  Backward:
+//   d L / d X_c = w_c (Wf^T gfeat) + D_c (Wf_sdf^T q)        fold_scatter_kernel, 32 channels
+//   d L / d [Wf | bf] = gfeat^T [xt, s] + (sdf rows) q^T (sum_a gg_a [d xt / d p_a, d s / d p_a])
+// (both GEMMs on pv2_gemm_tn from the rows saved here).  Exact up to fp32 re-association.
+// ------------------------------------------------------------------------------------------
+constexpr int kX = 32;        // channels of the pre-convolution volume
+constexpr int kXP = kX + 8;   // row width: xt(32), s, zero padding to a multiple of 8
+
+// One lane group of 8 (x float4 = 32 channels) per sample.
+__global__ __launch_bounds__(256) void fold_gather_kernel(
+    Vol vol, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ starts, int64_t n_total, int S, int norm_pts, float norm_div,
+    float* __restrict__ gval, float* __restrict__ gder) {
+  const int cq = threadIdx.x & 7;
+  const int64_t n = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (n >= n_total) return;
+  float p[3];
+  sample_point(n, S, origins, dirs, starts, norm_pts, norm_div, p);
+  const int scene = (int)((n / S) / vol.rays_per_scene);
+  const Axes ax = make_axes(p[0], p[1], p[2], vol);
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ax_ = av, ay_ = av, az_ = av;
+  float s = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int64_t off;
+    float w, dx, dy, dz;
+    if (corner(ax, vol, scene, c, kX, &off, &w, &dx, &dy, &dz)) {
+      const float4 v = ldg4(vol.p + off + 4 * cq);
+      av.x += w * v.x;  av.y += w * v.y;  av.z += w * v.z;  av.w += w * v.w;
+      ax_.x += dx * v.x; ax_.y += dx * v.y; ax_.z += dx * v.z; ax_.w += dx * v.w;
+      ay_.x += dy * v.x; ay_.y += dy * v.y; ay_.z += dy * v.z; ay_.w += dy * v.w;
+      az_.x += dz * v.x; az_.y += dz * v.y; az_.z += dz * v.z; az_.w += dz * v.w;
+      s += w;
+      sx += dx;
+      sy += dy;
+      sz += dz;
+    }
+  }
+  float* rv = gval + n * kXP;
+  float* rd = gder + n * 3 * kXP;
+  *reinterpret_cast<float4*>(rv + 4 * cq) = av;
+  *reinterpret_cast<float4*>(rd + 4 * cq) = ax_;
+  *reinterpret_cast<float4*>(rd + kXP + 4 * cq) = ay_;
+  *reinterpret_cast<float4*>(rd + 2 * kXP + 4 * cq) = az_;
+  if (cq < 2) {   // columns 32..39: [s, 0, 0, 0] and [0, 0, 0, 0]
+    const float m = cq == 0 ? 1.f : 0.f;
+    *reinterpret_cast<float4*>(rv + kX + 4 * cq) = make_float4(m * s, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(rd + kX + 4 * cq) = make_float4(m * sx, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(rd + kXP + kX + 4 * cq) = make_float4(m * sy, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(rd + 2 * kXP + kX + 4 * cq) = make_float4(m * sz, 0.f, 0.f, 0.f);
+  }
+}
+
+// gX[corner c] += w_c gx + D_c qx, D_c = sum_a gg_a dw_c/dp_a.  Half a wave per sample (lane =
+// channel: 128-byte contiguous atomic runs), scrambled sample order as in volume_scatter_kernel.
+__global__ __launch_bounds__(256) void fold_scatter_kernel(
+    Vol vol, const float* __restrict__ origins, const float* __restrict__ dirs,
+    const float* __restrict__ starts, int64_t n_total, int S, int norm_pts, float norm_div,
+    const float* __restrict__ gx, const float* __restrict__ gvec, const float* __restrict__ qx,
+    float* __restrict__ gvol, uint32_t perm) {
+  const int ch = threadIdx.x & 31;
+  const int64_t nh = (int64_t)gridDim.x * 8;
+  for (int64_t it = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); it < n_total; it += nh) {
+    const int64_t n = perm ? (int64_t)((uint64_t)it * perm % (uint64_t)n_total) : it;
+    float p[3];
+    sample_point(n, S, origins, dirs, starts, norm_pts, norm_div, p);
+    const int scene = (int)((n / S) / vol.rays_per_scene);
+    const Axes ax = make_axes(p[0], p[1], p[2], vol);
+    const float a0 = gvec[n * 4 + 0], a1 = gvec[n * 4 + 1], a2 = gvec[n * 4 + 2];
+    const float g = gx[n * kX + ch], qv = qx[n * kX + ch];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int64_t off;
+      float w, dx, dy, dz;
+      if (corner(ax, vol, scene, c, kX, &off, &w, &dx, &dy, &dz)) {
+        const float D = a0 * dx + a1 * dy + a2 * dz;
+        unsafeAtomicAdd(gvol + off + ch, w * g + D * qv);
       }
     }
   }
@@ -799,7 +918,9 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
     const float* __restrict__ lin_u, const float* __restrict__ u_rand, int u_rand_cols,
     float base_inv_s, float* __restrict__ bins_out, float* __restrict__ starts_out,
     float* __restrict__ deltas_out, int32_t* __restrict__ dbg_idx, float* __restrict__ dbg_sdf,
-    float* __restrict__ dbg_w) {
+    float* __restrict__ dbg_w, const float* __restrict__ wfs) {
+  // wfs != NULL: the volume has kX channels and wfs = [Wf_sdf | bf_sdf | 0] (kF x kXP) turns the
+  // gathered [xt, s] rows into the kF SDF features (folded final convolution, see above)
   __shared__ __attribute__((aligned(16))) float s_f[4][32 * kLdF];
   __shared__ float s_bins[kMaxS0 + 1], s_e[kMaxS0 + 1], s_sdf[kMaxS0], s_cos[kMaxS0],
       s_alpha[kMaxS0], s_w[kMaxS0], s_cdf[kMaxS0 + 1], s_new[kMaxImp + 1],
@@ -830,32 +951,72 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
     const float o0 = origins[ray * 3 + 0], o1 = origins[ray * 3 + 1], o2 = origins[ray * 3 + 2];
     const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
     float* sF = s_f[wave];
-    const int cq = lane & 15, sub = lane >> 4;
+    if (wfs == nullptr) {
+      const int cq = lane & 15, sub = lane >> 4;
 #pragma unroll 2
-    for (int pass = 0; pass < 8; ++pass) {
-      const int s = pass * 4 + sub;
-      const int k = wave * 32 + s;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < S0) {
-        const float t = s_e[k];
-        const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
+      for (int pass = 0; pass < 8; ++pass) {
+        const int s = pass * 4 + sub;
+        const int k = wave * 32 + s;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < S0) {
+          const float t = s_e[k];
+          const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          int64_t off;
-          float w, dx, dy, dz;
-          if (corner(ax, vol, scene, c, &off, &w, &dx, &dy, &dz)) {
-            const float4 v = ldg4(vol.p + off + 4 * cq);
-            acc.x += w * v.x;
-            acc.y += w * v.y;
-            acc.z += w * v.z;
-            acc.w += w * v.w;
+          for (int c = 0; c < 8; ++c) {
+            int64_t off;
+            float w, dx, dy, dz;
+            if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) {
+              const float4 v = ldg4(vol.p + off + 4 * cq);
+              acc.x += w * v.x;
+              acc.y += w * v.y;
+              acc.z += w * v.z;
+              acc.w += w * v.w;
+            }
           }
         }
+        *reinterpret_cast<float4*>(&sF[s * kLdF + 4 * cq]) = acc;
       }
-      *reinterpret_cast<float4*>(&sF[s * kLdF + 4 * cq]) = acc;
+    } else {   // 8 lanes x float4 = the kX channels of one sample, 8 samples per pass
+      const int cq = lane & 7, sub = lane >> 3;
+#pragma unroll 2
+      for (int pass = 0; pass < 4; ++pass) {
+        const int s = pass * 8 + sub;
+        const int k = wave * 32 + s;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wsum = 0.f;
+        if (k < S0) {
+          const float t = s_e[k];
+          const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            int64_t off;
+            float w, dx, dy, dz;
+            if (corner(ax, vol, scene, c, kX, &off, &w, &dx, &dy, &dz)) {
+              const float4 v = ldg4(vol.p + off + 4 * cq);
+              acc.x += w * v.x;
+              acc.y += w * v.y;
+              acc.z += w * v.z;
+              acc.w += w * v.w;
+              wsum += w;
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(&sF[s * kLdF + 4 * cq]) = acc;
+        if (cq < 2)
+          *reinterpret_cast<float4*>(&sF[s * kLdF + kX + 4 * cq]) =
+              make_float4(cq == 0 ? wsum : 0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   __syncthreads();
+  if (wfs != nullptr) {   // f_sdf = [xt, s] . wfs^T, in place (a branch uniform over the workgroup)
+    f32x16 fx[2];
+    zero_acc(fx);
+    if (wave * 32 < S0) tile_gemm<2>(s_f[wave], kLdF, wfs, kXP, kXP, fx, lane);
+    __syncthreads();
+    if (wave * 32 < S0) store_acc_lds<2>(s_f[wave], kLdF, fx, lane);
+    __syncthreads();
+  }
   if (wave * 32 < S0) {
     f32x16 a1[4], tt[4];
     mlp_hidden(s_f[wave], kLdF, P, lane, a1, tt, nullptr, 0, 0);
@@ -1009,21 +1170,22 @@ int pv2_neus_head_dims(int* hidden, int* f_sdf, int* f_rest, int* geo, int* valu
   return PV2_OK;
 }
 
-#define PV2_VOL_CHECK(name)                                                                      \
+#define PV2_VOL_CHECK_C(name, nch)                                                               \
   PV2_REQUIRE(vol_b >= 1 && vol_z >= 2 && vol_y >= 2 && vol_x >= 2, name ": bad volume shape");  \
-  PV2_REQUIRE(vol_c == kC, name ": the volume must have 128 channels (channels-last)");          \
+  PV2_REQUIRE(vol_c == nch, name ": wrong channel count of the (channels-last) volume");         \
   PV2_REQUIRE(n_rays >= 0 && (n_rays % vol_b) == 0, name ": rays must split evenly over scenes")
+#define PV2_VOL_CHECK(name) PV2_VOL_CHECK_C(name, kC)
 
-int pv2_neus_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
-                           int vol_c, const float* origins, const float* dirs, const float* nears,
-                           const float* fars, int64_t n_rays, int n_coarse, int n_importance,
-                           const float* lin_bins, const float* t_rand, int t_rand_cols,
-                           const float* lin_u, const float* u_rand, int u_rand_cols,
-                           const float* mw, const float* c0, const float* bc1, const float* w1,
-                           const float* b1, float base_inv_s, float* bins_out, float* starts_out,
-                           float* deltas_out, int32_t* dbg_idx, float* dbg_sdf, float* dbg_w,
-                           pv2_stream_t stream) {
-  PV2_VOL_CHECK("pv2_neus_coarse_sample");
+static int coarse_sample_impl(const float* wfs, const float* volume, int vol_b, int vol_z, int vol_y,
+                              int vol_x, int vol_c, const float* origins, const float* dirs,
+                              const float* nears, const float* fars, int64_t n_rays, int n_coarse,
+                              int n_importance, const float* lin_bins, const float* t_rand,
+                              int t_rand_cols, const float* lin_u, const float* u_rand,
+                              int u_rand_cols, const float* mw, const float* c0, const float* bc1,
+                              const float* w1, const float* b1, float base_inv_s, float* bins_out,
+                              float* starts_out, float* deltas_out, int32_t* dbg_idx, float* dbg_sdf,
+                              float* dbg_w, pv2_stream_t stream) {
+  PV2_VOL_CHECK_C("pv2_neus_coarse_sample", (wfs != nullptr ? kX : kC));
   PV2_REQUIRE(n_coarse >= 2 && n_coarse <= kMaxS0, "pv2_neus_coarse_sample: 2 <= n_coarse <= 128");
   PV2_REQUIRE(n_importance >= 1 && n_importance <= kMaxImp,
               "pv2_neus_coarse_sample: 1 <= n_importance <= 63");
@@ -1045,8 +1207,40 @@ int pv2_neus_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y,
   hipLaunchKernelGGL(coarse_sample_kernel, dim3((unsigned)n_rays), dim3(64 * waves), 0,
                      (hipStream_t)stream, v, P, origins, dirs, nears, fars, n_coarse, n_importance,
                      lin_bins, t_rand, t_rand_cols, lin_u, u_rand, u_rand_cols, base_inv_s, bins_out,
-                     starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w);
+                     starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w, wfs);
   return pv2::check_launch("neus_coarse_sample");
+}
+
+int pv2_neus_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                           int vol_c, const float* origins, const float* dirs, const float* nears,
+                           const float* fars, int64_t n_rays, int n_coarse, int n_importance,
+                           const float* lin_bins, const float* t_rand, int t_rand_cols,
+                           const float* lin_u, const float* u_rand, int u_rand_cols,
+                           const float* mw, const float* c0, const float* bc1, const float* w1,
+                           const float* b1, float base_inv_s, float* bins_out, float* starts_out,
+                           float* deltas_out, int32_t* dbg_idx, float* dbg_sdf, float* dbg_w,
+                           pv2_stream_t stream) {
+  return coarse_sample_impl(nullptr, volume, vol_b, vol_z, vol_y, vol_x, vol_c, origins, dirs, nears,
+                            fars, n_rays, n_coarse, n_importance, lin_bins, t_rand, t_rand_cols,
+                            lin_u, u_rand, u_rand_cols, mw, c0, bc1, w1, b1, base_inv_s, bins_out,
+                            starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w, stream);
+}
+
+int pv2_neus_coarse_sample_folded(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
+                                  int vol_c, const float* wfs, const float* origins,
+                                  const float* dirs, const float* nears, const float* fars,
+                                  int64_t n_rays, int n_coarse, int n_importance,
+                                  const float* lin_bins, const float* t_rand, int t_rand_cols,
+                                  const float* lin_u, const float* u_rand, int u_rand_cols,
+                                  const float* mw, const float* c0, const float* bc1, const float* w1,
+                                  const float* b1, float base_inv_s, float* bins_out,
+                                  float* starts_out, float* deltas_out, int32_t* dbg_idx,
+                                  float* dbg_sdf, float* dbg_w, pv2_stream_t stream) {
+  PV2_REQUIRE(wfs != nullptr, "pv2_neus_coarse_sample_folded: fold weights missing");
+  return coarse_sample_impl(wfs, volume, vol_b, vol_z, vol_y, vol_x, vol_c, origins, dirs, nears, fars,
+                            n_rays, n_coarse, n_importance, lin_bins, t_rand, t_rand_cols, lin_u,
+                            u_rand, u_rand_cols, mw, c0, bc1, w1, b1, base_inv_s, bins_out, starts_out,
+                            deltas_out, dbg_idx, dbg_sdf, dbg_w, stream);
 }
 
 int pv2_neus_field_forward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
@@ -1066,8 +1260,31 @@ int pv2_neus_field_forward(const float* volume, int vol_b, int vol_z, int vol_y,
   Head P{mw, c0, bc1, w1, b1, m_t, q0, a_rgb, b_rgb, inv_s, nullptr, nullptr};
   hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0,
                      (hipStream_t)stream, v, P, origins, dirs, starts, deltas, n_total, n_samples,
-                     norm_pts, norm_div, sdf, alpha, values, save_f, save_h0, save_a1, save_q);
+                     norm_pts, norm_div, sdf, alpha, values, save_f, save_h0, save_a1, save_q,
+                     (const float*)nullptr, (const float*)nullptr);
   return pv2::check_launch("neus_field_forward");
+}
+
+int pv2_neus_field_forward_rows(const float* frows, const float* jrows, const float* origins,
+                                const float* dirs, const float* starts, const float* deltas,
+                                int64_t n_rays, int n_samples, const float* mw, const float* c0,
+                                const float* bc1, const float* w1, const float* b1, const float* m_t,
+                                const float* q0, const float* a_rgb, const float* b_rgb,
+                                const float* inv_s, int norm_pts, float norm_div, float* sdf,
+                                float* alpha, float* values, float* save_f, float* save_h0,
+                                float* save_a1, float* save_q, pv2_stream_t stream) {
+  PV2_REQUIRE(frows != nullptr && jrows != nullptr, "pv2_neus_field_forward_rows: rows missing");
+  PV2_REQUIRE(n_samples >= 1 && n_rays >= 0, "pv2_neus_field_forward_rows: sizes");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_field_forward_rows: too many samples");
+  Vol v{nullptr, 1, 2, 2, 2, n_rays};   // no volume is read in this mode
+  Head P{mw, c0, bc1, w1, b1, m_t, q0, a_rgb, b_rgb, inv_s, nullptr, nullptr};
+  hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0,
+                     (hipStream_t)stream, v, P, origins, dirs, starts, deltas, n_total, n_samples,
+                     norm_pts, norm_div, sdf, alpha, values, save_f, save_h0, save_a1, save_q, frows,
+                     jrows);
+  return pv2::check_launch("neus_field_forward_rows");
 }
 
 int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x,
@@ -1094,7 +1311,7 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
   hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
                      origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
                      values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
-                     gq, gh, gy, sums);
+                     gq, gh, gy, sums, (const float*)nullptr);
   st = pv2::check_launch("neus_field_backward");
   if (st != PV2_OK || grad_volume == nullptr) return st;
   // grad_volume must be zero-initialised by the caller (it may already hold other contributions)
@@ -1103,6 +1320,73 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
                      origins, dirs, starts, n_total, n_samples, norm_pts, norm_div, gfeat, gvec,
                      save_q, grad_volume, scramble_for(n_total));
   return pv2::check_launch("neus_volume_scatter");
+}
+
+int pv2_neus_field_backward_rows(const float* jrows, const float* origins, const float* dirs,
+                                 const float* starts, const float* deltas, int64_t n_rays,
+                                 int n_samples, const float* mw, const float* w1, const float* m_t,
+                                 const float* w1g_t, const float* wc1_t, const float* a_rgb,
+                                 const float* inv_s, int norm_pts, float norm_div, const float* sdf,
+                                 const float* values, const float* save_h0, const float* weights,
+                                 const float* g_alpha, const float* g_sdf, const float* g_grad,
+                                 const float* g_comp, float* gfeat, float* gvec, float* gz,
+                                 float* tmat, float* gq, float* gh, float* gy, float* sums,
+                                 pv2_stream_t stream) {
+  PV2_REQUIRE(jrows != nullptr, "pv2_neus_field_backward_rows: rows missing");
+  PV2_REQUIRE(n_samples >= 1 && n_rays >= 0, "pv2_neus_field_backward_rows: sizes");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_field_backward_rows: too many samples");
+  hipStream_t s = (hipStream_t)stream;
+  Vol v{nullptr, 1, 2, 2, 2, n_rays};
+  Head P{mw, nullptr, nullptr, w1, nullptr, m_t, nullptr, a_rgb, nullptr, inv_s, w1g_t, wc1_t};
+  int st = pv2::zero_words(sums, kSumTotal, s);
+  if (st != PV2_OK) return st;
+  hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
+                     origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
+                     values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
+                     gq, gh, gy, sums, jrows);
+  return pv2::check_launch("neus_field_backward_rows");
+}
+
+int pv2_neus_fold_dims(int* channels, int* row_width) {
+  *channels = kX;
+  *row_width = kXP;
+  return PV2_OK;
+}
+
+int pv2_neus_fold_gather(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                         const float* origins, const float* dirs, const float* starts,
+                         int64_t n_rays, int n_samples, int norm_pts, float norm_div, float* gval,
+                         float* gder, pv2_stream_t stream) {
+  PV2_VOL_CHECK_C("pv2_neus_fold_gather", kX);
+  PV2_REQUIRE(n_samples >= 1, "pv2_neus_fold_gather: n_samples");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_fold_gather: too many samples");
+  Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
+  hipLaunchKernelGGL(fold_gather_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(256), 0,
+                     (hipStream_t)stream, v, origins, dirs, starts, n_total, n_samples, norm_pts,
+                     norm_div, gval, gder);
+  return pv2::check_launch("neus_fold_gather");
+}
+
+int pv2_neus_fold_scatter(int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                          const float* origins, const float* dirs, const float* starts,
+                          int64_t n_rays, int n_samples, int norm_pts, float norm_div,
+                          const float* gx, const float* gvec, const float* qx, float* grad_volume,
+                          pv2_stream_t stream) {
+  PV2_VOL_CHECK_C("pv2_neus_fold_scatter", kX);
+  PV2_REQUIRE(n_samples >= 1 && grad_volume != nullptr, "pv2_neus_fold_scatter: arguments");
+  const int64_t n_total = n_rays * n_samples;
+  if (n_total == 0) return PV2_OK;
+  // grad_volume must be zero-initialised by the caller (it may already hold other contributions)
+  Vol v{nullptr, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
+  const int64_t halves = n_total < 256 * 8 * 8 ? n_total : 256 * 8 * 8;
+  hipLaunchKernelGGL(fold_scatter_kernel, dim3((unsigned)((halves + 7) / 8)), dim3(256), 0,
+                     (hipStream_t)stream, v, origins, dirs, starts, n_total, n_samples, norm_pts,
+                     norm_div, gx, gvec, qx, grad_volume, scramble_for(n_total));
+  return pv2::check_launch("neus_fold_scatter");
 }
 
 }  // extern "C"

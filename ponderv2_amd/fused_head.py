@@ -26,6 +26,11 @@ from . import _lib
 from .kernels import _ptr, _require_device, _stream, zeros_by_kernel
 
 ENABLED = os.environ.get("PV2_FUSED_HEAD", "1") != "0"
+# The projection network's final 1x1x1 convolution applied per sample inside the head instead of per
+# grid cell before it (``FoldedVolume`` / ``field_render_folded`` below); PV2_FOLD_FINAL_CONV=0
+# materialises the 128-channel volume as the reference does.
+FOLD_ENABLED = os.environ.get("PV2_FOLD_FINAL_CONV", "1") != "0"
+KX, KXP = 32, 40   # channels of the pre-convolution volume / row width [xt, s, 0 x 7] (pv2_neus_fold_dims)
 # tests set this to a dict to receive the coarse pass's diagnostics (importance-sampling bin
 # indices, coarse SDF and weights) of the next render
 CAPTURE = None
@@ -54,6 +59,65 @@ def device_ok(t):
     """Tensors the kernels take (overridden by the host doubles in tests).  Reduced-precision
     volumes (the projection network under autocast) are widened to fp32 on the way in."""
     return t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.float16)
+
+
+class FoldedVolume:
+    """What the projection network hands the render head when its last layer - a 1x1x1
+    convolution (unet3d.py ``final_conv``) - is to be applied per SAMPLE: the activations in front
+    of it (B, 32, Z, Y, X) and the convolution module.  ``materialize()`` is the 128-channel volume
+    the reference builds, for every consumer other than the fused head."""
+
+    def __init__(self, pre, conv):
+        self.pre, self.conv = pre, conv
+
+    @property
+    def shape(self):
+        b, _, z, y, x = self.pre.shape
+        return torch.Size((b, self.conv.out_channels, z, y, x))
+
+    def dim(self):
+        return 5
+
+    @property
+    def dtype(self):
+        return self.pre.dtype
+
+    @property
+    def is_cuda(self):
+        return self.pre.is_cuda
+
+    def materialize(self):
+        from .ponder.models.ponder.unet3d import library_conv
+
+        return library_conv(self.conv, self.pre)
+
+    def rows(self):
+        """(x5, wfp): the (B,Z,Y,X,32) channels-last fp32 view of the activations and the
+        [C_out, 40] matrix [Wf | bf | 0] (built by torch ops: gradients reach the module)."""
+        x5 = self.pre.permute(0, 2, 3, 4, 1).float()
+        x5 = x5 if x5.is_contiguous() else x5.contiguous()
+        conv = self.conv
+        wf = conv.weight.reshape(conv.out_channels, conv.in_channels).float()
+        bf = (conv.bias.float() if conv.bias is not None
+              else torch.zeros(conv.out_channels, dtype=torch.float32, device=wf.device))
+        pad = torch.zeros((conv.out_channels, KXP - KX - 1), dtype=torch.float32, device=wf.device)
+        return x5, torch.cat([wf, bf[:, None], pad], dim=1)
+
+
+def fold_supported(conv, x):
+    """``conv`` is a 1x1x1 / stride 1 nn.Conv3d from KX to FS + F2 channels and ``x`` its device
+    input: the shape the folded kernels are compiled for."""
+    return (FOLD_ENABLED and ENABLED and isinstance(conv, torch.nn.Conv3d) and x.is_cuda
+            and x.dim() == 5 and tuple(conv.kernel_size) == (1, 1, 1)
+            and tuple(conv.stride) == (1, 1, 1) and tuple(conv.padding) == (0, 0, 0)
+            and conv.groups == 1 and conv.in_channels == KX and conv.out_channels == FS + F2
+            and conv.weight.dtype == torch.float32
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
+
+
+def unfold(volume_feature):
+    """The volume list with every ``FoldedVolume`` materialised (for the modular head)."""
+    return [v.materialize() if isinstance(v, FoldedVolume) else v for v in volume_feature]
 
 
 def _vol5(volume_feature, num_scenes):
@@ -101,6 +165,8 @@ def usable(model, ray_bundle, volume_feature):
     v = volume_feature[0]
     c = v.shape[1] if v.dim() == 5 else v.shape[0]
     n_scenes = getattr(ray_bundle, "num_scenes", 1)
+    if isinstance(v, FoldedVolume) and v.shape[0] != n_scenes:
+        return False
     rays = ray_bundle.origins.shape[0]
     return bool(c == FS + F2 and device_ok(v) and device_ok(ray_bundle.origins)
                 and rays % max(n_scenes, 1) == 0 and rays > 0)
@@ -114,8 +180,10 @@ def _check_dims():
 
 
 def coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_rand, n_importance,
-                  MW, c0, bc1, W1, b1, base_inv_s, debug=False):
-    """-> (bins (R,S+1), starts (R,S), deltas (R,S)[, debug dict]); nothing is differentiable."""
+                  MW, c0, bc1, W1, b1, base_inv_s, debug=False, wfs=None):
+    """-> (bins (R,S+1), starts (R,S), deltas (R,S)[, debug dict]); nothing is differentiable.
+    ``wfs`` [FS, 40]: ``vol5`` is the 32-channel pre-convolution volume (``FoldedVolume.rows``) and
+    wfs = [Wf_sdf | bf_sdf | 0] maps its samples to the SDF features."""
     _require_device(vol5, origins, dirs, nears, fars)
     _check_dims()
     B, Z, Y, X, C = vol5.shape
@@ -127,7 +195,7 @@ def coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_r
         f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
         vol5, origins, dirs, nears, fars = map(f32, (vol5, origins, dirs, nears, fars))
         t_rand, u_rand = f32(t_rand), f32(u_rand)
-        MW, c0, bc1, W1, b1 = map(f32, (MW, c0, bc1, W1, b1))
+        MW, c0, bc1, W1, b1, wfs = map(f32, (MW, c0, bc1, W1, b1, wfs))
         bins = torch.empty((R, S + 1), dtype=torch.float32, device=dev)
         starts = torch.empty((R, S), dtype=torch.float32, device=dev)
         deltas = torch.empty((R, S), dtype=torch.float32, device=dev)
@@ -136,8 +204,13 @@ def coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_r
             dbg = dict(idx=torch.empty((R, n_importance + 1), dtype=torch.int32, device=dev),
                        sdf=torch.empty((R, S0), dtype=torch.float32, device=dev),
                        weights=torch.empty((R, S0), dtype=torch.float32, device=dev))
-        _lib.check(_lib.lib().pv2_neus_coarse_sample(
-            _ptr(vol5), B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(nears.reshape(-1)),
+        fn = _lib.lib().pv2_neus_coarse_sample
+        head = (_ptr(vol5), B, Z, Y, X, C)
+        if wfs is not None:
+            fn = _lib.lib().pv2_neus_coarse_sample_folded
+            head += (_ptr(wfs),)
+        _lib.check(fn(
+            *head, _ptr(origins), _ptr(dirs), _ptr(nears.reshape(-1)),
             _ptr(fars.reshape(-1)), R, S0, n_importance, _ptr(f32(lin_bins)), _ptr(t_rand),
             0 if t_rand is None else t_rand.shape[-1], _ptr(f32(lin_u)), _ptr(u_rand),
             0 if u_rand is None else u_rand.shape[-1], _ptr(MW), _ptr(c0), _ptr(bc1), _ptr(W1),
@@ -252,6 +325,150 @@ class _FieldRender(torch.autograd.Function):
                 None)
 
 
+def _gemm_nt(x, w):
+    """x [M,K] . w[N,K]^T on pv2_gemm_nt (K % 8 == 0)."""
+    m, k = x.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and x.is_contiguous() and w.is_contiguous()
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pv2_gemm_nt(_ptr(x), m, k, _ptr(w), n, None, _ptr(y), _stream(x)),
+               "pv2_gemm_nt")
+    return y
+
+
+class _FieldRenderFolded(torch.autograd.Function):
+    """``_FieldRender`` on the 32-channel volume in front of the projection network's final 1x1x1
+    convolution, with that convolution (``wfp`` = [Wf | bf | 0], [128, 40]) applied per sample:
+    gather [xt, s] and its spatial derivatives (pv2_neus_fold_gather), two tall GEMMs to the
+    feature rows f and the Jacobian rows d f_sdf / d p, the field kernels in their rows mode; the
+    backward maps gfeat / q back through Wf and scatters 32 channels (csrc/raymarch_fused.hip,
+    "Folded final convolution").  Same results as the convolution followed by ``_FieldRender`` up
+    to fp32 re-association (tests/test_gpu_fused_head.py)."""
+
+    @staticmethod
+    def forward(ctx, x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
+                norm_pts, norm_div):
+        _require_device(x5, wfp, origins, dirs, starts, deltas, MW, W1, A)
+        _check_dims()
+        L = _lib.lib()
+        B, Z, Y, X, C = x5.shape
+        assert C == KX and tuple(wfp.shape) == (FS + F2, KXP), (x5.shape, wfp.shape)
+        R, S = starts.shape
+        N = R * S
+        dev = x5.device
+        c = lambda t: t.detach().contiguous()
+        x5, wfp, origins, dirs, starts, deltas = map(c, (x5, wfp, origins, dirs, starts, deltas))
+        MW, c0, bc1, W1, b1, A, b_rgb = map(c, (MW, c0, bc1, W1, b1, A, b_rgb))
+        inv_s_c = c(inv_s).reshape(1)
+        Mt = MW[:H].t().contiguous()
+        q0 = MW[H:].t().mv(W1[0]).contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        st = _stream(x5)
+        gval, gder = new(N, KXP), new(N, 3, KXP)
+        _lib.check(L.pv2_neus_fold_gather(
+            _ptr(x5), B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), R, S, int(norm_pts),
+            float(norm_div), _ptr(gval), _ptr(gder), st), "pv2_neus_fold_gather")
+        frows = _gemm_nt(gval, wfp)                               # f            [N, 128]
+        jrows = _gemm_nt(gder.view(3 * N, KXP), wfp[:FS].contiguous())   # d f_sdf / d p [N, 3, 64]
+        sdf, alpha, vals = new(R, S), new(R, S), new(R, S, NV)
+        sf, sh0, sa1, sq = new(N, FS), new(N, H), new(N, H), new(N, FS)
+        _lib.check(L.pv2_neus_field_forward_rows(
+            _ptr(frows), _ptr(jrows), _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S,
+            _ptr(MW), _ptr(c0), _ptr(bc1), _ptr(W1), _ptr(b1), _ptr(Mt), _ptr(q0), _ptr(A),
+            _ptr(b_rgb), _ptr(inv_s_c), int(norm_pts), float(norm_div), _ptr(sdf), _ptr(alpha),
+            _ptr(vals), _ptr(sf), _ptr(sh0), _ptr(sa1), _ptr(sq), st), "pv2_neus_field_forward_rows")
+        weights = new(R, S)
+        _lib.check(L.pv2_raymarch_weights_forward(_ptr(alpha), R, S, _ptr(weights), None, st),
+                   "pv2_raymarch_weights_forward")
+        comp = new(R, NV)
+        _lib.check(L.pv2_raymarch_accumulate_forward(_ptr(weights), _ptr(vals), R, S, NV, _ptr(comp),
+                                                     st), "pv2_raymarch_accumulate_forward")
+        ctx.save_for_backward(wfp, origins, dirs, starts, deltas, MW, W1, A, inv_s_c, sdf, alpha,
+                              vals, sf, sh0, sa1, sq, weights, Mt, gval, gder, jrows)
+        ctx.vol_shape = tuple(x5.shape)
+        ctx.norm = (int(norm_pts), float(norm_div))
+        ctx.inv_s_shape = inv_s.shape
+        grad = vals[:, :, COL_G:COL_G + 3].contiguous()
+        ctx.mark_non_differentiable(weights)
+        return sdf, grad, weights, comp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_grad, _g_weights, g_comp):
+        (wfp, origins, dirs, starts, deltas, MW, W1, A, inv_s, sdf, alpha, vals, sf, sh0, sa1, sq,
+         weights, Mt, gval, gder, jrows) = ctx.saved_tensors
+        L = _lib.lib()
+        B, Z, Y, X, C = ctx.vol_shape
+        R, S = starts.shape
+        N = R * S
+        dev = wfp.device
+        st = _stream(wfp)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_comp = (torch.zeros((R, NV), dtype=torch.float32, device=dev) if g_comp is None
+                  else g_comp.contiguous())
+        g_sdf = None if g_sdf is None else g_sdf.contiguous()
+        g_grad = None if g_grad is None else g_grad.contiguous()
+        gw = new(R, S)
+        _lib.check(L.pv2_raymarch_accumulate_backward(_ptr(weights), _ptr(vals), _ptr(g_comp), R, S,
+                                                      NV, _ptr(gw), None, st),
+                   "pv2_raymarch_accumulate_backward")
+        g_alpha = new(R, S)
+        _lib.check(L.pv2_raymarch_weights_backward(_ptr(alpha), _ptr(gw), R, S, _ptr(g_alpha), st),
+                   "pv2_raymarch_weights_backward")
+        gfeat, gvec, gz, tmat = new(N, FS + F2), new(N, 4), new(N, 2 * H), new(N, H)
+        gq, gh, gy, sums = new(N, FS), new(N, 68), new(N, 4), new(NSUM)
+        W1gt = W1[1:].t().contiguous()
+        Wc1t = MW[H:].t().contiguous()
+        _lib.check(L.pv2_neus_field_backward_rows(
+            _ptr(jrows), _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S, _ptr(MW),
+            _ptr(W1), _ptr(Mt), _ptr(W1gt), _ptr(Wc1t), _ptr(A), _ptr(inv_s), ctx.norm[0],
+            ctx.norm[1], _ptr(sdf), _ptr(vals), _ptr(sh0), _ptr(weights), _ptr(g_alpha), _ptr(g_sdf),
+            _ptr(g_grad), _ptr(g_comp), _ptr(gfeat), _ptr(gvec), _ptr(gz), _ptr(tmat), _ptr(gq),
+            _ptr(gh), _ptr(gy), _ptr(sums), st), "pv2_neus_field_backward_rows")
+        # head weight gradients: exactly as in _FieldRender.backward
+        g_MW = zeros_by_kernel((2 * H, FS), torch.float32, dev)
+        _gemm_tn_into(gz, sf, g_MW)
+        _gemm_tn_into(tmat, gq, g_MW[:H])
+        g_W1p = zeros_by_kernel((68, H), torch.float32, dev)
+        _gemm_tn_into(gh, sa1, g_W1p)
+        g_Ap = zeros_by_kernel((4, NV), torch.float32, dev)
+        _gemm_tn_into(gy, vals.reshape(N, NV), g_Ap)
+        qsum = sums[SUM_Q:SUM_Q + FS]
+        v1 = W1[0]
+        g_MW[H:] += torch.outer(v1, qsum)
+        g_W1 = g_W1p[:1 + G].clone()
+        g_W1[0] += sums[SUM_V1:SUM_V1 + H] + MW[H:].mv(qsum)
+        g_A = torch.cat([g_Ap[:3, COL_G:COL_G + 3], g_Ap[:3, COL_F2:COL_F2 + F2],
+                         g_Ap[:3, COL_GEO:COL_GEO + G],
+                         gy.reshape(R, S, 4).sum(1)[:, :3].t().mm(dirs)], dim=1)
+        # the folded convolution: gradient of the 32-channel volume and of [Wf | bf]
+        g_vol = g_wfp = None
+        if ctx.needs_input_grad[0]:
+            wf = wfp[:, :KX]
+            gx = _gemm_nt(gfeat, wf.t().contiguous())              # gfeat . Wf      [N, 32]
+            qx = _gemm_nt(sq, wf[:FS].t().contiguous())            # q . Wf_sdf      [N, 32]
+            g_vol = zeros_by_kernel(ctx.vol_shape, torch.float32, dev)
+            _lib.check(L.pv2_neus_fold_scatter(
+                B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), R, S, ctx.norm[0], ctx.norm[1],
+                _ptr(gx), _ptr(gvec), _ptr(qx), _ptr(g_vol), st), "pv2_neus_fold_scatter")
+        if ctx.needs_input_grad[1]:
+            g_wfp = zeros_by_kernel((FS + F2, KXP), torch.float32, dev)
+            _gemm_tn_into(gfeat, gval, g_wfp)                      # gfeat^T [xt, s]
+            y = (gvec[:, :3, None] * gder).sum(1)                  # sum_a gg_a d[xt, s]/dp_a  [N, 40]
+            _gemm_tn_into(sq, y.contiguous(), g_wfp[:FS])          # + q^T (...) on the SDF rows
+        return (g_vol, g_wfp, None, None, None, None, g_MW, sums[SUM_C0:SUM_C0 + H].clone(),
+                sums[SUM_BC1:SUM_BC1 + H].clone(), g_W1, sums[SUM_B1:SUM_B1 + 1 + G].clone(), g_A,
+                sums[SUM_RGB:SUM_RGB + 3].clone(), sums[SUM_INVS].reshape(ctx.inv_s_shape), None,
+                None)
+
+
+def field_render_folded(x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
+                        norm_pts, norm_div):
+    """``field_render`` for a ``FoldedVolume`` (``x5, wfp = volume.rows()``)."""
+    return _FieldRenderFolded.apply(x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A,
+                                    b_rgb, inv_s, norm_pts, norm_div)
+
+
 def field_render(vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
                  norm_pts, norm_div):
     """-> sdf (R,S), grad (R,S,3), weights (R,S) [no gradient], comp (R,140).  Differentiable (once)
@@ -294,7 +511,11 @@ def _render_outputs(model, ray_bundle, volume_feature):
 
     field, smp = model.field, model.sampler
     B = getattr(ray_bundle, "num_scenes", 1)
-    vol5 = _vol5(volume_feature, B).float()
+    folded = isinstance(volume_feature[0], FoldedVolume)
+    if folded:
+        vol5, wfp = volume_feature[0].rows()
+    else:
+        vol5, wfp = _vol5(volume_feature, B).float(), None
     o, d = ray_bundle.origins.float(), ray_bundle.directions.float()
     R = o.shape[0]
     dev = o.device
@@ -312,14 +533,17 @@ def _render_outputs(model, ray_bundle, volume_feature):
     res = coarse_sample(
         vol5, o, d, ray_bundle.nears.reshape(-1), ray_bundle.fars.reshape(-1), lin_bins, t_rand,
         lin_u, u_rand, n_imp, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], smp.base_variance,
-        debug=CAPTURE is not None)
+        debug=CAPTURE is not None, **({"wfs": wfp[:FS]} if folded else {}))
     bins, starts, deltas = res[:3]
     if CAPTURE is not None:
         CAPTURE.update(res[3], bins=bins)
     inv_s = field.deviation_network.get_variance()
-    sdf, grad, weights, comp = field_render(
-        vol5, o, d, starts, deltas, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], cp["A"],
-        cp["b_rgb"], inv_s, field.norm_pts, 1.0 + field.norm_padding + 10e-4)
+    head = (o, d, starts, deltas, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], cp["A"],
+            cp["b_rgb"], inv_s, field.norm_pts, 1.0 + field.norm_padding + 10e-4)
+    if folded:
+        sdf, grad, weights, comp = field_render_folded(vol5, wfp, *head)
+    else:
+        sdf, grad, weights, comp = field_render(vol5, *head)
     wsum = comp[:, COL_ONE:COL_ONE + 1]
     out = {}
     rgb = comp[:, COL_RGB:COL_RGB + 3]

@@ -19,6 +19,8 @@ reported but not added to ``loss`` (:699-704, Q10).
 import math
 from collections.abc import Sequence
 
+import inspect
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -408,14 +410,23 @@ class PonderIndoor(nn.Module):
         else:
             dense = self.to_dense(data_dict)
             project = self.proj_net
+        # UNet3D's last layer is a 1x1x1 convolution, which commutes with trilinear sampling: when
+        # all scenes are rendered in one pass by the fused head (training), the head applies it per
+        # sample and the 128-channel volume is never materialised (fused_head.FoldedVolume)
+        kw = {}
+        entry = project.forward if isinstance(project, nn.Module) else project
+        if (self.training and self.batched_render and self.dense_channels_last
+                and "fold_final" in inspect.signature(entry).parameters):
+            kw["fold_final"] = True
         amp_dtype = self._projection_dtype(data_dict["coord"].device)
         if amp_dtype is not None:
             with torch.autocast(data_dict["coord"].device.type, dtype=amp_dtype):
-                volume = project(dense)
-            volume = volume.float()
+                volume = project(dense, **kw)
+            if torch.is_tensor(volume):
+                volume = volume.float()
         else:
-            volume = project(dense)
-        if self.dense_channels_last:
+            volume = project(dense, **kw)
+        if self.dense_channels_last and torch.is_tensor(volume):
             volume = volume.contiguous(memory_format=torch.channels_last_3d)
         return [volume]
 

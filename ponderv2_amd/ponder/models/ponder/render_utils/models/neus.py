@@ -18,7 +18,8 @@ class NeuSModel(SurfaceModel):
         # every other configuration keeps the modular path below
         if fused_head.usable(self, ray_bundle, volume_feature):
             return fused_head.render_outputs(self, ray_bundle, volume_feature)
-        return super().get_outputs(ray_bundle, volume_feature, **kwargs)
+        # (a projection network that left its final convolution to the fused head applies it now)
+        return super().get_outputs(ray_bundle, fused_head.unfold(volume_feature), **kwargs)
 
     def sample_and_forward_field(self, ray_bundle, volume_feature):
         sampled = self.sampler(ray_bundle, occupancy_fn=self.field.get_occupancy,

@@ -296,7 +296,7 @@ class UNet3Dv1m2(nn.Module):
                 and not isinstance(first.basic_module.batchnorm, nn.SyncBatchNorm)
                 and tuple(first.basic_module.conv.kernel_size) == (3, 3, 3))
 
-    def forward_cells(self, cells):
+    def forward_cells(self, cells, fold_final=False):
         """Forward from the occupied cells of the input grid: level 0 ("bcr": BatchNorm3d -> conv
         -> ReLU on the 96-channel grid, half of this network's FLOPs) is computed sparsely
         (sparse_input.py), the rest of the U-Net runs on its dense output."""
@@ -307,15 +307,21 @@ class UNet3Dv1m2(nn.Module):
         first = self.encoders[0].basic_module
         with torch.autocast("cuda", enabled=False):  # the sparse kernels are fp32
             x = bn_conv_relu_on_cells(first.batchnorm, first.conv, cells)
-        return self.forward(None, first=x)
+        return self.forward(None, first=x, fold_final=fold_final)
 
-    def forward(self, x, first=None):
+    def forward(self, x, first=None, fold_final=False):
+        """``fold_final``: stop in front of ``final_conv`` when the fused render head can apply it
+        per sample (fused_head.FoldedVolume) - the 128-channel volume is then never built."""
         skips = []
         for level, encoder in enumerate(self.encoders):
             x = first if (level == 0 and first is not None) else encoder(x)
             skips.insert(0, x)
         for decoder, skip in zip(self.decoders, skips[1:]):
             x = decoder(skip, x)
+        if fold_final and not (self.testing and self.final_activation is not None):
+            from ponderv2_amd import fused_head
+            if fused_head.fold_supported(self.final_conv, x):
+                return fused_head.FoldedVolume(x, self.final_conv)
         x = library_conv(self.final_conv, x)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x)

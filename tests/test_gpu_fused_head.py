@@ -97,3 +97,120 @@ def test_fused_head_is_the_default_render_path(device, monkeypatch):
     errs = gc.run_neus(device)
     assert calls["n"] == 1
     assert max(v for k, v in errs.items() if k.startswith(("out_", "loss_"))) < 1e-4, errs
+
+
+def _fold_problem(seed, **shape):
+    """check_fused_head's seeded problem with the 128-channel volume replaced by a 32-channel one
+    and a random 1x1x1 convolution [Wf | bf] in front of the head."""
+    import check_fused_head as chk
+    from ponderv2_amd import fused_head as fhd
+
+    p = chk.make_problem(seed, **shape)
+    g = torch.Generator().manual_seed(1000 + seed)
+    B, Z, Y, X, C = p["vol"].shape
+    p["x5"] = torch.randn(B, Z, Y, X, fhd.KX, generator=g, dtype=torch.float64) * 0.8
+    p["Wf"] = torch.randn(C, fhd.KX, generator=g, dtype=torch.float64) * 0.15
+    p["bf"] = torch.randn(C, generator=g, dtype=torch.float64) * 0.2
+    return p
+
+
+HEAD_KEYS = ("MW", "c0", "bc1", "W1", "b1", "A", "b_rgb", "inv_s")
+
+
+@pytest.mark.parametrize("seed,shape", [(0, {}), (1, dict(B=1, R=5, S=45, S0=40, n_imp=7, Z=5, Y=9, X=11))])
+def test_folded_final_convolution_equals_convolution_then_head(device, seed, shape):
+    """field_render_folded(X, [Wf | bf]) against the fp64 oracle evaluated on the materialised
+    volume V = Wf X + bf: sdf, grad sdf, composited row, and the gradients of X, Wf, bf and of every
+    head parameter (second-order terms through grad sdf included)."""
+    from oracle import fused_head as fh
+    from ponderv2_amd import fused_head as fhd
+
+    p = _fold_problem(seed, **shape)
+    # ---- reference: fp64 autograd through the restatement
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("x5", "Wf", "bf") + HEAD_KEYS}
+    vol = leaves["x5"] @ leaves["Wf"].t() + leaves["bf"]
+    r = fh.field_render(vol, p["origins"], p["dirs"], p["starts"], p["deltas"],
+                        *[leaves[k] for k in HEAD_KEYS])
+    loss = (r["sdf"] * p["g_sdf"]).sum() + (r["grad"] * p["g_grad"]).sum() + (r["comp"] * p["g_comp"]).sum()
+    ref_g = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    # ---- kernels
+    dev = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+    dl = {k: dev(p[k]).requires_grad_(True) for k in leaves}
+    pad = torch.zeros((dl["Wf"].shape[0], fhd.KXP - fhd.KX - 1), device=device)
+    wfp = torch.cat([dl["Wf"], dl["bf"][:, None], pad], dim=1)
+    sdf, grad, w, comp = fhd.field_render_folded(
+        dl["x5"], wfp, dev(p["origins"]), dev(p["dirs"]), dev(p["starts"]), dev(p["deltas"]),
+        *[dl[k] for k in HEAD_KEYS], True, 1.0 + 0.1 + 10e-4)
+    for got, want in ((sdf, r["sdf"]), (grad, r["grad"]), (w, r["weights"]), (comp, r["comp"])):
+        err = (got.detach().double().cpu() - want.detach()).abs().max().item()
+        assert err <= REL_TOL * want.abs().max().item() + 1e-7, err
+    loss32 = (sdf * dev(p["g_sdf"])).sum() + (grad * dev(p["g_grad"])).sum() + (comp * dev(p["g_comp"])).sum()
+    got_g = dict(zip(dl, torch.autograd.grad(loss32, list(dl.values()))))
+    for k, want in ref_g.items():
+        err = (got_g[k].double().cpu() - want).abs().max().item()
+        tol = 5e-4 if k == "inv_s" else REL_TOL
+        assert err <= tol * want.abs().max().item() + 1e-7, (k, err, want.abs().max().item())
+
+
+def test_folded_coarse_pass_equals_the_oracle_on_the_materialised_volume(device):
+    """pv2_neus_coarse_sample_folded (32-channel gather + in-kernel [Wf_sdf | bf_sdf]) against the
+    oracle's coarse pass on V = Wf X + bf, with most start positions OUTSIDE the volume (the bias
+    then enters weighted by the in-bounds corner weights, not by 1)."""
+    from oracle import fused_head as fh
+    from ponderv2_amd import fused_head as fhd
+
+    for scale in (1.0, 4.0):
+        p = _fold_problem(3, R=8)
+        p["origins"] = p["origins"] * scale
+        vol = p["x5"] @ p["Wf"].t() + p["bf"]
+        ref = fh.coarse_sample(vol, p["origins"], p["dirs"], p["nears"], p["fars"], p["lin_bins"],
+                               p["t_rand"], p["u_rand"], p["n_imp"], p["MW"], p["c0"], p["bc1"],
+                               p["W1"][0], p["b1"][0], 64.0)
+        dev = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+        wfs = torch.cat([p["Wf"], p["bf"][:, None], torch.zeros(p["Wf"].shape[0], fhd.KXP - fhd.KX - 1,
+                                                                dtype=torch.float64)], dim=1)[:fhd.FS]
+        bins, _, _ = fhd.coarse_sample(dev(p["x5"]), dev(p["origins"]), dev(p["dirs"]), dev(p["nears"]),
+                                       dev(p["fars"]), dev(p["lin_bins"]), dev(p["t_rand"]), dev(p["lin_u"]),
+                                       dev(p["u_rand"]), p["n_imp"], dev(p["MW"]), dev(p["c0"]),
+                                       dev(p["bc1"]), dev(p["W1"]), dev(p["b1"]), 64.0, wfs=dev(wfs))
+        bad = ((bins.double().cpu() - ref).abs().amax(1) > 1e-4).sum().item()
+        assert bad <= 1, (scale, bad)
+
+
+def test_model_folds_the_final_convolution_by_default_and_unfolded_results_agree(device, monkeypatch):
+    """PonderIndoor in training mode hands the fused head a FoldedVolume (the 128-channel volume is
+    never built); with PV2_FOLD_FINAL_CONV off the same step gives the same losses and gradients
+    up to the step's own run-to-run noise."""
+    import golden_cases as gc
+    from ponderv2_amd import fused_head as fhd, kernels as K
+
+    monkeypatch.setattr(K, "USE_OS", True)
+    seen = []
+    orig = fhd.field_render_folded
+    monkeypatch.setattr(fhd, "field_render_folded", lambda *a: (seen.append(1), orig(*a))[1])
+
+    def step(fold):
+        monkeypatch.setattr(fhd, "FOLD_ENABLED", fold)
+        model, batch = gc.small_indoor(device)
+        torch.manual_seed(0)
+        out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v) for k, v in out.items()},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    ref_l, ref_g = step(False)
+    again_l, again_g = step(False)
+    assert not seen
+    new_l, new_g = step(True)
+    assert len(seen) == 1
+    for k, v in ref_l.items():
+        assert abs(new_l[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, v, new_l[k])
+    assert ref_g.keys() == new_g.keys()
+    bad = {}
+    for name, g0 in ref_g.items():
+        ref = g0.cpu().numpy()
+        floor, err = gc.rel_err(again_g[name], ref), gc.rel_err(new_g[name], ref)
+        if not err <= max(5e-4, 4.0 * floor):
+            bad[name] = (err, floor)
+    assert not bad, bad
