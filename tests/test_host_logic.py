@@ -438,3 +438,45 @@ def test_small_scene_hint_and_sync_free_helpers():
     assert torch.equal(offset2batch(offset), offset2batch(offset, 12))
     a = torch.randn(3, 4, 4, dtype=torch.float64) + 4 * torch.eye(4, dtype=torch.float64)
     assert torch.equal(pib._inv(a), torch.linalg.inv(a))
+
+
+def test_folded_volume_materialises_for_every_other_consumer():
+    """fused_head.FoldedVolume (the projection network's output with its final 1x1x1 convolution left
+    to the fused head) is only created for device volumes; ``unfold`` / ``materialize`` give the
+    128-channel volume the reference builds, and UNet3Dv1m2(fold_final=True) on the host returns it."""
+    import torch.nn as nn
+
+    from ponderv2_amd import fused_head as fhd
+    from ponderv2_amd.ponder.models.ponder.unet3d import UNet3Dv1m2
+
+    torch.manual_seed(0)
+    net = UNet3Dv1m2(96, 128)
+    x = torch.randn(1, 96, 8, 16, 16)
+    ref = net(x)
+    assert torch.equal(net(x, fold_final=True), ref)          # host tensors: nothing to fold
+    conv = nn.Conv3d(fhd.KX, fhd.FS + fhd.F2, 1)
+    pre = torch.randn(2, fhd.KX, 4, 6, 5)
+    assert not fhd.fold_supported(conv, pre)                    # not on a device
+    vol = fhd.FoldedVolume(pre, conv)
+    assert vol.shape == (2, 128, 4, 6, 5) and vol.dim() == 5 and not vol.is_cuda
+    out = fhd.unfold([vol, pre])
+    assert torch.allclose(out[0], conv(pre)) and out[1] is pre
+    x5, wfp = vol.rows()
+    assert x5.shape == (2, 4, 6, 5, fhd.KX) and wfp.shape == (128, fhd.KXP)
+    # [xt, s, 0...] . wfp^T is the convolution of a cell (s = 1: all corners inside)
+    cell = torch.cat([x5[1, 2, 3, 4], torch.ones(1), torch.zeros(fhd.KXP - fhd.KX - 1)])
+    assert torch.allclose(wfp @ cell, conv(pre)[1, :, 2, 3, 4], atol=1e-6)
+
+
+def test_optimizer_builder_prefers_the_fused_step_only_on_the_device(monkeypatch):
+    from ponderv2_amd.ponder.utils import optimizer as opt
+
+    cfg = dict(type="SGD", lr=0.1, momentum=0.9, nesterov=True)
+    host = [torch.nn.Parameter(torch.zeros(3))]
+    assert "fused" not in opt._prefer_fused(cfg, host)                      # host parameters
+    assert opt._prefer_fused(dict(cfg, foreach=True), host) == dict(cfg, foreach=True)
+    fake = [type("P", (), {"is_cuda": True, "dtype": torch.float32, "is_floating_point": lambda s: True})()]
+    monkeypatch.setattr(torch, "is_floating_point", lambda p: True)
+    assert opt._prefer_fused(cfg, fake).get("fused") is True
+    monkeypatch.setenv("PV2_FUSED_OPTIMIZER", "0")
+    assert "fused" not in opt._prefer_fused(cfg, fake)
