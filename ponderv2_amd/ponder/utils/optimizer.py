@@ -33,6 +33,27 @@ def _prefer_fused(cfg, params):
     return cfg
 
 
+def _ready_for_fused(optimizer):
+    """torch's fused SGD step takes the momentum buffers of a group as ONE list and fails when some
+    exist and some do not - which happens whenever parameters receive their first gradient at
+    different steps (the multi-dataset model trains one condition's normalisation layers per
+    step).  With dampening 0 a zero buffer gives the same first update as the lazily created one
+    (buf = momentum * 0 + grad), so the buffers are created up front; a group with dampening falls
+    back to the for-each step."""
+    if not (isinstance(optimizer, torch.optim.SGD) and optimizer.defaults.get("fused")):
+        return optimizer
+    for group in optimizer.param_groups:
+        if not group.get("fused"):
+            continue
+        if group.get("dampening", 0) != 0:
+            group["fused"], group["foreach"] = False, True
+            continue
+        if group.get("momentum", 0) != 0:
+            for p in group["params"]:
+                optimizer.state[p].setdefault("momentum_buffer", torch.zeros_like(p))
+    return optimizer
+
+
 def build_optimizer(cfg, model, param_dicts=None):
     """``param_dicts=[dict(keyword=..., lr=..., momentum=..., weight_decay=...)]`` puts the
     parameters whose name contains ``keyword`` into their own group with those ABSOLUTE settings
@@ -43,7 +64,7 @@ def build_optimizer(cfg, model, param_dicts=None):
     cfg = _prefer_fused(cfg, model.parameters())
     if param_dicts is None:
         cfg["params"] = model.parameters()
-        return OPTIMIZERS.build(cfg=cfg)
+        return _ready_for_fused(OPTIMIZERS.build(cfg=cfg))
     groups, names = [dict(params=[], lr=cfg["lr"])], [[]]
     for d in param_dicts:
         g = dict(params=[])
@@ -68,7 +89,7 @@ def build_optimizer(cfg, model, param_dicts=None):
         settings = "".join(f" {k}: {v};" for k, v in g.items() if k != "params")
         log.info(f"Params Group {i + 1} -{settings} Params: {names[i]}.")
     cfg["params"] = groups
-    return OPTIMIZERS.build(cfg=cfg)
+    return _ready_for_fused(OPTIMIZERS.build(cfg=cfg))
 
 
 @SCHEDULERS.register_module()
