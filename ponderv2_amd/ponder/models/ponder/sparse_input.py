@@ -145,7 +145,7 @@ class _ExpandClasses(torch.autograd.Function):
         zs, ys, xs = ctx.dims
         oz, oy, ox = ctx.cls["onehot"]                   # (n_classes, size) each
         c = g.shape[-1]
-        g = g.reshape(ctx.batch * zs, ys * xs * c)
+        g = g.to(oz.dtype).reshape(ctx.batch * zs, ys * xs * c)   # (an autocast region may hand over 16 bits)
         gz = oz.repeat(1, ctx.batch).mm(g)               # sum over batch and z-class: (nz, Y*X*C)
         gy = torch.einsum("ayxo,by->abxo", gz.view(-1, ys, xs, c), oy)
         gt = torch.einsum("abxo,cx->abco", gy, ox)
