@@ -196,7 +196,7 @@ def run_ponder_indoor(device):
     out["loss"].backward()
     errs = {}
     for name, val in zip(g["out_names"], g["out_values"]):
-        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+        errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
@@ -256,7 +256,7 @@ def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
     out["loss"].backward()
     errs = {}
     for name, val in zip(g["out_names"], g["out_values"]):
-        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+        errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
     for key in ("rgb", "depth", "normal"):
         errs["render_" + key] = rel_err(torch.cat(rendered[key]), g["render_" + key])
     params = dict(model.named_parameters())
@@ -326,7 +326,7 @@ def run_ponder_outdoor(device):
     out["loss"].backward()
     errs = {}
     for name, val in zip(g["out_names"], g["out_values"]):
-        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+        errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
@@ -401,20 +401,21 @@ def run_ponder_ppt(device):
     out["loss"].backward()
     errs = {}
     for name, val in zip(g["out_names"], g["out_values"]):
-        errs[str(name)] = abs(float(out[str(name)]) - val) / (abs(val) + 1e-12)
+        errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
     return errs
 
 
-def check_model_errors(errs, loss_tol=1e-4, rest_tol=5e-3, deep_tol=0.2):
+def check_model_errors(errs, loss_tol=1e-4, rest_tol=5e-3, deep_tol=5e-2):
     """Shared assertion of the end-to-end golden tests.  Every loss term to ``loss_tol`` (the north
     star's 1e-4 - no exception path).  Gradients that have crossed the sparse backbone's ~60
     BatchNorm layers (backbone parameters, the mask token, the context embedding) to ``deep_tol``:
     in these miniature scenes a different fp32 summation order alone (1 thread instead of 128 on
-    the host) moves them by a few percent while the loss moves by 1e-7..1e-4; every other gradient
-    to ``rest_tol``.
+    the host) moves them by up to ~3e-2 while the loss moves by 1e-7..1e-4 (measured with 128 host
+    threads: <= 4.4e-4; the GPU tests pass 5e-3); every other gradient to ``rest_tol`` (measured
+    <= 7.1e-4 on the host).
 
     The importance sampler inverts a CDF with ``searchsorted`` - integer work the full-size fixtures
     pin bit-exactly (tests/golden/ponder_indoor_cfg*.npz: ``pdf_bins``).  The GPU tests run the

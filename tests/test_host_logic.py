@@ -480,3 +480,82 @@ def test_optimizer_builder_prefers_the_fused_step_only_on_the_device(monkeypatch
     assert opt._prefer_fused(cfg, fake).get("fused") is True
     monkeypatch.setenv("PV2_FUSED_OPTIMIZER", "0")
     assert "fused" not in opt._prefer_fused(cfg, fake)
+
+
+def test_split_backward_conv_equals_the_library_convolution():
+    """unet3d._SplitBackwardConv issues grad-input and grad-weight as two ``convolution_backward``
+    calls (the second goes to the backward side stream on the device); values and all three
+    gradients equal ``nn.Conv3d`` / ``nn.ConvTranspose3d`` (with ``output_size``) exactly."""
+    import torch.nn as nn
+
+    from ponderv2_amd.ponder.models.ponder import unet3d as U
+
+    torch.manual_seed(0)
+    cases = [(nn.Conv3d(4, 6, 3, padding=1, bias=False), (2, 4, 5, 6, 7), None),
+             (nn.Conv3d(4, 6, 1), (2, 4, 5, 6, 7), None),
+             (nn.ConvTranspose3d(4, 3, 3, stride=2, padding=1), (2, 4, 3, 4, 5), [6, 7, 9])]
+    for mod, shape, out_size in cases:
+        x = torch.randn(*shape, requires_grad=True)
+        y = mod(x) if out_size is None else mod(x, out_size)
+        g = torch.randn_like(y)
+        y.backward(g)
+        ref = [x.grad.clone(), mod.weight.grad.clone(),
+               None if mod.bias is None else mod.bias.grad.clone()]
+        x.grad = None
+        mod.zero_grad()
+        transposed = isinstance(mod, nn.ConvTranspose3d)
+        pad = (tuple(mod._output_padding(x, out_size, mod.stride, mod.padding, mod.kernel_size, 3,
+                                         mod.dilation)) if transposed else (0, 0, 0))
+        y2 = U._SplitBackwardConv.apply(x, mod.weight, mod.bias, tuple(mod.stride), tuple(mod.padding),
+                                        tuple(mod.dilation), transposed, pad, mod.groups)
+        assert torch.equal(y, y2)
+        y2.backward(g)
+        assert torch.equal(x.grad, ref[0]) and torch.equal(mod.weight.grad, ref[1])
+        assert mod.bias is None or torch.equal(mod.bias.grad, ref[2])
+    # on host tensors the wrapper is the module itself (no side stream to feed)
+    conv = nn.Conv3d(32, 128, 1)
+    v = torch.randn(1, 32, 2, 3, 4)
+    assert torch.equal(U.library_conv(conv, v), conv(v)) and not U.pointwise_conv_supported(conv, v)
+
+
+def test_side_stream_switches_and_leaf_rule():
+    from ponderv2_amd import sidestream
+
+    w = torch.nn.Parameter(torch.zeros(4, 3))
+    assert sidestream.safe_leaf(w) and sidestream.safe_leaf(w.reshape(2, 6))   # a leaf / a view of one
+    assert not sidestream.safe_leaf(w.t().contiguous() * 1.0)                    # a copy: not a leaf
+    w.grad = torch.zeros_like(w)
+    assert not sidestream.safe_leaf(w.reshape(2, 6))                             # autograd would ADD
+    assert not sidestream.active(w)                                              # host tensor, no backward
+    was = sidestream.ENABLED
+    try:
+        sidestream.disable("test")
+        assert not sidestream.ENABLED and "test" in sidestream.status()
+        sidestream.enable()
+        assert sidestream.status() == ("on" if sidestream.ENABLED else "off (PV2_WGRAD_STREAM=0)")
+    finally:
+        sidestream.ENABLED = was
+
+
+def test_border_class_table_equals_the_full_size_constant_part():
+    """sparse_input._constant_part: the (3,3,3,C) class table expanded by a row gather equals the
+    response of a zero-padded 3x3x3 conv to a constant field, computed the long way, with its
+    gradients - including axes of size 1 and 2, where "first" and "last" coincide or touch."""
+    import torch.nn.functional as F
+
+    from ponderv2_amd.ponder.models.ponder import sparse_input as si
+
+    torch.manual_seed(0)
+    for dims in ((5, 4, 3), (1, 2, 6), (2, 1, 1)):
+        weight = torch.randn(5, 4, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        y0 = torch.randn(4, dtype=torch.float64, requires_grad=True)
+        bias = torch.randn(5, dtype=torch.float64, requires_grad=True)
+        got = si._constant_part(weight, y0, bias, 2, dims)
+        field = y0[None, :, None, None, None].expand(2, 4, *dims)
+        ref = F.conv3d(field, weight, bias, padding=1).permute(0, 2, 3, 4, 1).reshape(-1, 5)
+        assert torch.allclose(got, ref, atol=1e-12)
+        probe = torch.randn_like(ref)
+        g_got = torch.autograd.grad((got * probe).sum(), (weight, y0, bias))
+        g_ref = torch.autograd.grad((ref * probe).sum(), (weight, y0, bias))
+        for a, b in zip(g_got, g_ref):
+            assert torch.allclose(a, b, atol=1e-10)
