@@ -149,10 +149,24 @@ class _HostFieldRender(torch.autograd.Function):
                 g["b_rgb"], g["inv_s"].reshape(ctx.inv_s_shape), None, None)
 
 
+def _materialise(x5, wfp):
+    """V = Wf X + bf on every cell: what the folded head samples implicitly (wfp = [Wf | bf | 0])."""
+    kx = x5.shape[-1]
+    return x5 @ wfp[:, :kx].t() + wfp[:, kx]
+
+
+def _host_field_render_folded(x5, wfp, *head):
+    """Host double of ponderv2_amd.fused_head.field_render_folded: by definition the unfolded
+    operation on the materialised volume (autograd carries the gradients to x5 and wfp)."""
+    return _HostFieldRender.apply(_materialise(x5, wfp), *head)
+
+
 def _host_coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_rand,
-                        n_importance, MW, c0, bc1, W1, b1, base_inv_s, debug=False):
+                        n_importance, MW, c0, bc1, W1, b1, base_inv_s, debug=False, wfs=None):
     from oracle import fused_head as fh
 
+    if wfs is not None:   # folded final convolution: the SDF half of the volume, materialised
+        vol5 = _materialise(vol5.detach(), wfs.detach())
     with torch.no_grad():
         res = fh.coarse_sample(vol5, origins, dirs, nears, fars, lin_bins.to(vol5.dtype), t_rand,
                                u_rand, n_importance, MW, c0, bc1, W1[0], b1[0], base_inv_s,
@@ -212,3 +226,5 @@ def install(monkeypatch):
     monkeypatch.setattr(fhead, "device_ok", lambda t: True)
     monkeypatch.setattr(fhead, "coarse_sample", _host_coarse_sample)
     monkeypatch.setattr(fhead, "field_render", _HostFieldRender.apply)
+    monkeypatch.setattr(fhead, "field_render_folded", _host_field_render_folded)
+    monkeypatch.setattr(fhead, "fold_supported", fhead.fold_shape_ok)

@@ -94,24 +94,30 @@ class FoldedVolume:
     def rows(self):
         """(x5, wfp): the (B,Z,Y,X,32) channels-last fp32 view of the activations and the
         [C_out, 40] matrix [Wf | bf | 0] (built by torch ops: gradients reach the module)."""
-        x5 = self.pre.permute(0, 2, 3, 4, 1).float()
+        widen = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+        x5 = widen(self.pre.permute(0, 2, 3, 4, 1))   # (float64 stays: the host doubles of the tests)
         x5 = x5 if x5.is_contiguous() else x5.contiguous()
         conv = self.conv
-        wf = conv.weight.reshape(conv.out_channels, conv.in_channels).float()
-        bf = (conv.bias.float() if conv.bias is not None
-              else torch.zeros(conv.out_channels, dtype=torch.float32, device=wf.device))
-        pad = torch.zeros((conv.out_channels, KXP - KX - 1), dtype=torch.float32, device=wf.device)
+        wf = widen(conv.weight.reshape(conv.out_channels, conv.in_channels)).to(x5.dtype)
+        bf = (widen(conv.bias).to(x5.dtype) if conv.bias is not None
+              else torch.zeros(conv.out_channels, dtype=x5.dtype, device=wf.device))
+        pad = torch.zeros((conv.out_channels, KXP - KX - 1), dtype=x5.dtype, device=wf.device)
         return x5, torch.cat([wf, bf[:, None], pad], dim=1)
 
 
+def fold_shape_ok(conv, x):
+    """``conv`` is a 1x1x1 / stride 1 nn.Conv3d from KX to FS + F2 channels on a 5-D input: the
+    shape the folded kernels are compiled for."""
+    return (FOLD_ENABLED and ENABLED and isinstance(conv, torch.nn.Conv3d) and x.dim() == 5
+            and tuple(conv.kernel_size) == (1, 1, 1) and tuple(conv.stride) == (1, 1, 1)
+            and tuple(conv.padding) == (0, 0, 0) and conv.groups == 1
+            and conv.in_channels == KX and conv.out_channels == FS + F2)
+
+
 def fold_supported(conv, x):
-    """``conv`` is a 1x1x1 / stride 1 nn.Conv3d from KX to FS + F2 channels and ``x`` its device
-    input: the shape the folded kernels are compiled for."""
-    return (FOLD_ENABLED and ENABLED and isinstance(conv, torch.nn.Conv3d) and x.is_cuda
-            and x.dim() == 5 and tuple(conv.kernel_size) == (1, 1, 1)
-            and tuple(conv.stride) == (1, 1, 1) and tuple(conv.padding) == (0, 0, 0)
-            and conv.groups == 1 and conv.in_channels == KX and conv.out_channels == FS + F2
-            and conv.weight.dtype == torch.float32
+    """``fold_shape_ok`` on a device volume in a type the kernels take (the tests' host doubles
+    replace this by the shape check alone)."""
+    return (fold_shape_ok(conv, x) and x.is_cuda and conv.weight.dtype == torch.float32
             and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
 

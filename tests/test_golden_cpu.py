@@ -22,8 +22,23 @@ def test_neus_head_matches_reference(cpu_kernels):
     assert max(errs.values()) < 2e-4, errs
 
 
-def test_ponder_indoor_forward_matches_reference(cpu_kernels):
-    gc.check_model_errors(gc.run_ponder_indoor(torch.device("cpu")))
+def test_ponder_indoor_forward_matches_reference(cpu_kernels, monkeypatch):
+    """The reference's indoor golden through the product's host code.  The projection network hands
+    the head a FoldedVolume (its final 1x1x1 convolution applied per sample); with the fold
+    switched off the materialised volume gives the same numbers."""
+    from ponderv2_amd import fused_head as fhd
+
+    calls = []
+    orig = fhd.field_render_folded
+    monkeypatch.setattr(fhd, "field_render_folded", lambda *a: (calls.append(1), orig(*a))[1])
+    folded = gc.run_ponder_indoor(torch.device("cpu"))
+    gc.check_model_errors(folded)
+    assert len(calls) == 1
+    monkeypatch.setattr(fhd, "FOLD_ENABLED", False)
+    plain = gc.run_ponder_indoor(torch.device("cpu"))
+    gc.check_model_errors(plain)
+    assert len(calls) == 1
+    assert all(abs(folded[k] - plain[k]) < 2e-4 for k in folded), (folded, plain)
 
 
 def test_ponder_outdoor_forward_matches_reference(cpu_kernels):
