@@ -229,6 +229,30 @@ class SingleConv(nn.Sequential):
         return x
 
 
+# ATen has no channels-last kernel for max_pool3d: it transposes the input to (N, T, C, H, W) and the
+# gradient back - at the full-resolution level one 0.50 ms strided copy forward and a 0.20 ms strided
+# ReLU backward behind it per step.  ``channels_last_max_pool3d`` gets the same
+# pooling from kernels that DO know the layout.  Not measured on MI355X yet (written after the
+# round's GPU budget was spent), hence opt-in: PV2_CL_MAXPOOL=1.
+CL_MAXPOOL = os.environ.get("PV2_CL_MAXPOOL", "0") == "1"
+
+
+def channels_last_max_pool3d(x):
+    """``F.max_pool3d(x, 2)`` for a channels-last-3d ``x`` (B, C, Z, Y, X) without leaving the
+    layout: a 2x2 ``max_pool2d`` over (Y, X) on the ``(B*Z, C, Y, X)`` channels-last-2d view of the
+    same memory (ATen's NHWC kernel), then the maximum over pairs of z-slices.  Same values; the
+    gradient goes to one maximum per window as in max_pool3d (they can only differ in WHICH one on
+    exact ties, which after a ReLU are zeros whose gradient the ReLU drops anyway)."""
+    b, c, z, y, xx = x.shape
+    z2 = z // 2
+    rows = x.permute(0, 2, 3, 4, 1)[:, :2 * z2]                       # (B, 2*z2, Y, X, C), a view
+    planes = rows.reshape(b * 2 * z2, y, xx, c).permute(0, 3, 1, 2)    # (B*Z, C, Y, X) channels-last
+    pooled = torch.nn.functional.max_pool2d(planes, 2)                 # (B*Z, C, Y/2, X/2), NHWC
+    y2, x2 = pooled.shape[2], pooled.shape[3]
+    pairs = pooled.permute(0, 2, 3, 1).reshape(b, z2, 2, y2, x2, c)
+    return pairs.max(dim=2).values.permute(0, 4, 1, 2, 3)              # (B, C, Z/2, Y/2, X/2), channels-last
+
+
 class Encoder(nn.Module):
     def __init__(self, in_channels, out_channels, apply_pooling=True, order="bcr", num_groups=8):
         super().__init__()
@@ -238,7 +262,11 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         if self.pooling is not None:
-            x = self.pooling(x)
+            if (CL_MAXPOOL and x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d)
+                    and not x.is_contiguous()):
+                x = channels_last_max_pool3d(x)
+            else:
+                x = self.pooling(x)
         return self.basic_module(x)
 
 

@@ -559,3 +559,24 @@ def test_border_class_table_equals_the_full_size_constant_part():
         g_ref = torch.autograd.grad((ref * probe).sum(), (weight, y0, bias))
         for a, b in zip(g_got, g_ref):
             assert torch.allclose(a, b, atol=1e-10)
+
+
+def test_channels_last_max_pool_equals_max_pool3d():
+    """unet3d.channels_last_max_pool3d (2-D NHWC pooling + maximum over z pairs; opt-in) against
+    ``F.max_pool3d(x, 2)``: values exactly, gradients exactly away from ties; odd extents are
+    floored the same way; the result stays channels-last."""
+    import torch.nn.functional as F
+
+    from ponderv2_amd.ponder.models.ponder.unet3d import channels_last_max_pool3d
+
+    torch.manual_seed(0)
+    for shape in ((2, 8, 4, 6, 10), (1, 3, 5, 7, 9)):
+        x = torch.randn(*shape, dtype=torch.float64).contiguous(memory_format=torch.channels_last_3d)
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        got, ref = channels_last_max_pool3d(a), F.max_pool3d(b, 2)
+        assert torch.equal(got, ref) and got.is_contiguous(memory_format=torch.channels_last_3d)
+        probe = torch.randn_like(ref)
+        (got * probe).sum().backward()
+        (ref * probe).sum().backward()
+        assert torch.equal(a.grad, b.grad)
