@@ -589,7 +589,6 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("PV2_MIOPEN_SEARCH", "0") == "1"
     outdoor = args.workload == "outdoor"
     ppt = args.workload == "ppt"
-    ppt_modular = False
     cfg = model_cfg(args.rays_per_view, args.dense_dtype, args.workload, args.config)
     full = load_config(args.workload, args.config)
     model = build_model(ConfigDict(cfg)).to(device).train()
@@ -771,7 +770,7 @@ def main():
             "backward_side_stream": side_state,
             "render_head": (("fused ray-march kernels (csrc/raymarch_fused.hip)"
                              + (", UNet3D's final 1x1x1 convolution folded in per sample"
-                                if fused_head.FOLD_ENABLED and not ppt_modular else ""))
+                                if fused_head.FOLD_ENABLED else ""))
                             if fused_head.ENABLED and not outdoor else "modular (torch ops + kernels)"),
         }
         if kernels:
