@@ -43,8 +43,6 @@ int pv2_abi_version(void);
  * issued from this library while the stream was being captured into a hipGraph was not replayed
  * with the graph (stale bias gradients in the render head until it was replaced). */
 int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream);
-/* Debug only: kernel ablation flags used by tools/bench_spconv_kernels.py (0 = production). */
-int pv2_debug_set_ablate(int flags);
 int pv2_debug_set_os16_variant(int v); /* tuning knob of pv2_spconv16_os_forward (tools/bench_spconv16.py) */
 const char* pv2_last_error(void);
 
@@ -175,24 +173,6 @@ int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const fl
                           int kflip, const float* bias, float* out_feat, int64_t n_out,
                           pv2_stream_t stream);
 
-/* Output-stationary conv with an LDS accumulator tile, for rulebooks in canonical (k, output row)
- * order whose output rows are the natural row range (submanifold convs): a workgroup owns 64 or 128
- * consecutive output rows, walks the K offsets, processes its pairs of each offset COMPACTED (32
- * per MFMA row block), adds the result blocks into the LDS tile and writes every output element
- * once.  No atomics to memory, no zero-fill, bitwise reproducible.
- *   segments: seg[k*(T+1) + t] = first pair of offset k with pair_out >= 64*t, T = ceil(n_out/64);
- *             seg has K*(T+1) int32 entries.  Build once per rulebook.
- *   forward : out[o, n] = bias[n] + sum over pairs (i -> o, k) of in[i, :] . weight[n, kw(k), :],
- *             kw(k) = kflip ? K-1-k : k;  c_in % 32 == 0, c_out % 4 == 0.
- * Grad-input of a submanifold conv = forward on grad_out with the transposed weights
- * [c_in, K, c_out] and kflip = 1 on the SAME pair lists. */
-int pv2_spconv_osl_segments(const int32_t* pair_out, const int32_t* kstart, int K, int64_t n_out,
-                            int32_t* seg, pv2_stream_t stream);
-int pv2_spconv_osl_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
-                           int c_out, const int32_t* pair_in, const int32_t* pair_out,
-                           const int32_t* seg, int kflip, const float* bias, float* out_feat,
-                           int64_t n_out, pv2_stream_t stream);
-
 /* grad wrt weight:  dW[n, k, c] += sum_{p in k} dout[pair_out[p], n] * in[pair_in[p], c].
  * dweight must be zero-initialised by the caller.  Here tile_start / n_tiles count chunks of
  * tile_pairs = pv2_spconv_wgrad_tile(c_in, c_out, n_pairs, K) pairs (PV2_WGRAD_TILE or 2048). */
@@ -205,6 +185,92 @@ int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, con
                                float* dweight, pv2_stream_t stream);
 /* (grad wrt input is pv2_spconv_forward with pair_in/pair_out swapped and weight transposed to
  *  [c_in, K, c_out].) */
+
+/* The same weight gradient in a DETERMINISTIC two-stage form (c_in % 4 == 0, c_out % 4 == 0): every
+ * chunk of pairs writes its block of partial sums with plain stores into its own slab of `partial`
+ * (pv2_spconv_wgrad_partial_floats(c_in, c_out, n_tiles) floats, uninitialised), then one pass adds
+ * the slabs of each offset in slab order and writes EVERY element of dweight (which therefore needs
+ * no clearing).  No atomics: bitwise identical results on every run. */
+int64_t pv2_spconv_wgrad_partial_floats(int c_in, int c_out, int64_t n_tiles);
+int pv2_spconv_backward_weight_det(const float* in_feat, int64_t n_in, int c_in, const float* dout,
+                                   int64_t n_out, int c_out, int K, const int32_t* pair_in,
+                                   const int32_t* pair_out, const int32_t* kstart,
+                                   const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                                   float* partial, float* dweight, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Product-row form of the same convolutions (csrc/sparse_conv_pr.hip; same reference call sites:
+ * spconv_unet_v1m1_base.py:41,47,58,112,135,171): no atomics, no zero-fill, bitwise reproducible.
+ *
+ *   stage 1  pv2_spconv_products:   prod[p, :] = W[k(p)] . in[pair_in[p], :]  for every pair p of
+ *            the canonical (offset, output row) list - the pair-major MFMA GEMM of
+ *            pv2_spconv_forward with one result row per PAIR (plain stores).  c_in % 32 == 0;
+ *            tile_start / n_tiles count 128-pair tiles.  weight_reduction_major != 0: the weight is
+ *            given as [c_in, K, c_out] (pv2_spconv_forward_wt's layout; grad-input reads the
+ *            forward weight in place), c_out % 4 == 0.  prod: n_pairs x c_out floats.
+ *   stage 2  pv2_spconv_reduce_rows: out[o, :] = (addend[o, :] + bias) + sum over k ascending of
+ *            prod[pos[k*pos_stride + o], :] (entries < 0 skipped); c % 4 == 0, K <= 32.  addend and
+ *            bias may be NULL.  bn_partial != NULL: also the BatchNorm forward statistics of `out`
+ *            as per-block partial column sums (<= 1024 blocks x 2c floats, the workspace of
+ *            pv2_bn_forward; *bn_blocks receives the block count), shifted by row 0.
+ *   pv2_pair_positions: the position tables of a rulebook.  pos_out[k*out_stride + pair_out[p]] = p
+ *            and pos_in[k*in_stride + pair_in[p]] = p for p < kstart[K] (a device value;
+ *            n_pairs_bound >= it sizes the launch), every other entry -1.  Either table may be NULL.
+ *            A conv rulebook holds each (offset, row) at most once, so the tables are well defined.
+ * Grad-input = stage 1 on grad_out gathered by pair_out with the forward weight reduction-major,
+ * stage 2 over pos_in.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_pair_positions(const int32_t* pair_out, const int32_t* pair_in, const int32_t* kstart, int K,
+                       int64_t n_pairs_bound, int64_t out_stride, int64_t in_stride,
+                       int32_t* pos_out, int32_t* pos_in, pv2_stream_t stream);
+int pv2_spconv_products(const float* in_feat, int c_in, const float* weight, int K, int c_out,
+                        int weight_reduction_major, const int32_t* pair_in, const int32_t* kstart,
+                        const int32_t* tile_start, int64_t n_tiles, float* prod,
+                        pv2_stream_t stream);
+int pv2_spconv_reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
+                           int64_t n_rows, const float* bias, const float* addend, float* out,
+                           float* bn_partial, int* bn_blocks, pv2_stream_t stream);
+
+/* One conv -> BatchNorm1d -> (+ shortcut) -> ReLU unit of the backbone as ONE call per direction
+ * (BasicBlock.forward, spconv_unet_v1m1_base.py:70-83; the conv + norm_fn + ReLU stages :108,
+ * 120-121,143-145): the product-row conv, the statistics in its reduce epilogue, combine + apply.
+ * The geometry of the rulebook travels as one struct (device pointers + host sizes):
+ *   tile_start / n_tiles       prefix of 128-pair tiles per offset (pv2_tile_prefix)
+ *   tile_start_w / tile_pairs_w / n_tiles_w   the weight gradient's chunking (pv2_spconv_wgrad_tile)
+ *   pos_out / pos_in           position tables (pv2_pair_positions) with their row strides
+ * forward : y_conv = conv(x) [n_out, c_out] (kept for the backward), mean_invstd [2*c_out],
+ *           out = [relu]( bn(y_conv) [+ residual] ); running statistics updated as pv2_bn_forward.
+ *           prod_ws >= n_pairs * c_out floats, stats_ws = pv2_bn_workspace_floats(c_out).
+ * backward: gsum [2*c_out] = (d bias, d weight) of the BatchNorm, dy [n_out, c_out] = gradient of
+ *           y_conv (scratch the caller keeps alive until the side stream has joined), dres = masked
+ *           grad_out (NULL without a shortcut), dx [n_in, c_in] (NULL: not needed), dweight
+ *           [c_out, K, c_in] by the deterministic two-stage weight gradient on `side_stream` (NULL
+ *           handle: on `stream`) behind an event; part_ws >= pv2_spconv_wgrad_partial_floats(...).
+ *           prod_ws >= n_pairs * c_in floats.  out_or_null: the unit's output (the ReLU mask).
+ * c_in % 32 == 0 and c_out % 32 == 0 (every unit of SpUNet but the 6-channel stem). */
+typedef struct pv2_conv_geom {
+  int32_t K;
+  int32_t tile_pairs_w;
+  int64_t n_in, n_out, n_tiles, n_tiles_w, pos_out_stride, pos_in_stride;
+  const int32_t* pair_in;
+  const int32_t* pair_out;
+  const int32_t* kstart;
+  const int32_t* tile_start;
+  const int32_t* tile_start_w;
+  const int32_t* pos_out;
+  const int32_t* pos_in;
+} pv2_conv_geom;
+int pv2_convbn_forward(const pv2_conv_geom* g, const float* x, int c_in, const float* weight,
+                       int c_out, const float* bn_weight, const float* bn_bias,
+                       const float* residual, int relu, float eps, float momentum,
+                       float* running_mean, float* running_var, float* prod_ws, float* stats_ws,
+                       float* y_conv, float* mean_invstd, float* out, pv2_stream_t stream);
+int pv2_convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
+                        const float* weight, int c_out, const float* y_conv,
+                        const float* out_or_null, const float* mean_invstd, const float* bn_weight,
+                        float* prod_ws, float* stats_ws, float* gsum, float* dy,
+                        float* dres_or_null, float* dx_or_null, float* dweight_or_null,
+                        float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 MFMA GEMMs for the MLP heads of the render field (SDF / RGB / semantic decoders).

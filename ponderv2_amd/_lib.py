@@ -20,6 +20,15 @@ class VolumeDesc(Structure):
     _fields_ = [(k, c_int64) for k in ("n", "c", "d", "h", "w", "sn", "sc", "sd", "sh", "sw")]
 
 
+class ConvGeom(Structure):
+    """pv2_conv_geom: one rulebook as the fused conv + BatchNorm entry points take it."""
+    _fields_ = ([("K", c_int32), ("tile_pairs_w", c_int32)]
+                + [(k, c_int64) for k in ("n_in", "n_out", "n_tiles", "n_tiles_w", "pos_out_stride",
+                                          "pos_in_stride")]
+                + [(k, c_void_p) for k in ("pair_in", "pair_out", "kstart", "tile_start",
+                                           "tile_start_w", "pos_out", "pos_in")])
+
+
 class PointsDesc(Structure):
     _fields_ = [(k, c_int64) for k in ("n_points", "points_per_n", "o_sn", "o_sc", "o_sp")]
 
@@ -27,12 +36,11 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
     "pv2_last_error": (c_char_p, []),
-    "pv2_debug_set_ablate": (c_int, [c_int]),
     "pv2_debug_set_os16_variant": (c_int, [c_int]),
     "pv2_zero_fill": (c_int, [_P, c_int64, _P]),
     "pv2_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
@@ -53,9 +61,6 @@ SIGNATURES = {
     "pv2_table_masks": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
     "pv2_spconv_os_forward": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, c_int64, _P, c_int, _P, _P, c_int64, _P]),
-    "pv2_spconv_osl_segments": (c_int, [_P, _P, c_int, c_int64, _P, _P]),
-    "pv2_spconv_osl_forward": (
-        c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P]),
     "pv2_spconv_forward_wt": (
         c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, c_int64, _P]),
     "pv2_spconv16_packed_elems": (c_int64, [c_int, c_int, c_int]),
@@ -70,6 +75,20 @@ SIGNATURES = {
     "pv2_spconv_backward_weight": (
         c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P,
                 _P]),
+    "pv2_spconv_wgrad_partial_floats": (c_int64, [c_int, c_int, c_int64]),
+    "pv2_spconv_backward_weight_det": (
+        c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P,
+                _P]),
+    "pv2_pair_positions": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, _P, _P]),
+    "pv2_spconv_products": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int64, _P, _P]),
+    "pv2_spconv_reduce_rows": (
+        c_int, [_P, _P, c_int64, c_int, c_int, c_int64, _P, _P, _P, _P, POINTER(c_int), _P]),
+    "pv2_convbn_forward": (
+        c_int, [POINTER(ConvGeom), _P, c_int, _P, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P,
+                _P, _P, _P, _P, _P, _P]),
+    "pv2_convbn_backward": (
+        c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                _P, _P, _P, _P]),
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_bn_workspace_floats": (c_int64, [c_int]),

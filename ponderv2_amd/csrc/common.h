@@ -43,6 +43,24 @@ inline int grid_for(int64_t work_items, int block) {
   return (int)b;
 }
 
+// ---- internal (C++ linkage) entry points shared between translation units; the C ABI wraps them
+// sparse_conv.hip
+int spconv_products(bool trans, const float* in_feat, int c_in, const float* weight, int K,
+                    int c_out, const int32_t* pair_in, const int32_t* kstart,
+                    const int32_t* tile_start, int64_t n_tiles, float* prod, hipStream_t s);
+int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout, int64_t n_out,
+                 int c_out, int K, const int32_t* pair_in, const int32_t* pair_out,
+                 const int32_t* kstart, const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                 float* dweight, float* part, hipStream_t s);
+// rownorm.hip: the statistics kernels' partial-sum geometry (blocks <= 1024, rows per block) and the
+// second half of the fused BatchNorm forward - combine the per-block partial sums (written by
+// col_partials or by row_reduce_kernel's epilogue, shifted by row 0 of x) and apply.
+void bn_partial_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block);
+int bn_forward_from_partials(const float* x, int64_t n, int c, const float* partial, int blocks,
+                             const float* weight, const float* bias, const float* residual,
+                             int relu, float eps, float momentum, float* running_mean,
+                             float* running_var, float* mean_invstd, float* y, hipStream_t s);
+
 }  // namespace pv2
 
 #define PV2_REQUIRE(cond, msg)   \

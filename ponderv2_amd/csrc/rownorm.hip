@@ -447,6 +447,32 @@ int64_t pv2_bn_workspace_floats(int c) { return (int64_t)kMaxPartialBlocks * 2 *
 
 }  // extern "C"
 
+namespace pv2 {
+
+void bn_partial_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block) {
+  partial_geometry(n, c, blocks, rows_per_block);
+}
+
+int bn_forward_from_partials(const float* x, int64_t n, int c, const float* partial, int blocks,
+                             const float* weight, const float* bias, const float* residual,
+                             int relu, float eps, float momentum, float* running_mean,
+                             float* running_var, float* mean_invstd, float* y, hipStream_t s) {
+  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+                     partial, blocks, c, x, n, eps, momentum, running_mean, running_var,
+                     mean_invstd);
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((bn_apply_vec_kernel<F32, F32>), dim3(pv2::grid_for(n * c / 8, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<F32, F32>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  return pv2::check_launch("bn_forward_from_partials");
+}
+
+}  // namespace pv2
+
 namespace {
 
 template <typename EX, typename EY>

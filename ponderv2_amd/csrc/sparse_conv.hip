@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int n_groups,
-    float* __restrict__ Y, int ablate, int tile_base, int skip_lo, int skip_len, int store) {
+    float* __restrict__ Y, int tile_base, int skip_lo, int skip_len, int store) {
   constexpr int NT = 32 * NB;
   constexpr int LDT = NT + 4;  // row stride of the reduction-major (TRANS) slab
   __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
@@ -224,9 +224,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
   const int i = lane & 31, h = lane >> 5;
   const int p = p0 + wave * 32 + i;
   const bool pv = p < pend;
-  int row_in = pv ? pair_in[p] : 0;
-  const int row_out = pv ? pair_out[p] : -1;
-  if (ablate & 2) row_in = pv ? (p & 0x1ff) : 0;  // [ablation] contiguous rows instead of a gather
+  const int row_in = pv ? pair_in[p] : 0;
+  // store == 2: PRODUCT-ROW mode - the result of pair p is row p of Y (one row per pair, plain
+  // coalesced stores; the rows of one output voxel are summed in a fixed order by
+  // row_reduce_kernel, sparse_conv_pr.hip).  Otherwise rows go to pair_out[p].
+  const int row_out = pv ? (store == 2 ? p : pair_out[p]) : -1;
   const int n0 = grp * NT;
   const float* xrow = X + (int64_t)row_in * c_in + 4 * h;
 
@@ -304,13 +306,6 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     __syncthreads();
   }
 
-  if (ablate & 1) {  // [ablation] no scatter: keep the accumulators alive, write nothing
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[nb][r]));
-    return;
-  }
   int orow[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) orow[r] = __shfl(row_out, (r & 3) + 8 * (r >> 2) + 4 * h);
@@ -345,7 +340,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ dY, int c_out, int K,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
     const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int tile_pairs,
-    int n_ntile, int n_ctile, float* __restrict__ dW) {
+    int n_ntile, int n_ctile, float* __restrict__ dW, float* __restrict__ part) {
   static_assert(WN * WC * WK == 4, "4 waves");
   constexpr int TN = 64 * WN, TC = 64 * WC;
   constexpr int UA = TN / 32, UB = TC / 32;  // float4 staged per thread per step
@@ -440,6 +435,11 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     __syncthreads();
   }
 
+  // part != nullptr: the DETERMINISTIC two-stage form - every (chunk, split-K wave) writes its
+  // block of partial sums with plain stores into slab (tile * WK + wk) of `part` ([c_out, c_in]
+  // each); wgrad_reduce_kernel (sparse_conv_pr.hip) adds the slabs of an offset in a fixed order.
+  // Nothing to clear, no atomics, bitwise reproducible.
+  float* slab = part ? part + ((int64_t)tile * WK + wk) * c_out * c_in : nullptr;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int c = c0 + wc * 64 + b * 32 + i;
-          if (c < c_in) unsafeAtomicAdd(dW + ((int64_t)n * Kw + k) * c_in + c, acc[a][b][r]);
+          if (c < c_in) {
+            if (slab) slab[(int64_t)n * c_in + c] = acc[a][b][r];
+            else unsafeAtomicAdd(dW + ((int64_t)n * Kw + k) * c_in + c, acc[a][b][r]);
+          }
         }
       }
     }
@@ -688,238 +691,6 @@ __global__ __launch_bounds__(256) void spconv_os_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS-tile output-stationary kernel (submanifold convs: K <= 27 offsets): a workgroup keeps its
-// output rows x channels as an fp32 tile in LDS for the whole launch and writes every element once -
-// no atomics to memory, no zero-fill.  Exclusive (rows x channels) per wave, no barrier between
-// offsets, a three-stage software pipeline (chunk descriptor -> pair indices -> gathered rows and
-// weight rows -> MFMA) so that no load latency is exposed, and 16-row chunks
-// (v_mfma_f32_16x16x4_f32, same rate as 32x32x2) for finer compaction.
-//
-// Wave (cb, ph) owns output rows [row0 + ph*RW, +RW) x channels [n0 + 32 cb, +32).  Per offset k its
-// pairs are the contiguous run seg[k][blk .. blk + RW/64) of the canonical (k, output row) list; they
-// are cut into chunks of 16 and listed in LDS once (kChunkCap descriptors per row range), then
-// streamed: while chunk c's 8 * (c_in / 128 slabs) MFMA pairs execute, chunk c+1's rows and (when
-// the offset or slab changes) weight rows are in flight and chunk c+2's pair indices are being
-// read.  Results go into the wave's private part of the LDS tile with ds_add_f32; one coalesced
-// store per element at the end.  Deterministic: every element is owned by one wave, which adds its
-// contributions in the fixed order of the canonical list.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kChunkCap = 27 * 8;   // K <= 27 offsets x RW/16 chunks (RW <= 128)
-
-template <int NB, int RW>
-__global__ __launch_bounds__(256) void spconv_osl2_kernel(
-    const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
-    const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
-    const int32_t* __restrict__ seg, int n_tiles64, int kflip, const float* __restrict__ bias,
-    int64_t n_out, float* __restrict__ Y) {
-  constexpr int NPH = 4 / NB;          // row ranges per workgroup (NB in {1, 2, 4})
-  constexpr int TOUT = RW * NPH;
-  constexpr int NT = 32 * NB, LD = NT + 4;
-  constexpr int B64 = RW / 64;
-  __shared__ __attribute__((aligned(16))) float acc_s[TOUT * LD];
-  __shared__ int s_p0[NPH][kChunkCap];   // first pair of the chunk
-  __shared__ int s_kn[NPH][kChunkCap];   // offset k | valid rows << 8
-  __shared__ int s_cnt[NPH][32], s_src[NPH][32], s_base[NPH][32];
-  __shared__ int s_total[NPH];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 15, q = lane >> 4;
-  const int cb = wave % NB, ph = wave / NB;
-  const int64_t row0 = (int64_t)blockIdx.x * TOUT;
-  const int n0 = blockIdx.y * NT;
-
-  for (int e = tid; e < TOUT * LD; e += 256) acc_s[e] = 0.f;
-  // chunk lists: thread (l, k) counts offset k's pairs in row range l
-  {
-    const int l = tid >> 5, k = tid & 31;
-    if (l < NPH && k < K) {
-      const int b0 = ((int)blockIdx.x * NPH + l) * B64;
-      const int b1 = min(b0 + B64, n_tiles64);
-      const int32_t* sk = seg + (int64_t)k * (n_tiles64 + 1);
-      const int s = b0 < n_tiles64 ? sk[b0] : 0, e = b0 < n_tiles64 ? sk[b1] : 0;
-      s_src[l][k] = s;
-      s_cnt[l][k] = e - s;
-    }
-  }
-  __syncthreads();
-  if (tid < NPH) {
-    int base = 0;
-    for (int k = 0; k < K; ++k) {
-      s_base[tid][k] = base;
-      base += (s_cnt[tid][k] + 15) >> 4;
-    }
-    s_total[tid] = base;
-  }
-  __syncthreads();
-  {
-    const int l = tid >> 5, k = tid & 31;
-    if (l < NPH && k < K) {
-      const int n = s_cnt[l][k], s = s_src[l][k], base = s_base[l][k];
-      for (int j = 0; 16 * j < n; ++j) {
-        s_p0[l][base + j] = s + 16 * j;
-        s_kn[l][base + j] = k | (min(16, n - 16 * j) << 8);
-      }
-    }
-  }
-  __syncthreads();
-
-  const int total = s_total[ph];
-  const int nslab = (c_in + 127) >> 7;
-  const int64_t wave_row0 = row0 + (int64_t)ph * RW;
-  const float* wrow[2];
-  bool nok[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int n = n0 + cb * 32 + u * 16 + i;
-    nok[u] = n < c_out;
-    wrow[u] = W + (int64_t)(nok[u] ? n : 0) * K * c_in + 4 * q;
-  }
-
-  // pipeline state: unit = (chunk c, slab sl)
-  float4 a_cur[8], a_nxt[8], b_cur[2][8], b_nxt[2][8];
-  int in_cur = 0, ol_cur = -1, k_cur = -1;       // rows of the chunk being multiplied
-  int in_nxt = 0, ol_nxt = -1, k_nxt = -1, c_nxt = 0, sl_nxt = 0;
-  int in_n2 = 0, ol_n2 = -1, k_n2 = -1;          // indices of the chunk after next
-
-  auto load_idx = [&](int c, int* in, int* ol, int* k) {
-    if (c < total) {
-      const int kn = s_kn[ph][c];
-      const int p = s_p0[ph][c] + i;
-      const bool v = i < (kn >> 8);
-      *k = kn & 0xff;
-      *in = v ? pair_in[p] : 0;
-      *ol = v ? (int)(pair_out[p] - wave_row0) : -1;
-    } else {
-      *k = -1;
-      *in = 0;
-      *ol = -1;
-    }
-  };
-  auto load_a = [&](float4 (&a)[8], int in, int ol, int sl) {
-    const float* xrow = X + (int64_t)in * c_in + sl * 128 + 4 * q;
-    const int cw = min(128, c_in - sl * 128);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) a[s8] = ld4(xrow + 16 * s8, ol >= 0 && 16 * s8 < cw);
-  };
-  auto load_b = [&](float4 (&b)[2][8], int k, int sl) {
-    const int kw = kflip ? K - 1 - k : k;
-    const int cw = min(128, c_in - sl * 128);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
-        b[u][s8] = ld4(wrow[u] + (int64_t)kw * c_in + sl * 128 + 16 * s8, nok[u] && 16 * s8 < cw);
-  };
-
-  if (total > 0) {
-    load_idx(0, &in_nxt, &ol_nxt, &k_nxt);
-    load_idx(1, &in_n2, &ol_n2, &k_n2);
-    load_a(a_nxt, in_nxt, ol_nxt, 0);
-    load_b(b_nxt, k_nxt, 0);
-  }
-  int k_loaded = -1, sl_loaded = -1;   // which (k, slab) b_cur holds
-  f32x4 d[2];
-  const int n_units = total * nslab;
-  for (int u = 0; u < n_units; ++u) {
-    // ---- rotate: next -> current
-    const int c = c_nxt, sl = sl_nxt;
-    in_cur = in_nxt;
-    ol_cur = ol_nxt;
-    k_cur = k_nxt;
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) a_cur[s8] = a_nxt[s8];
-    if (k_cur != k_loaded || sl != sl_loaded) {
-#pragma unroll
-      for (int w2 = 0; w2 < 2; ++w2)
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) b_cur[w2][s8] = b_nxt[w2][s8];
-      k_loaded = k_cur;
-      sl_loaded = sl;
-    }
-    // ---- issue the loads of the next unit
-    if (u + 1 < n_units) {
-      if (sl + 1 < nslab) {
-        sl_nxt = sl + 1;            // same chunk, next slab of the reduction axis
-      } else {
-        c_nxt = c + 1;
-        sl_nxt = 0;
-        in_nxt = in_n2;
-        ol_nxt = ol_n2;
-        k_nxt = k_n2;
-        load_idx(c + 2, &in_n2, &ol_n2, &k_n2);
-      }
-      load_a(a_nxt, in_nxt, ol_nxt, sl_nxt);
-      if (k_nxt != k_loaded || sl_nxt != sl_loaded) load_b(b_nxt, k_nxt, sl_nxt);
-    }
-    // ---- multiply
-    if (sl == 0) {
-      d[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int cw = min(128, c_in - sl * 128);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) {
-      if (16 * s8 < cw) {
-#pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].x, b_cur[w2][s8].x, d[w2], 0, 0, 0);
-          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].y, b_cur[w2][s8].y, d[w2], 0, 0, 0);
-          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].z, b_cur[w2][s8].z, d[w2], 0, 0, 0);
-          d[w2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s8].w, b_cur[w2][s8].w, d[w2], 0, 0, 0);
-        }
-      }
-    }
-    // ---- accumulate into the tile after the chunk's last slab
-    if (sl == nslab - 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = __shfl(ol_cur, q * 4 + r);
-        if (orow >= 0) {
-          float* dst = &acc_s[(ph * RW + orow) * LD + cb * 32 + i];
-          atomicAdd(dst, d[0][r]);
-          atomicAdd(dst + 16, d[1][r]);
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  constexpr int Q = NT / 4;
-  for (int e4 = tid; e4 < TOUT * Q; e4 += 256) {
-    const int r = e4 / Q, c4 = (e4 % Q) * 4;
-    const int64_t orow = row0 + r;
-    const int nn = n0 + c4;
-    if (orow >= n_out || nn >= c_out) continue;
-    float4 v = *reinterpret_cast<const float4*>(&acc_s[r * LD + c4]);
-    if (bias) {
-      v.x += bias[nn];
-      v.y += bias[nn + 1];
-      v.z += bias[nn + 2];
-      v.w += bias[nn + 3];
-    }
-    *reinterpret_cast<float4*>(Y + orow * c_out + nn) = v;
-  }
-}
-
-// seg[k * (n_tiles64 + 1) + t] = first pair of offset k whose output row is >= 64 t (t = n_tiles64:
-// the end of the offset).  One thread per entry, binary search in the (k, output row) sorted list.
-__global__ void osl_segments_kernel(const int32_t* __restrict__ pair_out,
-                                    const int32_t* __restrict__ kstart, int K, int n_tiles64,
-                                    int32_t* __restrict__ seg) {
-  const int64_t total = (int64_t)K * (n_tiles64 + 1);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int k = (int)(e / (n_tiles64 + 1)), t = (int)(e % (n_tiles64 + 1));
-    int lo = kstart[k], hi = kstart[k + 1];
-    const int target = t * 64;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (pair_out[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    seg[e] = lo;
-  }
-}
-
 template <int NB>
 int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
@@ -941,44 +712,40 @@ int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const
   return pv2::check_launch("spconv_fwd");
 }
 
-int ablate_flags();
-
 template <int NB, bool TRANS>
 int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
                    const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
-                   float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi) {
+                   float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi,
+                   bool products = false) {
   const int n_groups = (c_out + NB * 32 - 1) / (NB * 32);
   if (n_tiles * n_groups > 0x7fffffffLL) {
     pv2::set_error("pv2_spconv_forward: grid too large");
     return PV2_E_BADARG;
   }
-  if (center_hi > center_lo) {
+  if (products) {  // one result row per pair, plain stores (Y = the product-row buffer)
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
+                       0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0, 0x7fffffff, 0, 2);
+  } else if (center_hi > center_lo) {
     // pass A: the centre offset touches every output row exactly once -> plain stores initialise
     // the output (no zero-fill, no atomics); pass B: every other offset accumulates on top.
     const int64_t nc = center_hi - center_lo;
     hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
-                       s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(),
+                       s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y,
                        (int)center_lo, 0x7fffffff, 0, 1);
     const int64_t rest = n_tiles - nc;
     if (rest > 0)
       hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(rest * n_groups)), dim3(256),
-                         0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
+                         0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0,
                          (int)center_lo, (int)nc, 0);
   } else {
     hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
-                       0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, ablate_flags(), 0,
+                       0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0,
                        0x7fffffff, 0, 0);
   }
   return pv2::check_launch("spconv_fwd_lds");
 }
 
 }  // namespace
-
-// Debug: ablation flags for tools/bench_spconv_kernels.py (0 in production).
-static int g_ablate = 0;
-namespace {
-int ablate_flags() { return g_ablate; }
-}
 
 // Debug switch: PV2_SPCONV_GENERIC=1 routes everything to the generic (v1) kernels.
 static bool force_generic() {
@@ -991,17 +758,157 @@ static bool force_generic() {
 
 extern "C" {
 
-int pv2_debug_set_ablate(int flags) {
-  g_ablate = flags;
-  return PV2_OK;
-}
-
 int pv2_spconv_forward_tile(int c_in, int c_out) {
   (void)c_out;
   return ((c_in % kKC) == 0 && !force_generic()) ? kFwdTile : PV2_PAIR_TILE;
 }
 
 }  // extern "C"
+
+
+// split-K factor over the waves of a weight-gradient workgroup (see spconv_wgrad_lds_kernel)
+static int wgrad_split_k(int c_in, int c_out) {
+  const bool big_n = c_out > 64, big_c = c_in > 64;
+  return (big_n && big_c) ? 1 : (big_n || big_c) ? 2 : 4;
+}
+
+namespace {
+
+// dW[n, k, c] = sum over the partial slabs of offset k, in slab order (fixed): the second stage of
+// the deterministic weight gradient.  One thread per 16 bytes of dW; writes EVERY element (zeros for
+// offsets without pairs), so dW needs no clearing.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
+    const float4* __restrict__ part, const int32_t* __restrict__ tile_start, int K, int wk,
+    int c_out, int c_in4, float4* __restrict__ dW) {
+  const int64_t total = (int64_t)c_out * K * c_in4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c4 = (int)(e % c_in4);
+    const int k = (int)((e / c_in4) % K);
+    const int n = (int)(e / ((int64_t)c_in4 * K));
+    const int64_t t0 = (int64_t)tile_start[k] * wk, t1 = (int64_t)tile_start[k + 1] * wk;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t slab4 = (int64_t)c_out * c_in4;
+    const float4* src = part + (int64_t)n * c_in4 + c4;
+    int64_t t = t0;
+    for (; t + 4 <= t1; t += 4) {  // four loads in flight, added in slab order
+      const float4 v0 = src[t * slab4], v1 = src[(t + 1) * slab4];
+      const float4 v2 = src[(t + 2) * slab4], v3 = src[(t + 3) * slab4];
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; t < t1; ++t) {
+      const float4 v = src[t * slab4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    dW[e] = acc;
+  }
+}
+
+}  // namespace
+
+namespace pv2 {
+
+// Weight gradient.  part == nullptr: workgroups add their blocks into the zero-initialised dweight
+// with atomics.  part != nullptr (c_in % 4 == 0, c_out % 4 == 0): two-stage deterministic form.
+int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout, int64_t n_out,
+                 int c_out, int K, const int32_t* pair_in, const int32_t* pair_out,
+                 const int32_t* kstart, const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                 float* dweight, float* part, hipStream_t s) {
+  PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_backward_weight: bad sizes");
+  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE || tile_pairs == kMaxWgradTile,
+              "pv2_spconv_backward_weight: tile_pairs must be 512 or 2048");
+  (void)n_in;
+  (void)n_out;
+  const bool lds = (c_in % 4) == 0 && (c_out % 4) == 0 && !force_generic();
+  PV2_REQUIRE(part == nullptr || lds,
+              "pv2_spconv_backward_weight_det: channel counts must be multiples of 4");
+  if (n_tiles == 0 && part == nullptr) return PV2_OK;
+  if (lds) {
+    const bool big_n = c_out > 64, big_c = c_in > 64;
+    const int n_ntile = (c_out + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
+    const int n_ctile = (c_in + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
+    const int64_t blocks = n_tiles * n_ntile * n_ctile;
+    if (blocks > 0x7fffffffLL) {
+      pv2::set_error("pv2_spconv_backward_weight: grid too large");
+      return PV2_E_BADARG;
+    }
+#define PV2_LAUNCH_WGRAD_LDS(WN, WC, WK)                                                          \
+  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, false>), dim3((unsigned)blocks),        \
+                     dim3(256), 0, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart,   \
+                     tile_start, tile_pairs, n_ntile, n_ctile, dweight, part)
+    if (blocks > 0) {
+      if (big_n && big_c) PV2_LAUNCH_WGRAD_LDS(2, 2, 1);
+      else if (big_n) PV2_LAUNCH_WGRAD_LDS(2, 1, 2);
+      else if (big_c) PV2_LAUNCH_WGRAD_LDS(1, 2, 2);
+      else PV2_LAUNCH_WGRAD_LDS(1, 1, 4);
+    }
+#undef PV2_LAUNCH_WGRAD_LDS
+    if (part != nullptr) {
+      const int64_t total4 = (int64_t)c_out * K * (c_in / 4);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pv2::grid_for(total4, 256)), dim3(256), 0, s,
+                         (const float4*)part, tile_start, K, wgrad_split_k(c_in, c_out), c_out,
+                         c_in / 4, (float4*)dweight);
+    }
+    return pv2::check_launch("spconv_wgrad_lds");
+  }
+  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE, "pv2_spconv_backward_weight: generic path needs 512");
+  const int n_nblk = (c_out + 31) / 32;
+  const int cblk = (c_in + 31) / 32;
+  const int cb = cblk >= 4 ? 4 : (cblk >= 2 ? 2 : 1);
+  const int n_cgrp = (cblk + cb - 1) / cb;
+  const int64_t n_items = n_tiles * n_nblk * n_cgrp;
+  const int64_t blocks = (n_items + 3) / 4;
+  if (blocks > 0x7fffffffLL) {
+    pv2::set_error("pv2_spconv_backward_weight: grid too large");
+    return PV2_E_BADARG;
+  }
+#define PV2_LAUNCH_WGRAD(CB)                                                                     \
+  hipLaunchKernelGGL((spconv_wgrad_kernel<CB>), dim3((unsigned)blocks), dim3(256), 0, s, in_feat, \
+                     c_in, dout, c_out, K, pair_in, pair_out, kstart, tile_start, n_items,       \
+                     n_nblk, n_cgrp, dweight)
+  if (cb == 4) PV2_LAUNCH_WGRAD(4);
+  else if (cb == 2) PV2_LAUNCH_WGRAD(2);
+  else PV2_LAUNCH_WGRAD(1);
+#undef PV2_LAUNCH_WGRAD
+  return pv2::check_launch("spconv_wgrad");
+}
+
+}  // namespace pv2
+
+namespace pv2 {
+
+// Stage one of the product-row convolution: prod[p, :] = W[k(p)] . in[pair_in[p], :] for every pair
+// p of the canonical list (trans: weight given reduction-major, as pv2_spconv_forward_wt).
+int spconv_products(bool trans, const float* in_feat, int c_in, const float* weight, int K,
+                    int c_out, const int32_t* pair_in, const int32_t* kstart,
+                    const int32_t* tile_start, int64_t n_tiles, float* prod, hipStream_t s) {
+  PV2_REQUIRE(c_in >= kKC && (c_in % kKC) == 0 && c_out >= 1 && K >= 1,
+              "pv2_spconv_products: c_in must be a multiple of 32");
+  PV2_REQUIRE(!trans || (c_out % 4) == 0, "pv2_spconv_products: c_out must be a multiple of 4");
+  if (n_tiles == 0) return PV2_OK;
+  const int nblk = (c_out + 31) / 32;
+#define PV2_PROD_ARGS in_feat, c_in, weight, K, c_out, pair_in, nullptr, kstart, tile_start, n_tiles, prod, s, 0, 0, true
+  if (trans) {
+    switch (nblk >= 4 ? 4 : nblk) {
+      case 1: return launch_fwd_lds<1, true>(PV2_PROD_ARGS);
+      case 2: return launch_fwd_lds<2, true>(PV2_PROD_ARGS);
+      case 3: return launch_fwd_lds<3, true>(PV2_PROD_ARGS);
+      default: return launch_fwd_lds<4, true>(PV2_PROD_ARGS);
+    }
+  }
+  switch (nblk >= 4 ? 4 : nblk) {
+    case 1: return launch_fwd_lds<1, false>(PV2_PROD_ARGS);
+    case 2: return launch_fwd_lds<2, false>(PV2_PROD_ARGS);
+    case 3: return launch_fwd_lds<3, false>(PV2_PROD_ARGS);
+    default: return launch_fwd_lds<4, false>(PV2_PROD_ARGS);
+  }
+#undef PV2_PROD_ARGS
+}
+
+}  // namespace pv2
 
 static int spconv_forward_impl(bool trans, const float* in_feat, int64_t n_in, int c_in,
                                const float* weight, int K, int c_out, const int32_t* pair_in,
@@ -1110,105 +1017,27 @@ int pv2_spconv_os_forward(const float* in_feat, int64_t n_in, int c_in, const fl
   return pv2::check_launch("spconv_os_forward");
 }
 
-int pv2_spconv_osl_segments(const int32_t* pair_out, const int32_t* kstart, int K, int64_t n_out,
-                            int32_t* seg, pv2_stream_t stream) {
-  PV2_REQUIRE(K >= 1 && n_out >= 0 && n_out < 0x7fffffffLL, "pv2_spconv_osl_segments: bad sizes");
-  const int n_tiles64 = (int)((n_out + 63) / 64);
-  hipLaunchKernelGGL(osl_segments_kernel, dim3(pv2::grid_for((int64_t)K * (n_tiles64 + 1), 256)),
-                     dim3(256), 0, (hipStream_t)stream, pair_out, kstart, K, n_tiles64, seg);
-  return pv2::check_launch("spconv_osl_segments");
-}
-
-int pv2_spconv_osl_forward(const float* in_feat, int64_t n_in, int c_in, const float* weight, int K,
-                           int c_out, const int32_t* pair_in, const int32_t* pair_out,
-                           const int32_t* seg, int kflip, const float* bias, float* out_feat,
-                           int64_t n_out, pv2_stream_t stream) {
-  PV2_REQUIRE(c_in >= 32 && (c_in % 32) == 0, "pv2_spconv_osl_forward: c_in must be a multiple of 32");
-  PV2_REQUIRE(c_out >= 4 && K >= 1 && K <= 27 && (c_out % 4) == 0,
-              "pv2_spconv_osl_forward: c_out % 4 == 0 and K <= 27");
-  PV2_REQUIRE(n_out >= 0 && n_out < 0x7fffffffLL, "pv2_spconv_osl_forward: bad row count");
-  (void)n_in;
-  if (n_out == 0) return PV2_OK;
-  const int n_tiles64 = (int)((n_out + 63) / 64);
-  const int nblk = (c_out + 31) / 32;
-  const int nb = nblk >= 3 ? 4 : nblk;           // 96 channels run as 4 blocks, one of them masked
-  const int groups = (nblk + nb - 1) / nb;
-  const int nph = 4 / nb;
-  // 128 rows per wave compact better (16-row chunks of ~36 pairs per offset); 64 keep the coarse
-  // levels' few thousand rows spread over the CUs
-  const bool big = ((n_out + 128LL * nph - 1) / (128LL * nph)) * groups >= 160;
-  const int rw = big ? 128 : 64;
-  const int64_t tiles = (n_out + (int64_t)rw * nph - 1) / ((int64_t)rw * nph);
-  const dim3 grid((unsigned)tiles, (unsigned)groups);
-  hipStream_t s = (hipStream_t)stream;
-#define PV2_LAUNCH_OSL2(NB, RW)                                                                     \
-  hipLaunchKernelGGL((spconv_osl2_kernel<NB, RW>), grid, dim3(256), 0, s, in_feat, c_in, weight, K, \
-                     c_out, pair_in, pair_out, seg, n_tiles64, kflip, bias, n_out, out_feat)
-  if (big) {
-    if (nb == 1) PV2_LAUNCH_OSL2(1, 128);
-    else if (nb == 2) PV2_LAUNCH_OSL2(2, 128);
-    else PV2_LAUNCH_OSL2(4, 128);
-  } else {
-    if (nb == 1) PV2_LAUNCH_OSL2(1, 64);
-    else if (nb == 2) PV2_LAUNCH_OSL2(2, 64);
-    else PV2_LAUNCH_OSL2(4, 64);
-  }
-#undef PV2_LAUNCH_OSL2
-  return pv2::check_launch("spconv_osl_forward");
-}
-
 int pv2_spconv_backward_weight(const float* in_feat, int64_t n_in, int c_in, const float* dout,
                                int64_t n_out, int c_out, int K, const int32_t* pair_in,
                                const int32_t* pair_out, const int32_t* kstart,
                                const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
                                float* dweight, pv2_stream_t stream) {
-  PV2_REQUIRE(c_in >= 1 && c_out >= 1 && K >= 1, "pv2_spconv_backward_weight: bad sizes");
-  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE || tile_pairs == kMaxWgradTile,
-              "pv2_spconv_backward_weight: tile_pairs must be 512 or 2048");
-  (void)n_in;
-  (void)n_out;
-  if (n_tiles == 0) return PV2_OK;
-  hipStream_t s = (hipStream_t)stream;
-  if ((c_in % 4) == 0 && (c_out % 4) == 0 && !force_generic()) {
-    const bool big_n = c_out > 64, big_c = c_in > 64;
-    const int n_ntile = (c_out + (big_n ? 127 : 63)) / (big_n ? 128 : 64);
-    const int n_ctile = (c_in + (big_c ? 127 : 63)) / (big_c ? 128 : 64);
-    const int64_t blocks = n_tiles * n_ntile * n_ctile;
-    if (blocks > 0x7fffffffLL) {
-      pv2::set_error("pv2_spconv_backward_weight: grid too large");
-      return PV2_E_BADARG;
-    }
-#define PV2_LAUNCH_WGRAD_LDS(WN, WC, WK)                                                          \
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, false>), dim3((unsigned)blocks),        \
-                     dim3(256), 0, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart,   \
-                     tile_start, tile_pairs, n_ntile, n_ctile, dweight)
-    if (big_n && big_c) PV2_LAUNCH_WGRAD_LDS(2, 2, 1);
-    else if (big_n) PV2_LAUNCH_WGRAD_LDS(2, 1, 2);
-    else if (big_c) PV2_LAUNCH_WGRAD_LDS(1, 2, 2);
-    else PV2_LAUNCH_WGRAD_LDS(1, 1, 4);
-#undef PV2_LAUNCH_WGRAD_LDS
-    return pv2::check_launch("spconv_wgrad_lds");
-  }
-  PV2_REQUIRE(tile_pairs == PV2_WGRAD_TILE, "pv2_spconv_backward_weight: generic path needs 512");
-  const int n_nblk = (c_out + 31) / 32;
-  const int cblk = (c_in + 31) / 32;
-  const int cb = cblk >= 4 ? 4 : (cblk >= 2 ? 2 : 1);
-  const int n_cgrp = (cblk + cb - 1) / cb;
-  const int64_t n_items = n_tiles * n_nblk * n_cgrp;
-  const int64_t blocks = (n_items + 3) / 4;
-  if (blocks > 0x7fffffffLL) {
-    pv2::set_error("pv2_spconv_backward_weight: grid too large");
-    return PV2_E_BADARG;
-  }
-#define PV2_LAUNCH_WGRAD(CB)                                                                     \
-  hipLaunchKernelGGL((spconv_wgrad_kernel<CB>), dim3((unsigned)blocks), dim3(256), 0, s, in_feat, \
-                     c_in, dout, c_out, K, pair_in, pair_out, kstart, tile_start, n_items,       \
-                     n_nblk, n_cgrp, dweight)
-  if (cb == 4) PV2_LAUNCH_WGRAD(4);
-  else if (cb == 2) PV2_LAUNCH_WGRAD(2);
-  else PV2_LAUNCH_WGRAD(1);
-#undef PV2_LAUNCH_WGRAD
-  return pv2::check_launch("spconv_wgrad");
+  return pv2::spconv_wgrad(in_feat, n_in, c_in, dout, n_out, c_out, K, pair_in, pair_out, kstart,
+                           tile_start, tile_pairs, n_tiles, dweight, nullptr, (hipStream_t)stream);
+}
+
+int64_t pv2_spconv_wgrad_partial_floats(int c_in, int c_out, int64_t n_tiles) {
+  return n_tiles * wgrad_split_k(c_in, c_out) * (int64_t)c_out * c_in;
+}
+
+int pv2_spconv_backward_weight_det(const float* in_feat, int64_t n_in, int c_in, const float* dout,
+                                   int64_t n_out, int c_out, int K, const int32_t* pair_in,
+                                   const int32_t* pair_out, const int32_t* kstart,
+                                   const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
+                                   float* partial, float* dweight, pv2_stream_t stream) {
+  PV2_REQUIRE(partial != nullptr, "pv2_spconv_backward_weight_det: needs the partial-sum buffer");
+  return pv2::spconv_wgrad(in_feat, n_in, c_in, dout, n_out, c_out, K, pair_in, pair_out, kstart,
+                           tile_start, tile_pairs, n_tiles, dweight, partial, (hipStream_t)stream);
 }
 
 int pv2_gemm_nt(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
@@ -1264,7 +1093,7 @@ int pv2_gemm_tn(const float* a, const float* b, int64_t m, int k1, int k2, float
 #define PV2_LAUNCH_TN(WN, WC, WK)                                                                \
   hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, true>), dim3((unsigned)blocks),         \
                      dim3(256), 0, s, b, k2, a, k1, (int)m, nullptr, nullptr, nullptr, nullptr,  \
-                     tile_pairs, n_ntile, n_ctile, c)
+                     tile_pairs, n_ntile, n_ctile, c, nullptr)
   if (big_n && big_c) PV2_LAUNCH_TN(2, 2, 1);
   else if (big_n) PV2_LAUNCH_TN(2, 1, 2);
   else if (big_c) PV2_LAUNCH_TN(1, 2, 2);

@@ -1,0 +1,371 @@
+// Product-row sparse convolution on gfx950: the atomic-free, bitwise reproducible fp32 path.
+//
+// Stands in for spconv 2.x's indice_conv / indice_conv_backward behind SubMConv3d / SparseConv3d /
+// SparseInverseConv3d (ponder/models/sparse_unet/spconv_unet_v1m1_base.py:41,47,58,112,135,171) and,
+// as `pv2_convbn_*`, for the conv -> BatchNorm1d -> (+shortcut) -> ReLU units those layers form
+// (:70-83 BasicBlock.forward, :108,120-121 the SparseSequential stages).
+//
+// Why two stages.  The pair-major scatter-add kernel (sparse_conv.hip) keeps the matrix core fed -
+// pairs of one offset are compacted, one LDS weight slab serves 128 of them - but its epilogue adds
+// every product row into the output with device-scope fp32 atomics, which MI355X executes at the
+// memory side at ~0.9 TB/s of payload: on the ScanNet-shaped bench geometry every C >= 64 layer's
+// time was its atomic bytes (P * c_out * 4) / 0.9 TB/s, the MFMA work hidden underneath
+// (profiles/r02_spconv_kernel_table_v10.txt).  An output-stationary kernel needs no atomics but
+// wastes the fp32 matrix core on absent neighbours (3-5 of 27 offsets are present per voxel here)
+// and re-streams the weights per 32-row tile.  So:
+//
+//   stage 1  spconv_fwd_lds_kernel<store = 2>: prod[p, :] = W[k(p)] . in[pair_in[p], :] - the same
+//            compacted pair-major GEMM, one PRODUCT ROW per pair written with plain coalesced
+//            stores (the buffer lives in the 256 MiB Infinity Cache between the stages);
+//   stage 2  row_reduce_kernel: out[o, :] = sum over the offsets k present at o, in ascending k, of
+//            prod[pos[k][o], :] - a gather-sum that streams, with the BatchNorm statistics
+//            (per-block partial column sums, rownorm.hip's format) accumulated in its epilogue.
+//
+// `pos` is the position table of the rulebook: pos[k * stride + o] = index p of the pair of offset k
+// whose output row is o, or -1 (one more [K, N] int32 table next to the neighbour table, built by
+// pair_positions_kernel).  Every output element is written exactly once in a fixed summation
+// order: no zero-fill, no atomics, identical bits on every run - in the forward pass, the
+// grad-input pass (same two stages over the transposed pair roles, weights read in place) and the
+// weight gradient (partial slabs + ordered reduction, sparse_conv.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int kRows = 64;       // output rows a workgroup stages per pass
+constexpr int kMaxK = 32;       // offsets per rulebook on this path (27 submanifold, 8 strided)
+constexpr int kListLd = kMaxK + 1;
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// pos_a[k * stride_a + pair_a[p]] = p (and the same for b) for every pair p < kstart[K]; a / b may
+// be null.  The tables were filled with -1.  Every (k, row) occurs at most once in a conv rulebook.
+__global__ void pair_positions_kernel(const int32_t* __restrict__ pair_a,
+                                      const int32_t* __restrict__ pair_b,
+                                      const int32_t* __restrict__ kstart, int K, int64_t stride_a,
+                                      int64_t stride_b, int32_t* __restrict__ pos_a,
+                                      int32_t* __restrict__ pos_b) {
+  const int64_t P = kstart[K];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+    int lo = 0, hi = K;  // invariant: kstart[lo] <= p < kstart[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (kstart[mid] <= p) lo = mid; else hi = mid;
+    }
+    if (pos_a) pos_a[(int64_t)lo * stride_a + pair_a[p]] = (int32_t)p;
+    if (pos_b) pos_b[(int64_t)lo * stride_b + pair_b[p]] = (int32_t)p;
+  }
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4& b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+
+// acc = (init_row + bias) + prod[list[0]] + prod[list[1]] + ...   (this order, always)
+// Lane l of a TS-lane team owns the 16-byte columns l, l + TS, ... (NJ of them) of the row.
+template <int TS, int NJ>
+__device__ __forceinline__ void sum_row(const float4* __restrict__ T4, int c4n,
+                                        const int* __restrict__ list, int cnt,
+                                        const float4* __restrict__ init_row,
+                                        const float4* __restrict__ bias4, int l,
+                                        float4 (&acc)[NJ]) {
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = l + j * TS;
+    float4 a = zero;
+    if (col < c4n) {
+      if (init_row) a = init_row[col];
+      if (bias4) add4(a, bias4[col]);
+    }
+    acc[j] = a;
+  }
+  int q = 0;
+  for (; q + 4 <= cnt; q += 4) {  // four product rows in flight, added in list order
+    const int64_t p0 = list[q], p1 = list[q + 1], p2 = list[q + 2], p3 = list[q + 3];
+    float4 v0[NJ], v1[NJ], v2[NJ], v3[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      const bool ok = col < c4n;
+      v0[j] = ok ? T4[p0 * c4n + col] : zero;
+      v1[j] = ok ? T4[p1 * c4n + col] : zero;
+      v2[j] = ok ? T4[p2 * c4n + col] : zero;
+      v3[j] = ok ? T4[p3 * c4n + col] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      add4(acc[j], v0[j]);
+      add4(acc[j], v1[j]);
+      add4(acc[j], v2[j]);
+      add4(acc[j], v3[j]);
+    }
+  }
+  for (; q < cnt; ++q) {
+    const int64_t p = list[q];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      if (col < c4n) add4(acc[j], T4[p * c4n + col]);
+    }
+  }
+}
+
+// Stage two.  A workgroup owns `rows_per_block` consecutive output rows; per pass of <= 64 rows
+// their position-table columns are read coalesced into LDS and compacted (per row, ascending k) by
+// one thread per row; then a team of TS lanes sums one row at a time.
+//
+// STATS: the BatchNorm forward statistics of the result in the same pass - per-block partial column
+// sums of (y - s) and (y - s)^2 with the shift s = y[0, :] (every workgroup recomputes row 0 with
+// the same instruction sequence, hence the same bits), written as partial[block][0..2c) exactly as
+// col_partials_kernel<0> (rownorm.hip) does, for col_combine_kernel<0> to finish.
+template <int TS, int NJ, bool STATS>
+__global__ __launch_bounds__(256) void row_reduce_kernel(
+    const float* __restrict__ T, const int32_t* __restrict__ pos, int64_t pos_stride, int K, int c,
+    int64_t n_rows, int64_t rows_per_block, const float* __restrict__ bias,
+    const float* __restrict__ addend, float* __restrict__ Y, float* __restrict__ partial) {
+  constexpr int NT = 256 / TS;
+  __shared__ int s_raw[kMaxK * kRows];
+  __shared__ int s_list[kRows * kListLd];
+  __shared__ int s_cnt[kRows];
+  __shared__ int s_list0[kMaxK];
+  __shared__ int s_cnt0;
+  __shared__ float s_red[STATS ? 2048 * NJ : 1];
+  const int tid = threadIdx.x, team = tid / TS, l = tid % TS;
+  const int c4n = c >> 2;
+  const float4* T4 = reinterpret_cast<const float4*>(T);
+  const float4* bias4 = reinterpret_cast<const float4*>(bias);
+  const float4* add4p = reinterpret_cast<const float4*>(addend);
+  float4* Y4 = reinterpret_cast<float4*>(Y);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = min(n_rows, r_begin + rows_per_block);
+
+  float4 sh[NJ], a0[NJ], a1[NJ];
+  if (STATS) {
+    if (tid < K) s_raw[tid] = pos[(int64_t)tid * pos_stride];  // row 0: the shift
+    __syncthreads();
+    if (tid == 0) {
+      int cnt = 0;
+      for (int k = 0; k < K; ++k) {
+        const int p = s_raw[k];
+        if (p >= 0) s_list0[cnt++] = p;
+      }
+      s_cnt0 = cnt;
+    }
+    __syncthreads();
+    sum_row<TS, NJ>(T4, c4n, s_list0, s_cnt0, add4p, bias4, l, sh);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a0[j] = a1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();  // s_raw is reused below
+  }
+
+  for (int64_t base = r_begin; base < r_end; base += kRows) {
+    const int rows = (int)min((int64_t)kRows, r_end - base);
+    for (int e = tid; e < K * rows; e += 256) {
+      const int k = e / rows, rr = e - k * rows;
+      s_raw[k * kRows + rr] = pos[(int64_t)k * pos_stride + base + rr];
+    }
+    __syncthreads();
+    for (int rr = tid; rr < rows; rr += 256) {
+      int cnt = 0;
+      for (int k = 0; k < K; ++k) {
+        const int p = s_raw[k * kRows + rr];
+        if (p >= 0) s_list[rr * kListLd + cnt++] = p;
+      }
+      s_cnt[rr] = cnt;
+    }
+    __syncthreads();
+    for (int rr = team; rr < rows; rr += NT) {
+      const int64_t row = base + rr;
+      float4 acc[NJ];
+      sum_row<TS, NJ>(T4, c4n, &s_list[rr * kListLd], s_cnt[rr],
+                      add4p ? add4p + row * c4n : nullptr, bias4, l, acc);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = l + j * TS;
+        if (col < c4n) {
+          Y4[row * c4n + col] = acc[j];
+          if (STATS) {
+            const float4 d = make_float4(acc[j].x - sh[j].x, acc[j].y - sh[j].y,
+                                         acc[j].z - sh[j].z, acc[j].w - sh[j].w);
+            add4(a0[j], d);
+            add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
+          }
+        }
+      }
+    }
+    __syncthreads();  // the staging arrays are rewritten by the next pass
+  }
+
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      if (col < c4n) {
+        float* r0 = &s_red[team * 2 * c + 4 * col];
+        r0[0] = a0[j].x; r0[1] = a0[j].y; r0[2] = a0[j].z; r0[3] = a0[j].w;
+        float* r1 = r0 + c;
+        r1[0] = a1[j].x; r1[1] = a1[j].y; r1[2] = a1[j].z; r1[3] = a1[j].w;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * c; t += 256) {
+      float s = 0.f;
+      for (int q = 0; q < NT; ++q) s += s_red[q * 2 * c + t];  // teams in a fixed order
+      partial[(int64_t)blockIdx.x * 2 * c + t] = s;
+    }
+  }
+}
+
+template <bool STATS>
+void launch_reduce(const float* T, const int32_t* pos, int64_t pos_stride, int K, int c,
+                   int64_t n_rows, int blocks, int64_t rpb, const float* bias, const float* addend,
+                   float* Y, float* partial, hipStream_t s) {
+  const int c4n = c / 4;
+#define PV2_RED(TS, NJ)                                                                          \
+  hipLaunchKernelGGL((row_reduce_kernel<TS, NJ, STATS>), dim3(blocks), dim3(256), 0, s, T, pos,  \
+                     pos_stride, K, c, n_rows, rpb, bias, addend, Y, partial)
+  if (c4n <= 8) PV2_RED(8, 1);
+  else if (c4n <= 16) PV2_RED(16, 1);
+  else if (c4n <= 32) PV2_RED(32, 1);
+  else if (c4n <= 64) PV2_RED(64, 1);
+  else PV2_RED(64, 2);
+#undef PV2_RED
+}
+
+int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
+                int64_t n_rows, const float* bias, const float* addend, float* out,
+                float* bn_partial, int* bn_blocks, hipStream_t s) {
+  PV2_REQUIRE(K >= 1 && K <= kMaxK, "pv2_spconv_reduce_rows: 1 <= K <= 32");
+  PV2_REQUIRE(c >= 4 && (c % 4) == 0 && c <= 512,
+              "pv2_spconv_reduce_rows: channel count must be a multiple of 4, at most 512");
+  PV2_REQUIRE(n_rows >= 0 && pos_stride >= n_rows, "pv2_spconv_reduce_rows: bad row count");
+  if (bn_blocks) *bn_blocks = 0;
+  if (n_rows == 0) return PV2_OK;
+  int blocks;
+  int64_t rpb;
+  pv2::bn_partial_geometry(n_rows, c, &blocks, &rpb);
+  if (bn_partial) {
+    launch_reduce<true>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,
+                        bn_partial, s);
+    if (bn_blocks) *bn_blocks = blocks;
+  } else {
+    launch_reduce<false>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,
+                         nullptr, s);
+  }
+  return pv2::check_launch("spconv_reduce_rows");
+}
+
+// Events that order the side stream of pv2_convbn_backward behind the caller's stream.  A wait
+// binds to the record that precedes it, so a small ring of reusable events is enough.
+hipEvent_t fork_event() {
+  constexpr int kRing = 64;
+  static hipEvent_t ring[kRing];
+  static int next = -1;
+  if (next < 0) {
+    for (int i = 0; i < kRing; ++i) (void)hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+    next = 0;
+  }
+  hipEvent_t e = ring[next];
+  next = (next + 1) % kRing;
+  return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_pair_positions(const int32_t* pair_out, const int32_t* pair_in, const int32_t* kstart, int K,
+                       int64_t n_pairs_bound, int64_t out_stride, int64_t in_stride,
+                       int32_t* pos_out, int32_t* pos_in, pv2_stream_t stream) {
+  PV2_REQUIRE(K >= 1 && n_pairs_bound >= 0 && out_stride >= 0 && in_stride >= 0,
+              "pv2_pair_positions: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (pos_out && out_stride > 0)
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(pv2::grid_for(K * out_stride, 256)), dim3(256), 0, s,
+                       pos_out, (int64_t)K * out_stride, -1);
+  if (pos_in && in_stride > 0)
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(pv2::grid_for(K * in_stride, 256)), dim3(256), 0, s,
+                       pos_in, (int64_t)K * in_stride, -1);
+  if (n_pairs_bound > 0 && (pos_out || pos_in))
+    hipLaunchKernelGGL(pair_positions_kernel, dim3(pv2::grid_for(n_pairs_bound, 256)), dim3(256), 0,
+                       s, pair_out, pair_in, kstart, K, out_stride, in_stride, pos_out, pos_in);
+  return pv2::check_launch("pair_positions");
+}
+
+int pv2_spconv_products(const float* in_feat, int c_in, const float* weight, int K, int c_out,
+                        int weight_reduction_major, const int32_t* pair_in, const int32_t* kstart,
+                        const int32_t* tile_start, int64_t n_tiles, float* prod,
+                        pv2_stream_t stream) {
+  return pv2::spconv_products(weight_reduction_major != 0, in_feat, c_in, weight, K, c_out, pair_in,
+                              kstart, tile_start, n_tiles, prod, (hipStream_t)stream);
+}
+
+int pv2_spconv_reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
+                           int64_t n_rows, const float* bias, const float* addend, float* out,
+                           float* bn_partial, int* bn_blocks, pv2_stream_t stream) {
+  return reduce_rows(prod, pos, pos_stride, K, c, n_rows, bias, addend, out, bn_partial, bn_blocks,
+                     (hipStream_t)stream);
+}
+
+int pv2_convbn_forward(const pv2_conv_geom* g, const float* x, int c_in, const float* weight,
+                       int c_out, const float* bn_weight, const float* bn_bias,
+                       const float* residual, int relu, float eps, float momentum,
+                       float* running_mean, float* running_var, float* prod_ws, float* stats_ws,
+                       float* y_conv, float* mean_invstd, float* out, pv2_stream_t stream) {
+  PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_forward: needs at least two output rows");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = pv2::spconv_products(false, x, c_in, weight, g->K, c_out, g->pair_in, g->kstart,
+                                   g->tile_start, g->n_tiles, prod_ws, s))
+    return e;
+  int blocks = 0;
+  if (int e = reduce_rows(prod_ws, g->pos_out, g->pos_out_stride, g->K, c_out, g->n_out, nullptr,
+                          nullptr, y_conv, stats_ws, &blocks, s))
+    return e;
+  return pv2::bn_forward_from_partials(y_conv, g->n_out, c_out, stats_ws, blocks, bn_weight, bn_bias,
+                                       residual, relu, eps, momentum, running_mean, running_var,
+                                       mean_invstd, out, s);
+}
+
+int pv2_convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
+                        const float* weight, int c_out, const float* y_conv,
+                        const float* out_or_null, const float* mean_invstd, const float* bn_weight,
+                        float* prod_ws, float* stats_ws, float* gsum, float* dy,
+                        float* dres_or_null, float* dx_or_null, float* dweight_or_null,
+                        float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream) {
+  PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_backward: needs at least two output rows");
+  hipStream_t s = (hipStream_t)stream;
+  hipStream_t side = side_stream ? (hipStream_t)side_stream : s;
+  if (int e = pv2_bn_backward(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, g->n_out, c_out,
+                              stats_ws, gsum, dy, dres_or_null, stream))
+    return e;
+  if (dweight_or_null) {
+    if (side != s) {  // the weight gradient feeds nothing until the optimizer: off the critical chain
+      hipEvent_t ev = fork_event();
+      if (int e = pv2::hip_status(hipEventRecord(ev, s))) return e;
+      if (int e = pv2::hip_status(hipStreamWaitEvent(side, ev, 0))) return e;
+    }
+    if (int e = pv2::spconv_wgrad(x, g->n_in, c_in, dy, g->n_out, c_out, g->K, g->pair_in,
+                                  g->pair_out, g->kstart, g->tile_start_w, g->tile_pairs_w,
+                                  g->n_tiles_w, dweight_or_null, part_ws, side))
+      return e;
+  }
+  if (dx_or_null) {
+    // grad-input: the same two stages with the pair roles swapped, forward weight read in place
+    if (int e = pv2::spconv_products(true, dy, c_out, weight, g->K, c_in, g->pair_out, g->kstart,
+                                     g->tile_start, g->n_tiles, prod_ws, s))
+      return e;
+    if (int e = reduce_rows(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
+                            nullptr, dx_or_null, nullptr, nullptr, s))
+      return e;
+  }
+  return PV2_OK;
+}
+
+}  // extern "C"

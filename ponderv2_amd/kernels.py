@@ -16,30 +16,41 @@ import os
 
 FWD_LDS_TILE = 128  # tile of the LDS-staged forward kernel (pv2_spconv_forward_tile)
 FWD_LDS_TILE_K = 32  # ... which needs the reduction width to be a multiple of this
-# Which forward / grad-input kernel a conv with a gather table on its rulebook runs on:
-#   "auto" (default)  the output-stationary kernel (no atomics, no zero-fill, bitwise reproducible)
-#                     where it is the faster one on MI355X - strided and inverse convs, 1.0-1.7x
-#                     (profiles/r02_spconv_os_ab.txt) - and the pair-major scatter-add kernel for
-#                     the 27-offset submanifold convs, whose weight slabs it shares between 128 pairs;
-#   True  / PV2_SPCONV_OS=1   output-stationary everywhere: the DETERMINISTIC mode (bitwise
-#                     identical forward passes; used by the parity tests that bound gradients);
+# Which forward / grad-input kernels an fp32 conv runs on.
+#
+# PRODUCT-ROW path (USE_PR, csrc/sparse_conv_pr.hip; the default): stage 1 is the pair-major MFMA
+# kernel writing one product row per PAIR with plain stores, stage 2 sums the rows of every output
+# voxel in ascending offset order.  No atomics, no zero-fill, bitwise reproducible; needs
+# c_in % 32 == 0 and c_out % 4 == 0 and a rulebook of at most 32 offsets.
+#   PV2_CONV_PR = "all" (default)  every eligible conv, strided / inverse convs included;
+#                 "subm"           the 27-offset submanifold convs only;
+#                 "0"              off: the kernels below.
+# Without it (or where it does not apply: the 6-channel stem, odd channel counts) USE_OS decides:
+#   "auto" (default)  the output-stationary kernel (no atomics, bitwise reproducible) for strided and
+#                     inverse convs, the pair-major scatter-add kernel (device-scope fp32 atomics on a
+#                     zero-filled output) for submanifold convs;
+#   True  / PV2_SPCONV_OS=1   output-stationary everywhere;
 #   False / PV2_SPCONV_OS=0   scatter-add everywhere.
 _OS_ENV = os.environ.get("PV2_SPCONV_OS", "auto")
 USE_OS = True if _OS_ENV == "1" else False if _OS_ENV == "0" else "auto"
+_PR_ENV = os.environ.get("PV2_CONV_PR", "all")
+USE_PR = False if _PR_ENV in ("0", "off", "") else ("subm" if _PR_ENV == "subm" else "all")
+# Weight gradient in the deterministic two-stage form (partial slabs + ordered reduction) instead of
+# fp32 atomics on a zero-filled dW.  PV2_WGRAD_DET=0 restores the atomics.
+USE_WGRAD_DET = os.environ.get("PV2_WGRAD_DET", "1") != "0"
+# conv -> BatchNorm -> (+shortcut) -> ReLU as one C call per direction (pv2_convbn_*; needs USE_PR).
+USE_CONVBN = os.environ.get("PV2_CONVBN", "1") != "0"
+PR_MAX_K = 32
 
 
-# The LDS-tile output-stationary kernel (pv2_spconv_osl_forward) for submanifold convs is
-# EXPERIMENTAL and off: no atomics (compacted 16-row pair chunks at full MFMA row efficiency, a
-# three-stage software pipeline, one store per element), bitwise reproducible, but with one fat
-# workgroup per ~128 output rows the machine holds too few waves to hide the gather latency and it
-# measures 2.6-4x SLOWER than the scatter-add kernel, whose 1500 small workgroups oversubscribe the
-# CUs (profiles/r02_spconv_os_ab_v3.txt).  PV2_SPCONV_OSL=1 switches it on for A/B runs.
-USE_OSL = os.environ.get("PV2_SPCONV_OSL", "0") == "1"
-
-
-def _use_osl(rb, c_in, c_out) -> bool:
-    return (USE_OSL and USE_OS is not False and rb.osl is not None and c_in % 32 == 0
-            and c_out % 4 == 0)
+def _use_pr(rb, c_in, c_out) -> bool:
+    if USE_PR is False or rb.K > PR_MAX_K or c_in % FWD_LDS_TILE_K or c_out % 4 or rb.n_pairs <= 0:
+        return False
+    if rb.bounded:  # pair counts known on the device only: the product buffer would be worst-case
+        return False
+    if c_in < FWD_LDS_TILE_K or c_out > 512:
+        return False
+    return USE_PR == "all" or rb.center_k >= 0 and rb.K > 1
 
 
 def _use_os(rb) -> bool:
@@ -47,8 +58,8 @@ def _use_os(rb) -> bool:
         return False
     return True if USE_OS is True else rb.K <= 8
 # Run the centre offset of submanifold convs as a separate plain-store pass (no zero-fill, fewer
-# atomics).  Measured neutral on MI355X at the ScanNet batch (the second launch and its smaller
-# grids cost what the saved fill and atomics gain), so the single-launch path is the default.
+# atomics) on the scatter-add path.  Measured neutral on MI355X at the ScanNet batch (the second
+# launch and its smaller grids cost what the saved fill and atomics gain): off.
 USE_CENTER_STORE = False
 
 
@@ -91,6 +102,30 @@ def zeros_by_kernel(shape, dtype, device):
     return _zero_fill(torch.empty(shape, dtype=dtype, device=device))
 
 
+_WORKSPACES = {}
+
+
+def workspace(kind: str, device, floats: int, stream=None) -> torch.Tensor:
+    """A reusable fp32 scratch buffer per (kind, device, stream): launches on one stream are
+    ordered, so one buffer serves every layer.  ``stream``: a torch stream the buffer is used on
+    when that is not the current one (it is then allocated from that stream's pool).  Grown with
+    slack on demand."""
+    handle = (stream.cuda_stream if stream is not None
+              else _raw_stream(device.index) if _raw_stream is not None
+              else torch.cuda.current_stream(device).cuda_stream)
+    key = (kind, device.index, handle)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < floats:
+        n = max(int(floats * 1.25), 1 << 16)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                ws = torch.empty(n, dtype=torch.float32, device=device)
+        else:
+            ws = torch.empty(n, dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -124,9 +159,11 @@ class Rulebook:
     perm: Optional[torch.Tensor] = None
     kflip: int = 0
     _transposed_os: Optional[tuple] = None   # (nbr, stride, perm, kflip) of the transposed rulebook
-    # LDS-accumulator output-stationary view (submanifold convs): the canonical pair lists, the
-    # per-offset segment starts of every 64-row output block, and the weight-offset mirror flag
-    osl: Optional[tuple] = None              # (pair_in, pair_out, seg, kflip)
+    # position tables of the product-row path (pv2_pair_positions): pos_out[k, o] / pos_in[k, i] =
+    # index of the pair of offset k with output row o / input row i, or -1; (tensor, row stride)
+    _pos: Optional[tuple] = None             # (pos_out, out_stride, pos_in, in_stride)
+    bounded: bool = False                    # host-side pair counts are upper bounds (no read-back)
+    _geoms: dict = field(default_factory=dict)
 
     @property
     def n_pairs(self) -> int:
@@ -156,12 +193,52 @@ class Rulebook:
         rb = Rulebook(self.K, self.n_out, self.n_in, self.pair_out, self.pair_in, self.kstart,
                       self.kstart_host, self.center_k if self.n_in == self.n_out else -1)
         rb._tiles = self._tiles
+        rb.bounded = self.bounded
         if self._transposed_os is not None:
             rb.nbr, rb.nbr_stride, rb.perm, rb.kflip = self._transposed_os
             rb._transposed_os = (self.nbr, self.nbr_stride, self.perm, self.kflip)
-        if self.osl is not None:  # same canonical lists, weight offsets mirrored
-            rb.osl = self.osl[:3] + (1 - self.osl[3],)
+        if self._pos is not None:
+            po, so, pi, si = self._pos
+            rb._pos = (pi, si, po, so)
+        else:
+            rb._pos_source = self   # built on demand on the parent, then mirrored
         return rb
+
+    def positions(self):
+        """(pos_out, out_stride, pos_in, in_stride), built on first use (one fill + one scatter
+        launch per table; the U-Net's are built a batch ahead with the rulebooks)."""
+        if self._pos is None:
+            src = getattr(self, "_pos_source", None)
+            if src is not None:
+                po, so, pi, si = src.positions()
+                self._pos = (pi, si, po, so)
+            else:
+                dev = self.kstart.device
+                so, si = max(self.n_out, 1), max(self.n_in, 1)
+                pos_out = torch.empty(self.K * so, dtype=torch.int32, device=dev)
+                pos_in = torch.empty(self.K * si, dtype=torch.int32, device=dev)
+                _lib.check(_lib.lib().pv2_pair_positions(
+                    _ptr(self.pair_out), _ptr(self.pair_in), _ptr(self.kstart), self.K,
+                    self.n_pairs, so, si, _ptr(pos_out), _ptr(pos_in), _stream(self.kstart)),
+                    "pv2_pair_positions")
+                self._pos = (pos_out, so, pos_in, si)
+        return self._pos
+
+    def geom(self, c_in: int, c_out: int):
+        """The rulebook as the pv2_conv_geom struct of the fused conv + BatchNorm entry points
+        (cached per weight-gradient chunk size; holds raw pointers into this rulebook's tensors)."""
+        tile_w = int(_lib.lib().pv2_spconv_wgrad_tile(c_in, c_out, self.n_pairs, self.K))
+        g = self._geoms.get(tile_w)
+        if g is None:
+            pos_out, so, pos_in, si = self.positions()
+            ts, n_tiles, _ = self.tiles(FWD_LDS_TILE)
+            tsw, n_tiles_w, _ = self.tiles(tile_w)
+            g = _lib.ConvGeom(self.K, tile_w, self.n_in, self.n_out, n_tiles, n_tiles_w, so, si,
+                              self.pair_in.data_ptr(), self.pair_out.data_ptr(),
+                              self.kstart.data_ptr(), ts.data_ptr(), tsw.data_ptr(),
+                              pos_out.data_ptr(), pos_in.data_ptr())
+            self._geoms[tile_w] = g
+        return g
 
 
 def _compact(tbl: torch.Tensor, K: int, n: int, n_rows_dev: Optional[torch.Tensor]):
@@ -225,11 +302,6 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     if n > 0:
         # the neighbour table is its own transpose up to mirroring the offsets (coordinates are
         # unique): grad-input reads the same table with the weight offsets flipped
-        if USE_OSL and K <= 27:
-            seg = torch.empty(K * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
-            _lib.check(L.pv2_spconv_osl_segments(_ptr(pair_out), _ptr(kstart), K, n, _ptr(seg),
-                                                 _stream(coords)), "pv2_spconv_osl_segments")
-            rb.osl = (pair_in, pair_out, seg, 0)
         # (the mask sort is only worth its launches when the submanifold convs run output-stationary)
         rb.nbr, rb.nbr_stride = nbr, n
         rb.perm = _mask_order(nbr, K, n, n) if USE_OS is True else None
@@ -265,7 +337,9 @@ def rulebook_from_table(tbl: torch.Tensor, K: int, n_in: int, n_out: int,
     _lib.check(L.pv2_table_compact(_ptr(flat), K, n_in, _ptr(n_rows_dev), _ptr(block_sums),
                                    _ptr(pair_out), _ptr(pair_in), _stream(tbl)), "pv2_table_compact")
     bound = np.arange(K + 1, dtype=np.int64) * n_in
-    return Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, bound)
+    rb = Rulebook(K, n_in, n_out, pair_in, pair_out, kstart, bound)
+    rb.bounded = True
+    return rb
 
 
 def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List[int]):
@@ -435,6 +509,16 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
                    "pv2_table_masks")
         return torch.argsort(mask, stable=True).to(torch.int32)
 
+    def positions(pair_in, pair_out, kstart, K, bound):
+        """Position tables of the product-row conv path, capacity-sized (row stride ``cap``)."""
+        if USE_PR is False or K > PR_MAX_K:
+            return None
+        pos_out = torch.empty(K * cap, dtype=torch.int32, device=dev)
+        pos_in = torch.empty(K * cap, dtype=torch.int32, device=dev)
+        _lib.check(L.pv2_pair_positions(_ptr(pair_out), _ptr(pair_in), _ptr(kstart), K, bound, cap,
+                                        cap, _ptr(pos_out), _ptr(pos_in), st), "pv2_pair_positions")
+        return (pos_out, cap, pos_in, cap)
+
     ws_bytes = int(L.pv2_downsample_workspace_bytes(cap))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     for l in range(1, n_levels + 1):
@@ -456,7 +540,7 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
                    "pv2_table_invert")
         downs.append(dict(pair_in=pair_in, pair_out=pair_out, kstart=kstart, tbl=tbl, parent=parent,
                           perm=order(tbl, 8, n_out_dev), perm_t=order(parent, 8, n_dev[-1]),
-                          out_shape=out_shape))
+                          out_shape=out_shape, pos=positions(pair_in, pair_out, kstart, 8, cap)))
         coords.append(out_coords)
         n_dev.append(n_out_dev)
         shapes.append(out_shape)
@@ -478,6 +562,8 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
             pair_in, pair_out, kstart = compact(nbr, K, None, K * cap if level == 0 else 27 * cap)
             subms.append(dict(key=key, ksize=ksize, level=level, K=K, nbr=nbr, pair_in=pair_in,
                               pair_out=pair_out, kstart=kstart,
+                              pos=positions(pair_in, pair_out, kstart, K,
+                                            K * cap if level == 0 else 27 * cap),
                               perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None))
     state = dict(cap=cap, n_levels=n_levels, coords=coords, shapes=shapes, downs=downs, subms=subms,
                  readback=readback, dev=dev)
@@ -505,6 +591,8 @@ def _finish_unet_geometry(state, host) -> dict:
         if n_lvl[l] > 0:
             rb.nbr, rb.nbr_stride, rb.perm = d["tbl"], cap, d["perm"]
             rb._transposed_os = (d["parent"], cap, d["perm_t"], 0)
+            if d.get("pos") is not None:
+                rb._pos = d["pos"]
         out[f"spconv{l}"] = dict(kind="down", ksize=2, rulebook=rb, in_indices=coords[l - 1][:n_lvl[l - 1]],
                                  in_spatial_shape=shapes[l - 1], out_indices=coords[l][:n_lvl[l]],
                                  out_shape=d["out_shape"], prebuilt=True)
@@ -516,11 +604,8 @@ def _finish_unet_geometry(state, host) -> dict:
         if n > 0:
             rb.nbr, rb.nbr_stride, rb.perm = d["nbr"], cap, d["perm"]
             rb._transposed_os = (d["nbr"], cap, d["perm"], 1)
-            if USE_OSL and d["K"] <= 27:
-                seg = torch.empty(d["K"] * ((n + 63) // 64 + 1), dtype=torch.int32, device=dev)
-                _lib.check(L.pv2_spconv_osl_segments(_ptr(rb.pair_out), _ptr(rb.kstart), d["K"], n,
-                                                     _ptr(seg), st), "pv2_spconv_osl_segments")
-                rb.osl = (rb.pair_in, rb.pair_out, seg, 0)
+            if d.get("pos") is not None:
+                rb._pos = d["pos"]
         out[d["key"]] = dict(kind="subm", ksize=d["ksize"], n=n, rulebook=rb)
     return out
 
@@ -538,11 +623,32 @@ def _forward_tile(c_in: int, c_out: int) -> int:
     return t
 
 
+def _pr_conv(feats, weight, rb, c_in, c_out, reduction_major, pair_in, pos, pos_stride, n_rows,
+             bias=None, addend=None, bn_partial=None):
+    """The two stages of the product-row conv (csrc/sparse_conv_pr.hip): prod[p] = W[k(p)] .
+    feats[pair_in[p]], then out[o] = (addend[o] + bias) + sum_k prod[pos[k, o]] in ascending k."""
+    L = _lib.lib()
+    dev = feats.device
+    tile_start, n_tiles, _ = rb.tiles(FWD_LDS_TILE)
+    prod = workspace("prod", dev, rb.n_pairs * c_out)
+    st = _stream(feats)
+    _lib.check(L.pv2_spconv_products(_ptr(feats), c_in, _ptr(weight), rb.K, c_out,
+                                     int(reduction_major), _ptr(pair_in), _ptr(rb.kstart),
+                                     _ptr(tile_start), n_tiles, _ptr(prod), st), "pv2_spconv_products")
+    out = torch.empty((n_rows, c_out), dtype=torch.float32, device=dev)
+    blocks = ctypes.c_int(0)
+    _lib.check(L.pv2_spconv_reduce_rows(_ptr(prod), _ptr(pos), pos_stride, rb.K, c_out, n_rows,
+                                        _ptr(bias), _ptr(addend), _ptr(out), _ptr(bn_partial),
+                                        ctypes.byref(blocks), st), "pv2_spconv_reduce_rows")
+    return out, blocks.value
+
+
 def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
                    out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[pair_out] += W[k] . feats[pair_in].  weight_okc: fp32 [c_out, K, c_in] contiguous.
-    With a gather table on the rulebook (and no tensor to accumulate onto) the output-stationary
-    kernel computes ``bias + conv`` and writes every element once."""
+    Without a tensor to accumulate onto, the product-row path (default) or the output-stationary
+    kernel computes ``bias + conv`` and writes every element once; ``out`` given: it is added to
+    (product-row path: read as the addend, the result is a new tensor)."""
     _require_device(feats, weight_okc)
     assert feats.dtype == torch.float32 and weight_okc.dtype == torch.float32
     feats = feats.contiguous()
@@ -550,13 +656,11 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
     c_out, K, c_in = weight_okc.shape
     assert K == rb.K and feats.shape == (rb.n_in, c_in), (weight_okc.shape, feats.shape, rb.K, rb.n_in)
     L = _lib.lib()
-    if out is None and _use_osl(rb, c_in, c_out):
-        pin, pout, seg, kflip = rb.osl
-        out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
-        _lib.check(L.pv2_spconv_osl_forward(
-            _ptr(feats), rb.n_in, c_in, _ptr(weight_okc), K, c_out, _ptr(pin), _ptr(pout), _ptr(seg),
-            kflip, _ptr(bias), _ptr(out), rb.n_out, _stream(feats)), "pv2_spconv_osl_forward")
-        return out
+    if out is None and _use_pr(rb, c_in, c_out) and rb.n_out > 0:
+        pos_out, so, _, _ = rb.positions()
+        res, _ = _pr_conv(feats, weight_okc, rb, c_in, c_out, False, rb.pair_in, pos_out, so,
+                          rb.n_out, bias=bias)
+        return res
     if out is None and _use_os(rb):
         out = torch.empty((rb.n_out, c_out), dtype=torch.float32, device=feats.device)
         _lib.check(L.pv2_spconv_os_forward(
@@ -564,7 +668,7 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
             _ptr(rb.perm), rb.kflip, _ptr(bias), _ptr(out), rb.n_out, _stream(feats)),
             "pv2_spconv_os_forward")
         return out
-    assert bias is None or out is None, "bias is fused only by the output-stationary path"
+    assert bias is None or out is None, "bias is fused only by the atomic-free paths"
     tile = _forward_tile(c_in, c_out)
     tile_start, n_tiles, tile_host = rb.tiles(tile)
     c_lo = c_hi = 0
@@ -584,17 +688,28 @@ def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
 
 def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rulebook,
                            c_out: int, tile: Optional[int] = None) -> torch.Tensor:
-    """dW [c_out, K, c_in] for out = conv(feats, W)."""
+    """dW [c_out, K, c_in] for out = conv(feats, W): the deterministic two-stage form (partial slabs
+    + ordered reduction, no atomics, nothing to clear) where the channel counts allow, else fp32
+    atomics on a zero-filled dW."""
     _require_device(feats, grad_out)
     feats = feats.contiguous()
     grad_out = grad_out.contiguous()
     c_in = feats.shape[1]
     assert grad_out.shape == (rb.n_out, c_out) and feats.shape[0] == rb.n_in
-    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
     L = _lib.lib()
     if tile is None:
         tile = L.pv2_spconv_wgrad_tile(c_in, c_out, rb.n_pairs, rb.K)
     tile_start, n_tiles, _ = rb.tiles(tile)
+    if USE_WGRAD_DET and c_in % 4 == 0 and c_out % 4 == 0 and os.environ.get("PV2_SPCONV_GENERIC") != "1":
+        dw = torch.empty((c_out, rb.K, c_in), dtype=torch.float32, device=feats.device)
+        part = workspace("wgrad", feats.device,
+                         int(L.pv2_spconv_wgrad_partial_floats(c_in, c_out, n_tiles)))
+        _lib.check(L.pv2_spconv_backward_weight_det(
+            _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, rb.K, _ptr(rb.pair_in),
+            _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(part), _ptr(dw),
+            _stream(feats)), "pv2_spconv_backward_weight_det")
+        return dw
+    dw = zeros_by_kernel((c_out, rb.K, c_in), torch.float32, feats.device)
     _lib.check(L.pv2_spconv_backward_weight(
         _ptr(feats), rb.n_in, c_in, _ptr(grad_out), rb.n_out, c_out, rb.K, _ptr(rb.pair_in),
         _ptr(rb.pair_out), _ptr(rb.kstart), _ptr(tile_start), tile, n_tiles, _ptr(dw),
@@ -602,15 +717,22 @@ def spconv_backward_weight(feats: torch.Tensor, grad_out: torch.Tensor, rb: Rule
     return dw
 
 
-def spconv_grad_input(grad_out: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook) -> torch.Tensor:
-    """d loss / d feats of ``out = conv(feats, W)``: the conv of ``grad_out`` over the transposed
-    rulebook with W^T.  On the scatter-add path the forward weight [c_out, K, c_in] is read as it is
-    stored (reduction-major for this pass, pv2_spconv_forward_wt) - no transposed copy per layer per
-    step; the output-stationary kernels read 16-byte pieces along their reduction axis and take the
-    materialised transpose."""
+def spconv_grad_input(grad_out: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
+                      addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d loss / d feats of ``out = conv(feats, W)`` (+ ``addend``, product-row path only): the conv
+    of ``grad_out`` over the transposed rulebook with W^T.  The product-row and scatter-add paths
+    read the forward weight [c_out, K, c_in] as it is stored (reduction-major for this pass) - no
+    transposed copy per layer per step; the output-stationary kernels read 16-byte pieces along
+    their reduction axis and take the materialised transpose."""
     rbt = rb.transposed()
     c_out, K, c_in = weight_okc.shape
-    scatter = not (_use_osl(rbt, c_out, c_in) or _use_os(rbt))
+    if _use_pr(rbt, c_out, c_in) and rbt.n_out > 0:
+        _, _, pos_in, si = rb.positions()
+        res, _ = _pr_conv(grad_out.contiguous(), weight_okc.contiguous(), rb, c_out, c_in, True,
+                          rb.pair_out, pos_in, si, rb.n_in, addend=addend)
+        return res
+    assert addend is None
+    scatter = not _use_os(rbt)
     if scatter and c_out % FWD_LDS_TILE_K == 0 and c_in % 4 == 0 and rbt.n_pairs > 0:
         grad_out = grad_out.contiguous()
         weight_okc = weight_okc.contiguous()

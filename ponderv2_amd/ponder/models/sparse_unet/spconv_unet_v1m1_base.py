@@ -47,12 +47,11 @@ class BasicBlock(spconv.SparseModule):
         self.stride = stride
 
     def forward(self, x):
-        y = self.conv1(x)
-        y = y.replace_feature(fused_bn(self.bn1, y.features, relu=True))
-        y = self.conv2(y)
+        # conv -> bn -> relu and conv -> bn -> (+ shortcut) -> relu: one fused unit each
+        # (ponderv2_amd/convbn.py; the conv followed by fused_bn where the unit does not apply)
+        y = self.conv1.forward_bn(x, self.bn1, relu=True)
         shortcut = self.proj(x).features
-        # relu(bn2(conv2) + shortcut) in one pass over the feature matrix
-        return y.replace_feature(fused_bn(self.bn2, y.features, residual=shortcut, relu=True))
+        return self.conv2.forward_bn(y, self.bn2, residual=shortcut, relu=True)
 
 
 @MODELS.register_module("SpUNet-v1m1")

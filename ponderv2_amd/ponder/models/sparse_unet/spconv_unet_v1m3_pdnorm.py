@@ -82,6 +82,19 @@ class PDBatchNorm(nn.Module):
         return F.relu(y) if relu else y
 
 
+def _conv_norm(conv, norm, x, condition, context, residual=None, relu=False):
+    """``[relu](norm(conv(x)) [+ residual])`` for a sparse conv and a PDBatchNorm: the fused conv +
+    BatchNorm unit (ponderv2_amd/convbn.py, with the layer's effective affine pair) where it applies."""
+    bn = norm.bns[norm.conditions.index(condition)] if norm.decouple else norm.bn
+    if not norm.adaptive:
+        return conv.forward_bn(x, bn, residual=residual, relu=relu)
+    if isinstance(context, PreparedContext) and can_fuse(bn, x.features):
+        weight, bias = context.pairs[norm]
+        return conv.forward_bn(x, bn, residual=residual, relu=relu, weight=weight, bias=bias)
+    y = conv(x)
+    return y.replace_feature(norm(y.features, condition, context, residual=residual, relu=relu))
+
+
 class BasicBlock(spconv.SparseModule):
     expansion = 1
 
@@ -106,14 +119,12 @@ class BasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         x, condition, context = x
-        y = self.conv1(x)
-        y = y.replace_feature(self.bn1(y.features, condition, context, relu=True))
-        y = self.conv2(y)
+        y = _conv_norm(self.conv1, self.bn1, x, condition, context, relu=True)
         if self.in_channels == self.embed_channels:
             shortcut = self.proj(x).features
         else:
-            shortcut = self.proj_norm(self.proj_conv(x).features, condition, context)
-        y = y.replace_feature(self.bn2(y.features, condition, context, residual=shortcut, relu=True))
+            shortcut = _conv_norm(self.proj_conv, self.proj_norm, x, condition, context).features
+        y = _conv_norm(self.conv2, self.bn2, y, condition, context, residual=shortcut, relu=True)
         return y, condition, context
 
 
@@ -122,8 +133,7 @@ class _ConvNormReLU(nn.Module):
 
     def forward(self, x):
         x, condition, context = x
-        y = self.conv(x)
-        return y.replace_feature(self.bn(y.features, condition, context, relu=True))
+        return _conv_norm(self.conv, self.bn, x, condition, context, relu=True)
 
 
 class SPConvDown(_ConvNormReLU):

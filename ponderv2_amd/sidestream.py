@@ -28,8 +28,15 @@ import os
 
 import torch
 
-ENABLED = os.environ.get("PV2_WGRAD_STREAM", "1") != "0"
-_DISABLED_BECAUSE = None
+# The fork / join below lean on three private torch entry points (the current graph task id, the
+# raw stream switch, the engine's final-callback queue).  They exist in the torch 2.x line this
+# image ships (2.10); where any of them is missing the side stream switches itself off - weight
+# gradients then simply stay on the main stream - instead of failing in the middle of a backward.
+_PRIVATE_API_OK = (hasattr(torch._C, "_current_graph_task_id") and hasattr(torch._C, "_cuda_setStream")
+                   and hasattr(getattr(torch.autograd.Variable, "_execution_engine", None),
+                               "queue_callback"))
+ENABLED = os.environ.get("PV2_WGRAD_STREAM", "1") != "0" and _PRIVATE_API_OK
+_DISABLED_BECAUSE = None if _PRIVATE_API_OK else "this torch build lacks the private stream / graph-task hooks"
 _STREAMS = {}
 _JOIN_QUEUED = {}   # device index -> id of the graph task whose final callback joins the stream
 
@@ -42,7 +49,8 @@ def disable(reason="disabled by the caller"):
 
 def enable():
     global ENABLED, _DISABLED_BECAUSE
-    ENABLED, _DISABLED_BECAUSE = os.environ.get("PV2_WGRAD_STREAM", "1") != "0", None
+    ENABLED = os.environ.get("PV2_WGRAD_STREAM", "1") != "0" and _PRIVATE_API_OK
+    _DISABLED_BECAUSE = None if _PRIVATE_API_OK else "this torch build lacks the private stream / graph-task hooks"
 
 
 def status():
@@ -69,13 +77,47 @@ def active(t):
     return ENABLED and t.is_cuda and _graph_task_id() != -1
 
 
+_TASK_LEAVES = {}   # device index -> (graph task id, ids of the leaves already forked in it)
+
+
+def _drop_stale_state(device, task):
+    """A backward pass that raised never ran its final callback: its join is still pending and the
+    side stream's operands are still held.  Join now, then let go."""
+    queued = _JOIN_QUEUED.get(device.index)
+    if queued is not None and queued != task:
+        torch.cuda.current_stream(device).wait_stream(stream(device))
+        _JOIN_QUEUED.pop(device.index, None)
+        _KEEP.pop(device.index, None)
+
+
 def safe_leaf(param_view):
     """The gradient handed to autograd for this tensor will only be STORED as ``.grad`` of a leaf -
-    no kernel of the main stream touches it before the join: the tensor is a parameter or a plain
-    view of one (a copy, e.g. ``permute().contiguous()``, sends its gradient through further
-    autograd kernels), and that parameter has no ``.grad`` yet to be added to."""
+    no kernel of the main stream touches it before the join:
+      * the tensor is a parameter or a plain view of one (a copy, e.g. ``permute().contiguous()``,
+        sends its gradient through further autograd kernels);
+      * that parameter has no ``.grad`` yet to be added to, and no tensor hooks / post-accumulate
+        hooks that would read the gradient when it arrives;
+      * it is the FIRST gradient this backward pass produces for that leaf.  A parameter that feeds
+        two nodes (tied weights, a module called twice) gets its two gradients summed by the
+        engine on the main stream the moment the second one exists: the second one is computed on
+        the main stream, after the main stream has waited for the side stream's first."""
     base = param_view._base if param_view._base is not None else param_view
-    return base.is_leaf and base.grad is None
+    if not (base.is_leaf and base.grad is None):
+        return False
+    if getattr(base, "_backward_hooks", None) or getattr(base, "_post_accumulate_grad_hooks", None):
+        return False
+    if not base.is_cuda:
+        return True
+    device, task = base.device, _graph_task_id()
+    rec = _TASK_LEAVES.get(device.index)
+    if rec is None or rec[0] != task:
+        _drop_stale_state(device, task)
+        rec = _TASK_LEAVES[device.index] = (task, set())
+    if id(base) in rec[1]:
+        torch.cuda.current_stream(device).wait_stream(stream(device))
+        return False
+    rec[1].add(id(base))
+    return True
 
 
 _KEEP = {}          # device index -> tensors the side stream reads, held until the join
@@ -94,6 +136,16 @@ def _queue_join(device, side):
         _KEEP.pop(device.index, None)
 
     torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def native_fork(device, reads):
+    """For entry points that launch on the side stream THEMSELVES (pv2_convbn_backward records the
+    fork event and makes the side stream wait inside the C call): keep ``reads`` - everything the
+    side stream touches - alive until the join, queue the join, and return the side stream."""
+    side = stream(device)
+    _KEEP.setdefault(device.index, []).append(reads)
+    _queue_join(device, side)
+    return side
 
 
 _EVENTS = {}        # device index -> (ring of reusable events, next slot)

@@ -22,7 +22,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .. import kernels as K
+from .. import convbn, kernels as K
 from ..rownorm import fused_bn
 
 
@@ -108,13 +108,35 @@ class _SparseConvBase(SparseModule):
             out = out + self.bias
         return out
 
+    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+        rb, make = self._prepare(x)
+        return make(self._apply_conv(x.features, rb))
+
+    def forward_bn(self, x: SparseConvTensor, bn, residual=None, relu=False, weight=None,
+                   bias=None) -> SparseConvTensor:
+        """``[relu](bn(self(x)) [+ residual])``: one native call per direction where the fused unit
+        applies (ponderv2_amd/convbn.py), the conv followed by ``fused_bn`` otherwise.  ``weight`` /
+        ``bias``: affine overrides of the BatchNorm (see rownorm.fused_bn)."""
+        rb, make = self._prepare(x)
+        if x.indices.shape[0] == 0:
+            return make(self._apply_conv(x.features, rb))
+        feats = x.features
+        w = self.weight.reshape(self.out_channels, -1, self.in_channels)
+        if self.bias is None and convbn.supported(feats, w, rb, bn):
+            return make(convbn.conv_bn(self, bn, feats, rb, residual=residual, relu=relu,
+                                       weight=weight, bias=bias))
+        y = self._apply_conv(feats, rb)
+        if weight is not None or bias is not None:
+            return make(fused_bn(bn, y, residual=residual, relu=relu, weight=weight, bias=bias))
+        return make(fused_bn(bn, y, residual=residual, relu=relu))
+
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
                 f"stride={self.stride}, indice_key={self.indice_key}")
 
 
 class SubMConv3d(_SparseConvBase):
-    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+    def _prepare(self, x: SparseConvTensor):
         ks = self.kernel_size[0]
         key = self.indice_key
         entry = x.indice_dict.get(key) if key is not None else None
@@ -125,11 +147,11 @@ class SubMConv3d(_SparseConvBase):
             rb = K.build_subm_rulebook(x.indices, ks)
             if key is not None:
                 x.indice_dict[key] = dict(kind="subm", ksize=ks, n=x.indices.shape[0], rulebook=rb)
-        return x.replace_feature(self._apply_conv(x.features, rb))
+        return rb, x.replace_feature
 
 
 class SparseConv3d(_SparseConvBase):
-    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+    def _prepare(self, x: SparseConvTensor):
         ks, st = self.kernel_size[0], self.stride[0]
         if ks != st or self.padding != [0, 0, 0]:
             raise NotImplementedError(
@@ -148,22 +170,23 @@ class SparseConv3d(_SparseConvBase):
                 x.indice_dict[self.indice_key] = dict(
                     kind="down", ksize=ks, rulebook=rb, in_indices=x.indices,
                     in_spatial_shape=x.spatial_shape)
-        return SparseConvTensor(self._apply_conv(x.features, rb), out_indices, out_shape,
-                                x.batch_size, x.indice_dict)
+        return rb, lambda f: SparseConvTensor(f, out_indices, out_shape, x.batch_size, x.indice_dict)
 
 
 class SparseInverseConv3d(_SparseConvBase):
     def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True):
         super().__init__(in_channels, out_channels, kernel_size, bias=bias, indice_key=indice_key)
 
-    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+    def _prepare(self, x: SparseConvTensor):
         entry = x.indice_dict.get(self.indice_key)
         if entry is None or entry["kind"] != "down":
             raise RuntimeError(f"SparseInverseConv3d: no strided conv saved under "
                                f"indice_key={self.indice_key!r}")
-        rb = entry["rulebook"].transposed()
-        return SparseConvTensor(self._apply_conv(x.features, rb), entry["in_indices"],
-                                entry["in_spatial_shape"], x.batch_size, x.indice_dict)
+        rb = entry.get("rulebook_t")
+        if rb is None:   # one transposed view per strided conv (its position tables are cached on it)
+            rb = entry["rulebook_t"] = entry["rulebook"].transposed()
+        return rb, lambda f: SparseConvTensor(f, entry["in_indices"], entry["in_spatial_shape"],
+                                              x.batch_size, x.indice_dict)
 
 
 class SparseSequential(SparseModule):
@@ -191,7 +214,13 @@ class SparseSequential(SparseModule):
         i = 0
         while i < len(mods):
             module = mods[i]
-            if isinstance(module, SparseModule):
+            if (isinstance(module, _SparseConvBase) and i + 1 < len(mods)
+                    and type(mods[i + 1]) is nn.BatchNorm1d and isinstance(x, SparseConvTensor)):
+                # conv + BatchNorm1d (+ ReLU): one fused unit (convbn.py)
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = module.forward_bn(x, mods[i + 1], relu=relu)
+                i += 1 + int(relu)
+            elif isinstance(module, SparseModule):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.indices.shape[0] != 0:
