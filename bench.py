@@ -31,26 +31,45 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-PMC_FILE = "profiles/r02_pmc_fetch_write_per_kernel.json"
+PMC_FILE = "profiles/r03_pmc_fetch_write_per_kernel.json"
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel sources and the C ABI header: what a per-kernel PMC
+    measurement stays valid for.  tools/pmc_to_json.py stamps the same value into the PMC file."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "ponderv2_amd", "csrc")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "ponderv2_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_key):
     """(HBM-side bytes per launch, source) of a kernel from the rocprofv3 PMC passes committed with
     this round (tools/gpu_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench command;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streaming reads).
-    A STATIC read of that file - the counters cannot be collected inside a timed run - so the
-    commit it was measured at travels with it.  (None, reason) when absent."""
+    The counters cannot be collected inside a timed run, so this is a read of that file - accepted
+    only while the kernel sources are the ones it was measured on (``kernel_source_hash``): a file
+    measured on other sources is REFUSED (traffic null) rather than quoted.  (None, reason) when
+    absent or stale."""
     path = os.path.join(ROOT, PMC_FILE)
     try:
         with open(path) as f:
             doc = json.load(f)
+        if doc.get("kernel_source_hash") != kernel_source_hash():
+            return None, (f"{PMC_FILE} is stale: measured on kernel sources "
+                          f"{doc.get('kernel_source_hash', '?')} (commit {doc.get('commit', '?')}), "
+                          f"the sources here hash to {kernel_source_hash()}; re-run tools/gpu_pmc.sh")
         # every instantiation whose name starts with the key (e.g. "<4, false>" and "<4, true>":
         # forward and grad-input), weighted by launches
         recs = [r for k, r in doc["kernels"].items() if k.startswith(kernel_key)]
@@ -58,9 +77,49 @@ def pmc_traffic(kernel_key):
         kb = sum((2.0 * r["fetch_kb_per_launch"] + r["write_kb_per_launch"]) * r.get("launches", 1)
                  for r in recs) / n
         return (1024.0 * kb,
-                f"{PMC_FILE} (static; measured at commit {doc.get('commit', '?')}, {n} launches)")
+                f"{PMC_FILE} (same kernel sources {doc['kernel_source_hash']}; measured at commit "
+                f"{doc.get('commit', '?')}, {n} launches)")
     except Exception as e:  # noqa: BLE001
         return None, f"{PMC_FILE} unavailable ({type(e).__name__})"
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks of one
+    node under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), the way the
+    reference's launch() spawns its workers (ponder/engines/launch.py:38-100, tools/train.py:34).
+    Rank 0 of the children prints the JSON line; this process just forwards the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args):
+    """--launch-check: the multi-process plumbing of this script without the model - process group
+    (gloo when there is no GPU: this is what the CPU test runs), barrier, max-over-ranks reduction of
+    a per-rank timing, one JSON line from rank 0.  NOT a measurement (says so in the line)."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    gpu = torch.cuda.is_available()
+    if world > 1:
+        if gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if gpu else "gloo")
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda" if gpu else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_requested": args.gpus,
+                          "max_over_ranks": float(t), "backend": "nccl" if gpu else "gloo",
+                          "note": "plumbing check only: no model ran, not a measurement"}))
 
 
 def parse():
@@ -101,6 +160,9 @@ def parse():
                     help="config file to take the model / optimizer / scheduler sections from "
                          "(default: the repository's synthetic-data config of the workload; the "
                          "reference's own config file works unchanged)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only exercise the rank spawning / process group / rank-0 reporting path "
+                         "(no model, works without a GPU over gloo); prints a JSON line saying so")
     ap.add_argument("--print-losses", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-layer-shape kernel table here")
     args = ap.parse_args()
@@ -214,6 +276,8 @@ class KernelTimer:
                     timer._excl = None
                     timer._pending = None
                 e.record()
+                if pend.get("skip"):
+                    return out
                 if "events" in pend:   # the C-ABI launch itself was bracketed (launch hook below):
                     s, e = pend["events"]   # events right around the kernel launch, nothing else
                     excl = []
@@ -224,6 +288,27 @@ class KernelTimer:
                 return out
 
             setattr(K, name, fn)
+
+        # the product-row conv path (kernels._pr_conv): two C-ABI launches per conv, each bracketed
+        # by its own event pair.  The MFMA kernel (stage 1) carries the conv's flops and the
+        # conv's algorithmic bytes; the row reduce (stage 2) is a streaming kernel
+        # priced by the bytes IT has to move: the product rows in, the result rows out, the table.
+        orig_pr = K._pr_conv
+        self._orig["_pr_conv"] = orig_pr
+        self._pr_ctx = None
+
+        def timed_pr(feats, weight, rb, c_in, c_out, *a, **k):
+            if timer._pending is not None:
+                timer._pending["skip"] = True     # recorded here, not by the outer wrapper
+            n_rows = a[4] if len(a) > 4 else k["n_rows"]
+            timer._pr_ctx = dict(p=rb.n_pairs, c_in=c_in, c_out=c_out, K=rb.K,
+                                 n_src=feats.shape[0], n_rows=n_rows)
+            try:
+                return orig_pr(feats, weight, rb, c_in, c_out, *a, **k)
+            finally:
+                timer._pr_ctx = None
+
+        K._pr_conv = timed_pr
 
         orig_fill = K._zero_fill
         self._orig["_zero_fill"] = orig_fill
@@ -245,7 +330,7 @@ class KernelTimer:
         def conv_family(c_in, c_out, rb, out):
             """Which kernel kernels.spconv_forward runs this call on (same rules as over there)."""
             if out is None and K._use_os(rb):
-                return "spconv_os_kernel (fwd+dgrad: strided / inverse convs)"
+                return "spconv_os_kernel (fwd: the 125-offset stem, odd channel counts)"
             if c_in % 32 == 0:
                 nb = min(4, (c_out + 31) // 32)
                 return "spconv_fwd_lds_kernel<%d> (fwd+dgrad, %s output channels per workgroup)" % (
@@ -273,8 +358,9 @@ class KernelTimer:
             if c_in % 4 or c_out % 4:
                 return "spconv_wgrad_kernel (stem, any channel count)"
             big_n, big_c = c_out > 64, c_in > 64
-            return "spconv_wgrad_lds_kernel<%s>" % ("2, 2, 1" if big_n and big_c else "2, 1, 2" if big_n
-                                                    else "1, 2, 2" if big_c else "1, 1, 4")
+            return "spconv_wgrad_lds_kernel<%s>%s" % (
+                "2, 2, 1" if big_n and big_c else "2, 1, 2" if big_n else "1, 2, 2" if big_c else "1, 1, 4",
+                " + wgrad_reduce_kernel (two-stage, deterministic)" if K.USE_WGRAD_DET else "")
 
         # 16-bit kernels (csrc/sparse_conv16.hip): same algorithmic flops, 2-byte features and
         # weights, fp32 dW; the gather table instead of pair lists on the output-stationary pass
@@ -351,9 +437,46 @@ class KernelTimer:
             setattr(handle, cname, fnc)
 
         for cname in ("pv2_spconv_forward", "pv2_spconv_forward_wt", "pv2_spconv_os_forward",
-                      "pv2_spconv_osl_forward", "pv2_spconv_backward_weight",
+                      "pv2_spconv_backward_weight", "pv2_spconv_backward_weight_det",
                       "pv2_spconv16_os_forward", "pv2_spconv16_backward_weight"):
             hook_launch(cname)
+
+        def hook_pr(cname, cost):
+            orig_c = getattr(handle, cname)
+            self._orig_c[cname] = orig_c
+
+            def fnc(*a):
+                ctx = timer._pr_ctx
+                if ctx is None:
+                    return orig_c(*a)
+                s_ = torch.cuda.Event(enable_timing=True)
+                e_ = torch.cuda.Event(enable_timing=True)
+                s_.record()
+                rc = orig_c(*a)
+                e_.record()
+                flops, nbytes, shape, fam = cost(ctx)
+                timer.peaks.setdefault(fam, F32_MFMA_PEAK_TFLOPS)
+                timer._add(fam, s_, e_, flops, nbytes, shape)
+                return rc
+
+            setattr(handle, cname, fnc)
+
+        def products_cost(c):
+            nb = min(4, (c["c_out"] + 31) // 32)
+            fam = ("spconv_fwd_lds_kernel<%d> (product rows: fwd+dgrad, %s output channels per "
+                   "workgroup)" % (nb, {1: "32", 2: "64", 3: "96", 4: "128"}[nb]))
+            return (2.0 * c["p"] * c["c_in"] * c["c_out"],
+                    4.0 * (c["n_src"] * c["c_in"] + c["n_rows"] * c["c_out"]
+                           + c["K"] * c["c_in"] * c["c_out"]) + 8.0 * c["p"],
+                    (c["c_in"], c["c_out"], c["K"], c["p"]), fam)
+
+        def reduce_cost(c):
+            return (0.0, 4.0 * c["c_out"] * (c["p"] + c["n_rows"]) + 4.0 * c["K"] * c["n_rows"],
+                    (c["c_in"], c["c_out"], c["K"], c["p"]),
+                    "row_reduce_kernel (ordered sum of product rows: fwd+dgrad)")
+
+        hook_pr("pv2_spconv_products", products_cost)
+        hook_pr("pv2_spconv_reduce_rows", reduce_cost)
 
         def vol_bytes(a):
             return 4.0 * a[1] * a[2] * a[3] * a[4] * a[5]
@@ -463,7 +586,11 @@ class KernelTimer:
             if fam in self.l2_bytes:
                 out[-1]["l2_gather_gbs"] = self.l2_bytes[fam] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 out[-1]["frac_of_f32_mfma_peak"] = out[-1]["tflops"] / F32_MFMA_PEAK_TFLOPS
-                out[-1]["frac_of_hbm_peak"] = out[-1]["alg_gbs"] / HBM_PEAK_GBS
+                # these kernels gather from a volume that was just written and sits in the 256 MiB
+                # Infinity Cache / the L2s: bytes / time is a CACHE rate (it can exceed what HBM
+                # delivers), so no HBM roofline fraction is quoted for them
+                del out[-1]["frac_of_hbm_peak"]
+                out[-1]["cache_resident_gbs"] = out[-1].pop("alg_gbs")
         return sorted(out, key=lambda r: -r["total_ms"])
 
     def shape_table(self, steps):
@@ -561,7 +688,14 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)      # does not return
+    if args.launch_check:
+        return launch_check(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting "
+              f"n_gpus={world}", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -712,12 +846,16 @@ def main():
     if not args.no_kernel_timing:
         timer = KernelTimer()
         timer.install()
-        was_on = sidestream.ENABLED
-        sidestream.ENABLED = False
+        # (and conv + BatchNorm units taken apart: pv2_convbn_* launch several kernels per C call,
+        # which events recorded from Python cannot separate; the same kernels run either way - the
+        # row reduce without its statistics epilogue, the statistics as col_partials)
+        import ponderv2_amd.kernels as K_
+        was_on, was_fused = sidestream.ENABLED, K_.USE_CONVBN
+        sidestream.ENABLED, K_.USE_CONVBN = False, False
         try:
             elapsed_instr, _, _ = timed_pass(args.steps)
         finally:
-            sidestream.ENABLED = was_on
+            sidestream.ENABLED, K_.USE_CONVBN = was_on, was_fused
 
     kernels = timer.summary() if timer else []
     if timer:
@@ -779,7 +917,7 @@ def main():
                 result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma",
                                       "achieved": dom["tflops"], "peak": dom["mfma_peak_tflops"],
                                       "unit": "TFLOP/s", "frac": dom["tflops"] / dom["mfma_peak_tflops"],
-                                      "hbm_frac_of_alg_bytes": dom["frac_of_hbm_peak"],
+                                      "hbm_frac_of_alg_bytes": dom.get("frac_of_hbm_peak"),
                                       "traffic": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[0],
                                       "traffic_source": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[1],
                                       "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + "
@@ -790,9 +928,10 @@ def main():
                                       "alg_flops_per_launch": dom["alg_flops_per_launch"],
                                       "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
             else:
+                gbs = dom.get("alg_gbs", dom.get("cache_resident_gbs", 0.0))
                 result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm",
-                                      "achieved": dom["alg_gbs"], "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": dom["alg_gbs"] / HBM_PEAK_GBS,
+                                      "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": None, "avg_launch_us": dom["avg_us"],
                                       "launches": dom["launches"]}
             result["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v)

@@ -25,12 +25,15 @@ FWD_LDS_TILE_K = 32  # ... which needs the reduction width to be a multiple of t
 #   PV2_CONV_PR = "all" (default)  every eligible conv, strided / inverse convs included;
 #                 "subm"           the 27-offset submanifold convs only;
 #                 "0"              off: the kernels below.
-# Without it (or where it does not apply: the 6-channel stem, odd channel counts) USE_OS decides:
-#   "auto" (default)  the output-stationary kernel (no atomics, bitwise reproducible) for strided and
-#                     inverse convs, the pair-major scatter-add kernel (device-scope fp32 atomics on a
-#                     zero-filled output) for submanifold convs;
-#   True  / PV2_SPCONV_OS=1   output-stationary everywhere;
-#   False / PV2_SPCONV_OS=0   scatter-add everywhere.
+# Where it does not apply (channel counts that are no multiples of 32 / 4, the 125-offset stem) and
+# when it is off, USE_OS decides:
+#   "auto" (default) / True / PV2_SPCONV_OS=1   the output-stationary kernel over the rulebook's
+#                     gather table (no atomics, bitwise reproducible, any channel count);
+#   False / PV2_SPCONV_OS=0   the pair-major scatter-add kernels (device-scope fp32 atomics on a
+#                     zero-filled output) - the round-1/2 default for submanifold convs, kept as the
+#                     A/B baseline.  Rulebooks without a gather table (the dense grid's first layer,
+#                     models/ponder/sparse_input.py) always take them.
+# So the default selection contains no atomics anywhere in the sparse backbone.
 _OS_ENV = os.environ.get("PV2_SPCONV_OS", "auto")
 USE_OS = True if _OS_ENV == "1" else False if _OS_ENV == "0" else "auto"
 _PR_ENV = os.environ.get("PV2_CONV_PR", "all")
@@ -56,7 +59,7 @@ def _use_pr(rb, c_in, c_out) -> bool:
 def _use_os(rb) -> bool:
     if rb.nbr is None or USE_OS is False:
         return False
-    return True if USE_OS is True else rb.K <= 8
+    return True
 # Run the centre offset of submanifold convs as a separate plain-store pass (no zero-fill, fewer
 # atomics) on the scatter-add path.  Measured neutral on MI355X at the ScanNet batch (the second
 # launch and its smaller grids cost what the saved fill and atomics gain): off.

@@ -80,7 +80,20 @@ def _mix_offsets(batch, mix_prob):
 def _own_collate(samples, inner, mix_prob, max_point):
     if max_point > 0:
         samples = _within_budget(samples, max_point)
-    return _mix_offsets(inner(samples), mix_prob)
+    batch = inner(samples)
+    if mix_prob > 0:
+        # Mix3D halves ``offset``; batches that carry per-scene stacks next to the points (views,
+        # poses, ray offsets, conditions: every pre-training batch) would be left with B scenes of
+        # poses against B/2 scenes of points.  The reference only mixes plain point batches.
+        per_scene = [k for k in ("rgb", "depth", "extrinsic", "intrinsic", "ray_offset", "condition")
+                     if k in batch]
+        if per_scene:
+            raise ValueError(
+                f"mix_prob={mix_prob} > 0 cannot be applied to batches with per-scene entries "
+                f"{per_scene} (Mix3D merges neighbouring scenes' points only); set mix_prob=0 for "
+                "this dataset")
+        batch = _mix_offsets(batch, mix_prob)
+    return batch
 
 
 def loader_collate(dataset, mix_prob=0, max_point=-1):

@@ -198,8 +198,14 @@ def bn_conv_relu_on_cells(bn, conv, cells):
         var = ((x * x).sum(0) / n_tot - mean * mean).clamp_min(0.0)
         if bn.training and bn.track_running_stats:
             with torch.no_grad():
-                bn.num_batches_tracked.add_(1)
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                if bn.momentum is not None:   # counted on the host, as every fused BatchNorm
+                    from ponderv2_amd.rownorm import _bump_batches_tracked
+
+                    _bump_batches_tracked(bn)
+                    m = bn.momentum
+                else:
+                    bn.num_batches_tracked.add_(1)
+                    m = 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
                 bn.running_var.mul_(1 - m).add_(var * (n_tot / max(n_tot - 1.0, 1.0)), alpha=m)
     else:

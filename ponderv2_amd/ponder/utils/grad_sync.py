@@ -30,6 +30,8 @@ class FlatGradSync:
         self._views = None
         self._flag_key, self._flags = None, None
         self.uniform_usage = uniform_usage
+        # uniform usage is an ASSUMPTION about the model; it is checked, not trusted (see sync)
+        self._last_used, self._steps, self.check_every = None, 0, 64
 
     def _buffers(self):
         if self._flat is None:
@@ -53,7 +55,22 @@ class FlatGradSync:
         flat, views = self._buffers()
         used = [i for i, p in enumerate(self.params) if p.grad is not None]
         if not self.uniform_usage:
-            flat.zero_()  # (uniform usage: the same slices are overwritten every step, the rest stay 0)
+            flat.zero_()
+        else:
+            # the same slices are overwritten every step and the rest stay 0 - as long as the set of
+            # parameters with gradients does not change.  When it does change on this rank, the
+            # slices that fell out are cleared (a silent rank must contribute zeros, not last
+            # step's averages), and a checksum of the set rides along with the data: every
+            # ``check_every`` steps (and right after a local change) it is read back and compared -
+            # ranks that disagree about the set raise instead of silently diverging, which is what
+            # DistributedDataParallel(find_unused_parameters=False) does in this situation.
+            key = tuple(used)
+            if self._last_used is not None and key != self._last_used:
+                for i in set(self._last_used) - set(key):
+                    views[i].zero_()
+                self._steps = 0   # check at once
+            self._last_used = key
+            flat[self.numel] = float(sum(i + 1 for i in used))
         if used:
             torch._foreach_copy_([views[i] for i in used], [self.params[i].grad for i in used])
         if not self.uniform_usage:
@@ -66,11 +83,21 @@ class FlatGradSync:
         # RCCL averages in the reduction itself; other backends (gloo in the CPU tests) sum
         avg = dist.get_backend(self.group) == "nccl" and self.uniform_usage
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        end = self.numel if self.uniform_usage else flat.numel()
+        end = self.numel + 1 if self.uniform_usage else flat.numel()
         handles = [dist.all_reduce(flat[a:min(a + self.slice_elems, end)], op=op, group=self.group,
                                    async_op=True) for a in range(0, end, self.slice_elems)]
         for h in handles:
             h.wait()
+        if self.uniform_usage:
+            if self._steps % self.check_every == 0:
+                mine = float(sum(i + 1 for i in used))
+                total = float(flat[self.numel]) * (world if avg else 1.0)
+                if abs(total - mine * world) > 0.5:
+                    raise RuntimeError(
+                        "FlatGradSync(uniform_usage=True): the ranks disagree about which parameters "
+                        "received a gradient this step (a rank skipped a branch of the model); use "
+                        "uniform_usage=False for such models")
+            self._steps += 1
         if self.uniform_usage or len(used) == len(self.params):
             anywhere = [p.grad is not None for p in self.params]
         else:  # somebody else's parameters: one small read, only when this rank skipped some

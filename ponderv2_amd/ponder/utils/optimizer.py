@@ -50,7 +50,15 @@ def _ready_for_fused(optimizer):
             continue
         if group.get("momentum", 0) != 0:
             for p in group["params"]:
-                optimizer.state[p].setdefault("momentum_buffer", torch.zeros_like(p))
+                if optimizer.state[p].get("momentum_buffer") is None:
+                    optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p)
+    if not getattr(optimizer, "_pv2_reready_hook", False):
+        # load_state_dict REPLACES the state: a checkpoint written by the for-each step (or by the
+        # reference), or one in which some parameters were never stepped (the multi-dataset model's
+        # per-condition norms), brings back the mixed None / tensor buffer list the fused step
+        # fails on - so the buffers are completed again after every load
+        optimizer.register_load_state_dict_post_hook(lambda opt: _ready_for_fused(opt) and None)
+        optimizer._pv2_reready_hook = True
     return optimizer
 
 

@@ -51,8 +51,23 @@ def _bump_batches_tracked(bn):
                 module.num_batches_tracked.add_(module._pv2_pending_batches)
             module._pv2_pending_batches = 0
 
+        def forget(*args):   # the loaded buffer is the truth: steps counted before it are history
+            bn._pv2_pending_batches = 0
+
         bn.register_state_dict_pre_hook(flush)
+        bn._register_load_state_dict_pre_hook(forget)
     bn._pv2_pending_batches += 1
+
+
+def flush_bn_counters(model):
+    """Write every pending ``num_batches_tracked`` count to its buffer.  Call before anything reads
+    the buffers directly - ``model.buffers()`` broadcasts, ``copy.deepcopy`` for an EMA model;
+    ``state_dict()`` does it by itself."""
+    for m in model.modules():
+        pending = getattr(m, "_pv2_pending_batches", 0)
+        if pending and getattr(m, "num_batches_tracked", None) is not None:
+            m.num_batches_tracked.add_(pending)
+            m._pv2_pending_batches = 0
 
 
 class _FusedBNFunction(torch.autograd.Function):

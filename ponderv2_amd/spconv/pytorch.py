@@ -21,6 +21,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import convbn, kernels as K
 from ..rownorm import fused_bn
@@ -103,6 +104,12 @@ class _SparseConvBase(SparseModule):
         # fp32 kernels otherwise, also inside autocast regions (widen whatever the region produced)
         if features.dtype in (torch.bfloat16, torch.float16):
             features = features.float()
+        if self.in_channels % 4 and features.is_cuda:
+            # zero-pad the reduction axis to a multiple of 8 (the 6-channel stem): exact, and it puts
+            # the layer on the vector-load forward kernel and the deterministic weight gradient
+            pad = -self.in_channels % 8
+            features = F.pad(features, (0, pad))
+            w = F.pad(w, (0, pad))
         out = K.SparseConvFunction.apply(features, w, rb)
         if self.bias is not None:
             out = out + self.bias

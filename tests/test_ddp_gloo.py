@@ -187,3 +187,25 @@ def _run_and_resume(tmp_path, cfg):
     # same scheduler position as the uninterrupted run
     assert again["scheduler"]["last_epoch"] == last["scheduler"]["last_epoch"] == 2
     assert again["optimizer"]["state"][0]["step"] == last["optimizer"]["state"][0]["step"]
+
+
+def test_bench_spawns_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it re-runs itself as two ranks under
+    torch.distributed.run (as the reference's launch() spawns its workers, engines/launch.py:38-100)
+    and rank 0 alone reports ``n_gpus: 2``.  ``--launch-check`` exercises exactly that plumbing
+    (spawn, rendezvous on 127.0.0.1, barrier, max-over-ranks reduce, one JSON line) without the
+    model - over gloo here, where there is no GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout            # rank 0 only
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["gpus_requested"] == 2 and doc["launch_check"] is True
+    assert doc["max_over_ranks"] == 2.0            # the reduction saw both ranks

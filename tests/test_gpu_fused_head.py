@@ -184,7 +184,6 @@ def test_model_folds_the_final_convolution_by_default_and_unfolded_results_agree
     import golden_cases as gc
     from ponderv2_amd import fused_head as fhd, kernels as K
 
-    monkeypatch.setattr(K, "USE_OS", True)
     seen = []
     orig = fhd.field_render_folded
     monkeypatch.setattr(fhd, "field_render_folded", lambda *a: (seen.append(1), orig(*a))[1])

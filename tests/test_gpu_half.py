@@ -186,7 +186,6 @@ def test_spunet_16bit_mode_tracks_fp32(device, monkeypatch):
     from ponderv2_amd import precision
     from ponderv2_amd.ponder.models import build_model
 
-    monkeypatch.setattr(K, "USE_OS", True)  # the fp32 stem conv (6 input channels) without atomics
 
     torch.manual_seed(0)
     cfg = dict(FULL_BACKBONE)

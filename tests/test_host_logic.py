@@ -331,8 +331,18 @@ def test_loaders_apply_the_point_budget_of_the_config():
     samples = [ds[0], ds[1]]
     n0 = len(samples[0]["coord"])
     assert loader_collate(ds, max_point=n0 + 1)(samples)["offset"].tolist() == [n0]
-    mixed = loader_collate(ds, mix_prob=1.0)(samples)          # Mix3D: two scenes become one
-    assert mixed["offset"].tolist() == [n0 + len(samples[1]["coord"])] == mixed["offset_host"]
+    # Mix3D merges the points of neighbouring scenes only: a pre-training batch carries per-scene
+    # views / poses next to them, which would go out of step - refused with a clear message
+    with pytest.raises(ValueError, match="mix_prob"):
+        loader_collate(ds, mix_prob=1.0)(samples)
+
+    class OwnCollate(Scenes):   # own batch assembly, plain point batches: mixing applies
+        @staticmethod
+        def collate_fn(batch):
+            return point_collate_fn(batch)
+
+    mixed = loader_collate(OwnCollate(), mix_prob=1.0)([Scenes()[0], Scenes()[1]])
+    assert mixed["offset"].tolist() == [30]
     # the multi-dataset loader no longer refuses the reference's settings
     loader = MultiDatasetDataloader(ConcatDataset([Scenes(), Scenes()], loop=1), 2, 0, mix_prob=0,
                                     seed=3, max_point=2000000)
@@ -580,3 +590,45 @@ def test_channels_last_max_pool_equals_max_pool3d():
         (got * probe).sum().backward()
         (ref * probe).sum().backward()
         assert torch.equal(a.grad, b.grad)
+
+
+def test_fused_sgd_buffers_are_completed_again_after_a_partial_load():
+    """A checkpoint without momentum buffers for some parameters (written by the for-each step, by
+    the reference, or with per-condition norms that were never stepped) must not leave the fused
+    SGD step with a mixed None / tensor buffer list: build_optimizer re-completes them after
+    load_state_dict.  (Host tensors never get ``fused=True``; the hook is exercised directly.)"""
+    from ponderv2_amd.ponder.utils import optimizer as O
+
+    model = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.Linear(3, 2))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    opt.defaults["fused"] = True            # what _prefer_fused sets on a GPU model
+    for g in opt.param_groups:
+        g["fused"] = True
+    O._ready_for_fused(opt)
+    assert all("momentum_buffer" in opt.state[p] for p in model.parameters())
+    partial = opt.state_dict()
+    for idx in (2, 3):                      # the second layer was never stepped in that checkpoint
+        partial["state"].pop(idx)
+    opt.load_state_dict(partial)
+    bufs = [opt.state[p].get("momentum_buffer") for p in model.parameters()]
+    assert all(b is not None for b in bufs)
+
+
+def test_pending_batchnorm_counts_do_not_survive_a_checkpoint_load():
+    from ponderv2_amd import rownorm
+
+    bn = torch.nn.BatchNorm1d(4)
+    for _ in range(3):
+        rownorm._bump_batches_tracked(bn)
+    assert int(bn.num_batches_tracked) == 0 and bn._pv2_pending_batches == 3
+    saved = bn.state_dict()                 # flushes: the checkpoint says 3
+    assert int(saved["num_batches_tracked"]) == 3
+    rownorm._bump_batches_tracked(bn)       # a warm-up step before the resume
+    other = torch.nn.BatchNorm1d(4)
+    other.num_batches_tracked.fill_(10)
+    bn.load_state_dict(other.state_dict())
+    assert bn._pv2_pending_batches == 0 and int(bn.state_dict()["num_batches_tracked"]) == 10
+    rownorm._bump_batches_tracked(bn)
+    model = torch.nn.Sequential(bn)
+    rownorm.flush_bn_counters(model)        # for direct readers of the buffers (EMA copy, broadcast)
+    assert int(bn.num_batches_tracked) == 11 and bn._pv2_pending_batches == 0

@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """Merge the per-kernel FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_summary.py output of two
 separate rocprofv3 --pmc passes) into the JSON bench.py reads for `roofline.traffic`:
-    python tools/pmc_to_json.py fetch_by_kernel.csv write_by_kernel.csv <commit> out.json"""
+    python tools/pmc_to_json.py fetch_by_kernel.csv write_by_kernel.csv <commit> out.json
+The file is stamped with bench.kernel_source_hash() of the tree it is run in (run it on the GPU box,
+next to the sources the counters were collected on): bench.py refuses a file whose hash differs."""
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -37,7 +42,9 @@ def main():
         if k in write:
             kernels[k] = dict(fetch_kb_per_launch=f, write_kb_per_launch=write[k][0], launches=n,
                               avg_us=us)
-    json.dump(dict(commit=sys.argv[3], note="KB per launch; FETCH_SIZE is to be doubled on gfx950 "
+    import bench
+
+    json.dump(dict(commit=sys.argv[3], kernel_source_hash=bench.kernel_source_hash(), note="KB per launch; FETCH_SIZE is to be doubled on gfx950 "
                    "(MI355X_MICROARCH.md, HBM section)", kernels=kernels),
               open(sys.argv[4], "w"), indent=1)
     print("wrote", sys.argv[4], len(kernels), "kernels")
