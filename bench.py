@@ -769,6 +769,9 @@ def main():
         batches = [per_cond[k] for k in PPT_SCHEDULE]
 
     amp_dtype = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
+    if amp_dtype is not None:   # the 16-bit backbone runs output-stationary: group rows by offset mask
+        import ponderv2_amd.kernels as K_amp
+        K_amp.MASK_ORDER = True
     scaler = torch.amp.GradScaler("cuda", enabled=amp_dtype == torch.float16)
 
     # The trainer's one-batch lookahead (engines/train.py staged_batches): the NEXT step's batch is

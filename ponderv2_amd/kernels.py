@@ -139,6 +139,20 @@ def _require_device(*tensors):
 # --------------------------------------------------------------------------------------------
 # Rulebooks
 # --------------------------------------------------------------------------------------------
+TILE_SIZES = (PAIR_TILE, FWD_LDS_TILE, WGRAD_TILE, 2048)
+
+
+def device_tile_prefixes(kstart: torch.Tensor, K: int) -> torch.Tensor:
+    """int32 [4, K+1] on the device: prefix of ceil(count_k / t) for the four tile sizes the conv
+    kernels use, by ONE small launch on the current stream from the device copy of ``kstart`` (no
+    host->device copy, which would stall the host behind the queue)."""
+    dev = torch.empty((len(TILE_SIZES), K + 1), dtype=torch.int32, device=kstart.device)
+    arr = (ctypes.c_int32 * len(TILE_SIZES))(*TILE_SIZES)
+    _lib.check(_lib.lib().pv2_tile_prefix(_ptr(kstart), K, arr, len(TILE_SIZES), _ptr(dev),
+                                          _stream(kstart)), "pv2_tile_prefix")
+    return dev
+
+
 @dataclass
 class Rulebook:
     """Indice pairs of one sparse conv, in canonical (offset k, output row) order."""
@@ -165,6 +179,8 @@ class Rulebook:
     # position tables of the product-row path (pv2_pair_positions): pos_out[k, o] / pos_in[k, i] =
     # index of the pair of offset k with output row o / input row i, or -1; (tensor, row stride)
     _pos: Optional[tuple] = None             # (pos_out, out_stride, pos_in, in_stride)
+    # device tile prefixes [4, K+1] launched where the rulebook was BUILT (see device_tile_prefixes)
+    _tiles_dev: Optional[torch.Tensor] = None
     bounded: bool = False                    # host-side pair counts are upper bounds (no read-back)
     _geoms: dict = field(default_factory=dict)
 
@@ -172,7 +188,7 @@ class Rulebook:
     def n_pairs(self) -> int:
         return int(self.kstart_host[-1])
 
-    TILE_SIZES = (PAIR_TILE, FWD_LDS_TILE, WGRAD_TILE, 2048)
+    TILE_SIZES = TILE_SIZES
 
     def tiles(self, tile: int):
         """(device prefix int32[K+1], total, host prefix) of ceil(count_k / tile).  The device
@@ -180,21 +196,28 @@ class Rulebook:
         (pv2_tile_prefix on the device copy of ``kstart`` - no host->device copy, which would
         stall the host behind the queue); the totals come from the host copy of ``kstart``."""
         if not self._tiles:
-            sizes = self.TILE_SIZES
-            dev = torch.empty((len(sizes), self.K + 1), dtype=torch.int32, device=self.kstart.device)
-            arr = (ctypes.c_int32 * len(sizes))(*sizes)
-            _lib.check(_lib.lib().pv2_tile_prefix(_ptr(self.kstart), self.K, arr, len(sizes),
-                                                  _ptr(dev), _stream(self.kstart)), "pv2_tile_prefix")
-            for i, t in enumerate(sizes):
+            dev = self._tiles_dev if self._tiles_dev is not None else device_tile_prefixes(self.kstart, self.K)
+            for i, t in enumerate(self.TILE_SIZES):
                 host = np.zeros(self.K + 1, dtype=np.int64)
                 np.cumsum((np.diff(self.kstart_host) + t - 1) // t, out=host[1:])
                 self._tiles[t] = (dev[i], int(host[-1]), host)
         return self._tiles[tile]
 
+    def __post_init__(self):
+        # The device-side tile prefixes are launched HERE, on the stream that builds the rulebook
+        # (the caller's, or the geometry side stream, which every consumer is ordered behind) - not
+        # lazily at first use: the first user may be a weight gradient running on the backward side
+        # stream, and a grad-input kernel on the main stream would then read the table before the
+        # side stream has written it (found in round 3: wrong gradients below a 48-channel
+        # inverse conv whenever the allocator handed out a dirty block).
+        if self._tiles_dev is None and self.kstart is not None and self.kstart.is_cuda:
+            self._tiles_dev = device_tile_prefixes(self.kstart, self.K)
+
     def transposed(self) -> "Rulebook":
         """Same pairs with the roles of input and output swapped (inverse conv / grad-input)."""
         rb = Rulebook(self.K, self.n_out, self.n_in, self.pair_out, self.pair_in, self.kstart,
-                      self.kstart_host, self.center_k if self.n_in == self.n_out else -1)
+                      self.kstart_host, self.center_k if self.n_in == self.n_out else -1,
+                      _tiles_dev=self._tiles_dev)
         rb._tiles = self._tiles
         rb.bounded = self.bounded
         if self._transposed_os is not None:
@@ -263,10 +286,22 @@ def _compact(tbl: torch.Tensor, K: int, n: int, n_rows_dev: Optional[torch.Tenso
     return pair_other, pair_row, kstart, kstart_host
 
 
+def _want_mask_order() -> bool:
+    """The row grouping of the output-stationary kernel costs a mask pass and a device sort (~10
+    launches) per table; it only pays when that kernel runs the bulk of the convs.  With the
+    product-row path on (default) the output-stationary kernel is left with the stem and odd channel
+    counts, which take rows in natural order."""
+    return USE_PR != "all" or MASK_ORDER
+
+
+# (the 16-bit training mode runs every conv output-stationary: trainers / bench.py --amp set this)
+MASK_ORDER = os.environ.get("PV2_OS_MASK_ORDER", "0") == "1"
+
+
 def _mask_order(tbl: torch.Tensor, K: int, n_cols: int, stride: int) -> Optional[torch.Tensor]:
     """Row order for the output-stationary kernel: rows sorted (stably) by the bit mask of their
     present offsets.  None (natural order) for windows wider than 63 offsets and tiny tables."""
-    if K > 63 or n_cols < 64:
+    if K > 63 or n_cols < 64 or not _want_mask_order():
         return None
     mask = torch.empty(n_cols, dtype=torch.int64, device=tbl.device)
     _lib.check(_lib.lib().pv2_table_masks(_ptr(tbl), K, n_cols, stride, None, _ptr(mask),
@@ -493,6 +528,8 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
     shapes = [[int(v) for v in spatial_shape]]
     downs, readback = [], []
 
+    tiles_dev = {}
+
     def compact(tbl, K, n_rows_dev, out_cap):
         nchunks = max(1, (cap + SCAN_CHUNK - 1) // SCAN_CHUNK)
         block_sums = torch.empty(K * nchunks, dtype=torch.int32, device=dev)
@@ -504,9 +541,12 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
         _lib.check(L.pv2_table_compact(_ptr(tbl), K, cap, _ptr(n_rows_dev), _ptr(block_sums),
                                        _ptr(other), _ptr(row), st), "pv2_table_compact")
         readback.append(kstart)
+        tiles_dev[id(kstart)] = device_tile_prefixes(kstart, K)   # on this (the geometry) stream
         return other, row, kstart
 
     def order(tbl, K, n_cols_dev):
+        if not _want_mask_order():
+            return None
         mask = torch.empty(cap, dtype=torch.int64, device=dev)
         _lib.check(L.pv2_table_masks(_ptr(tbl), K, cap, cap, _ptr(n_cols_dev), _ptr(mask), st),
                    "pv2_table_masks")
@@ -568,6 +608,8 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
                               pos=positions(pair_in, pair_out, kstart, K,
                                             K * cap if level == 0 else 27 * cap),
                               perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None))
+    for d in downs + subms:
+        d["tiles_dev"] = tiles_dev[id(d["kstart"])]
     state = dict(cap=cap, n_levels=n_levels, coords=coords, shapes=shapes, downs=downs, subms=subms,
                  readback=readback, dev=dev)
     return state, torch.cat([t.reshape(-1) for t in readback + n_dev[1:]])
@@ -590,7 +632,8 @@ def _finish_unet_geometry(state, host) -> dict:
     for l, d in enumerate(downs, start=1):
         kh = hosts[l - 1]
         P = int(kh[-1])
-        rb = Rulebook(8, n_lvl[l - 1], n_lvl[l], d["pair_in"][:P], d["pair_out"][:P], d["kstart"], kh)
+        rb = Rulebook(8, n_lvl[l - 1], n_lvl[l], d["pair_in"][:P], d["pair_out"][:P], d["kstart"], kh,
+                      _tiles_dev=d["tiles_dev"])
         if n_lvl[l] > 0:
             rb.nbr, rb.nbr_stride, rb.perm = d["tbl"], cap, d["perm"]
             rb._transposed_os = (d["parent"], cap, d["perm_t"], 0)
@@ -603,7 +646,7 @@ def _finish_unet_geometry(state, host) -> dict:
         n = n_lvl[d["level"]]
         P = int(kh[-1])
         rb = Rulebook(d["K"], n, n, d["pair_in"][:P], d["pair_out"][:P], d["kstart"], kh,
-                      center_k=d["K"] // 2)
+                      center_k=d["K"] // 2, _tiles_dev=d["tiles_dev"])
         if n > 0:
             rb.nbr, rb.nbr_stride, rb.perm = d["nbr"], cap, d["perm"]
             rb._transposed_os = (d["nbr"], cap, d["perm"], 1)

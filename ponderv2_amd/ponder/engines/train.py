@@ -128,6 +128,12 @@ class Trainer(TrainerBase):
             cfg.get("amp_dtype", "bfloat16")]
         self.scaler = (torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
                        if cfg.enable_amp else None)
+        if cfg.enable_amp and self.device.type == "cuda":
+            # the 16-bit sparse backbone runs every conv output-stationary: its row tiles are
+            # grouped by offset mask (one device sort per table, with the geometry prefetch)
+            from ponderv2_amd import kernels as _kernels
+
+            _kernels.MASK_ORDER = True
         self.register_hooks(cfg.hooks)
 
     def build_model(self):

@@ -71,7 +71,8 @@ def run(device, dtype, with_bn, seed=0):
                     dbeta=rel(bn_new.bias.grad, bn_ref.bias.grad),
                     running_mean=rel(bn_new.running_mean, bn_ref.running_mean),
                     running_var=rel(bn_new.running_var, bn_ref.running_var))
-        assert int(bn_new.num_batches_tracked) == 1
+        # (counted on the host, written back when the module's state is read: rownorm.py)
+        assert int(bn_new.state_dict()["num_batches_tracked"]) == 1
     else:
         errs["dbias"] = rel(conv_new.bias.grad, conv_ref.bias.grad)
     return errs

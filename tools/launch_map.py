@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Where do the kernel launches of a training step come from?  One step under torch.profiler;
+launches (kernels + async copies / memsets) are counted per phase of the forward pass (host
+``record_function`` ranges) and, for the backward pass, per autograd node type."""
+import collections, os, sys
+import torch
+from torch.profiler import ProfilerActivity, profile, record_function
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from ponderv2_amd.ponder.models import build_model
+from ponderv2_amd.ponder.utils.config import ConfigDict
+
+dev = torch.device("cuda:0")
+model = build_model(ConfigDict(bench.model_cfg(256, "float32"))).to(dev).train()
+opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4, fused=True)
+batch = bench.make_batch(0, 2, 2, dev)
+staged = [model.prefetch(bench.clone_batch(batch))]
+
+
+def step(tag=False):
+    rf = record_function if tag else (lambda name: __import__("contextlib").nullcontext())
+    cur = staged.pop()
+    with rf("phase:stage_next_batch(prefetch geometry)"):
+        staged.append(model.prefetch(bench.clone_batch(batch)))
+    with rf("phase:extract_feature(backbone fwd)"):
+        d = model.extract_feature(cur)
+    with rf("phase:prepare_ray"):
+        ray, d = model.prepare_ray(d)
+    with rf("phase:prepare_volume(to_dense + UNet3D)"):
+        vol = model.prepare_volume(d)
+    with rf("phase:render"):
+        out = model.render_func(ray, vol)
+    with rf("phase:losses"):
+        res = model.render_loss(out, ray)
+    loss = res[0] if isinstance(res, (tuple, list)) else res["loss"]
+    with rf("phase:zero_grad"):
+        opt.zero_grad(set_to_none=True)
+    with rf("phase:backward"):
+        loss.backward()
+    with rf("phase:optimizer"):
+        opt.step()
+
+
+for _ in range(4):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(tag=True)
+    torch.cuda.synchronize()
+
+
+def launches(ev):
+    return len(ev.kernels) + sum(launches(c) for c in ev.cpu_children)
+
+
+events = prof.events()
+phases = [e for e in events if e.name.startswith("phase:")]
+total = 0
+for ph in phases:
+    n = launches(ph)
+    total += n
+    print("%-46s %5d launches  host %.2f ms" % (ph.name[6:], n, ph.cpu_time_total / 1e3))
+    groups = collections.Counter()
+    hosts = collections.Counter()
+    for c in ph.cpu_children:
+        name = c.name.replace("autograd::engine::evaluate_function: ", "bwd ")
+        groups[name] += launches(c)
+        hosts[name] += c.cpu_time_total
+    for name, k in groups.most_common(14 if "backward" in ph.name else 8):
+        if k:
+            print("        %5d  %-60s host %.2f ms" % (k, name[:60], hosts[name] / 1e3))
+print("total launches in the step:", total)
