@@ -32,3 +32,15 @@ def fill_deterministic(module):
                 v = formula_tensor(name, p.shape, 0.1)
             p.copy_(v.to(p.dtype))
     return module
+
+
+GRAD_PROBES = 8
+
+
+def grad_probe(name, i, shape):
+    """The i-th random probe of parameter ``name``: iid standard normals from a CPU generator seeded
+    by the name (same torch build here and on the GPU box => same values).  A gradient's projection
+    on it estimates the gradient ERROR without storing 40 M reference values: for e = g - g_ref,
+    E[(probe . e)^2] = |e|^2."""
+    g = torch.Generator().manual_seed(zlib.crc32(f"{name}|{i}".encode()))
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32)

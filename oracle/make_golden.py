@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import ref_shims  # noqa: E402
-from oracle.detweights import fill_deterministic, formula_tensor  # noqa: E402
+from oracle.detweights import GRAD_PROBES, fill_deterministic, formula_tensor, grad_probe  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -101,20 +101,6 @@ class _EverythingDouble:
     def __exit__(self, *exc):
         torch.set_default_dtype(self._default)
         torch.FloatTensor, torch.Tensor.float = self._ft, self._float
-
-
-GRAD_PROBES = 8
-
-
-def grad_probe(name, i, shape):
-    """The i-th random probe of parameter ``name``: iid standard normals from a CPU generator seeded
-    by the name (same torch build here and on the GPU box => same values).  A gradient's projection
-    on it estimates the gradient ERROR without storing 40 M reference values: for e = g - g_ref,
-    E[(probe . e)^2] = |e|^2."""
-    import zlib
-
-    g = torch.Generator().manual_seed(zlib.crc32(f"{name}|{i}".encode()))
-    return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
 
 
 def float64_gradient_record(model, batch, rec, post=None):
@@ -291,23 +277,36 @@ def ponder_indoor_cfg0_case(ConfigDict, scenes=1, rays_per_view=64, n_voxels=200
     model section (SpUNet-v1m1 32..256 channels, (2,3,4,6,2,2,2,2) blocks, 128x128x32 grid,
     UNet3D-v1m2, NeuS head 96+36 samples) on one synthetic ScanNet-shaped scene of 20 000 voxels and
     2 views x 64 = 128 rays, fp32, training mode.  Besides the losses and gradient probes the
-    fixture holds what the renderer returned per ray (RGB, depth) and the importance sampler's
-    searchsorted bin indices (integer work: asserted bit-exact by the tests)."""
-    import time
-
-    from ponder.models.builder import MODELS
+    fixture holds what the renderer returned per ray (RGB, depth), the importance sampler's
+    searchsorted bin indices (integer work: asserted bit-exact by the tests) and the FLOAT64 record
+    of every parameter gradient (float64_gradient_record)."""
     from ponderv2_amd.ponder.datasets import collate_fn, make_scene
 
     cfg = _render_cfg()
     mcfg = cfg.model.to_dict()
     mcfg.update(ray_nsample=rays_per_view, template="a photo of a [x]")
+    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
+                        for i in range(scenes)])
+    gnames = ["backbone.conv_input.1.bias", "backbone.enc.3.block5.bn2.weight",
+              "backbone.dec.0.block1.bn2.bias", "proj_net.final_conv.bias",
+              "renderer.field.sdf_decoder.lin1.bias", "renderer.field.rgb_decoder.lin0.weight",
+              "renderer.field.semantic_decoder.lin0.bias", "renderer.field.deviation_network.variance"]
+    _indoor_full_step(ConfigDict, mcfg, batch, name, rays_per_view, gnames)
+
+
+def _indoor_full_step(ConfigDict, mcfg, batch, name, rays_per_view, gnames):
+    """One reference training step of a PonderIndoor model at full size -> tests/golden/<name>.npz."""
+    import time
+
+    from ponder.models.builder import MODELS
+
+    scenes = len(batch["offset"])
     torch.manual_seed(0)
     model = MODELS.build(ConfigDict(mcfg))
     fill_deterministic(model)
     model.train()
-    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
-                        for i in range(scenes)])
-    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()
+           if not k.endswith("_host")}
     captured = {"rgb": [], "depth": [], "normal": []}
     orig_render = model.renderer.forward
 
@@ -334,13 +333,9 @@ def ponder_indoor_cfg0_case(ConfigDict, scenes=1, rays_per_view=64, n_voxels=200
             sel = next(it)[:rays_per_view]
             pix[b, v, :, 0], pix[b, v, :, 1] = ys[sel].numpy(), xs[sel].numpy()
     params = dict(model.named_parameters())
-    gnames = ["backbone.conv_input.1.bias", "backbone.enc.3.block5.bn2.weight",
-              "backbone.dec.0.block1.bn2.bias", "proj_net.final_conv.bias",
-              "renderer.field.sdf_decoder.lin1.bias", "renderer.field.rgb_decoder.lin0.weight",
-              "renderer.field.semantic_decoder.lin0.bias", "renderer.field.deviation_network.variance"]
     assert len(rec.search) == scenes
     model.renderer.forward = orig_render
-    g64 = float64_gradient_record(model, batch, rec)
+    g64 = float64_gradient_record(model, {k: v for k, v in batch.items() if not k.endswith("_host")}, rec)
     np.savez_compressed(
         os.path.join(GOLDEN, name + ".npz"), ray_pixels=pix, **g64,
         rands=np.array(len(rec.rand)),
@@ -354,6 +349,44 @@ def ponder_indoor_cfg0_case(ConfigDict, scenes=1, rays_per_view=64, n_voxels=200
         **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
     print(name + ":", {k: round(float(v), 6) for k, v in out.items()},
           "rand draws", [tuple(r.shape) for r in rec.rand])
+
+
+PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
+PPT_VALID = (tuple(range(0, 13)), tuple(range(5, 25)), tuple(range(20, 36)))
+
+
+def ponder_ppt_full_case(ConfigDict, rays_per_view=256):
+    """BASELINE.json configs[3] at FULL size: the model section of the reference's shipped
+    multi-dataset config (configs/scannet/pretrain-ponder-ppt-v1m1-0-sc-s3-st-spunet.py:22-90:
+    SpUNet-v1m3 PDNorm 32..256 channels, (2,3,4,6,2,2,2,2) blocks, decoupled + adaptive + affine
+    norms, 128x128x32 grid, UNet3D-v1m2, NeuS head, ray_nsample 256) - only the class tables are
+    the stub text encoder's - run for ONE BATCH PER CONDITION (2 scenes, 512 rays each):
+    tests/golden/ponder_ppt_full_<condition>.npz."""
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+    from ponderv2_amd.ponder.utils.config import Config
+
+    cfg = Config.fromfile(os.path.join(
+        ref_shims.REFERENCE_ROOT, "configs/scannet/pretrain-ponder-ppt-v1m1-0-sc-s3-st-spunet.py"))
+    ref_shims.install(num_classes=36)
+    for k, cond in enumerate(PPT_CONDITIONS):
+        mcfg = cfg.model.to_dict()
+        mcfg.update(ray_nsample=rays_per_view, conditions=PPT_CONDITIONS,
+                    class_name=tuple(f"class {i}" for i in range(36)), valid_index=PPT_VALID,
+                    template=("a", "b"))
+        kw = dict(num_views=2, image_hw=(480, 640), condition=cond, num_classes=len(PPT_VALID[k]))
+        batch = collate_fn([make_scene(700 + 10 * k + i, **kw) for i in range(2)])
+        bns = PPT_CONDITIONS_BACKBONE.index(cond)
+        gnames = ["embedding_table.weight", "backbone.conv_input.bn.modulation.1.weight",
+                  f"backbone.enc.3.block5.bn2.bns.{bns}.weight",
+                  f"backbone.dec.0.block1.bn2.bns.{bns}.bias", "proj_net.final_conv.bias",
+                  "renderer.field.sdf_decoder.lin1.bias", "renderer.field.semantic_decoder.lin0.bias",
+                  "renderer.field.deviation_network.variance"]
+        _indoor_full_step(ConfigDict, mcfg, batch, "ponder_ppt_full_" + cond.lower(), rays_per_view,
+                          gnames)
+    ref_shims.install()  # back to the default 20-class text table
+
+
+PPT_CONDITIONS_BACKBONE = ("ScanNet", "S3DIS", "Structured3D")   # the shipped backbone's order
 
 
 # reduced nuScenes geometry shared with tests/golden_cases.py: a 54 m box, 1.2 m dense cells
@@ -428,6 +461,55 @@ def ponder_outdoor_case(ConfigDict):
           "rays", batch["ray_offset"].tolist(), "voxels", batch["offset"].tolist())
 
 
+def ponder_outdoor_full_case(ConfigDict):
+    """BASELINE.json configs[4] at FULL size: the reference's PonderOutdoor.forward with the model
+    section of configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py UNCHANGED (SpUNet-v1m1
+    32..256 channels over a 1080 x 1080 x 80 voxel range, 180 x 180 x 5 dense grid, SimpleConv3D
+    projection, 16-wide five-block SDF MLP, 72 + 24 samples, mask ratio 0.8) on ONE synthetic lidar
+    sweep with 6 x 512 rays; fp32 step + the float64 record of every parameter gradient."""
+    import time
+
+    from ponder.models.builder import MODELS
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+    from ponderv2_amd.ponder.utils.config import Config
+
+    cfg = Config.fromfile(os.path.join(ref_shims.REFERENCE_ROOT,
+                                       "configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py"))
+    mcfg = cfg.model.to_dict()
+    ref_shims.install(num_classes=16)
+    torch.manual_seed(0)
+    model = MODELS.build(ConfigDict(mcfg))
+    fill_deterministic(model)
+    model.train()
+    batch = lidar_collate_fn([make_lidar_scene(900, point_nsample=512)])
+    inp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()
+           if not k.endswith("_host")}
+    torch.manual_seed(99)
+    t0 = time.perf_counter()
+    with Recorder() as rec:
+        out = model(inp)
+    out["loss"].backward()
+    print("ponder_outdoor_full reference step: %.1f s" % (time.perf_counter() - t0))
+    B = len(batch["offset"])
+    mask_rand = np.concatenate([r.numpy().reshape(-1) for r in rec.rand[:B]])
+    draws = rec.rand[B:]
+    params = dict(model.named_parameters())
+    gnames = ["mtoken", "backbone.conv_input.1.bias", "backbone.enc.3.block5.bn2.weight",
+              "backbone.dec.0.block1.bn2.bias", "proj_net.conv.1.bias",
+              "renderer.field.sdf_decoder.lin1.bias", "renderer.field.deviation_network.variance"]
+    g64 = float64_gradient_record(model, {k: v for k, v in batch.items() if not k.endswith("_host")}, rec)
+    np.savez_compressed(
+        os.path.join(GOLDEN, "ponder_outdoor_full.npz"), mask_rand=mask_rand, **g64,
+        rands=np.array(len(draws)), **{f"rand_{i}": r.numpy() for i, r in enumerate(draws)},
+        n_voxels=np.array(int(batch["offset"][-1])), n_rays=np.array(int(batch["ray_offset"][-1])),
+        out_names=np.array(list(out.keys())), out_values=np.array([float(v) for v in out.values()]),
+        grad_names=np.array(gnames),
+        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(gnames)})
+    ref_shims.install()
+    print("ponder_outdoor_full:", {k: round(float(v), 6) for k, v in out.items()},
+          "rays", batch["ray_offset"].tolist(), "voxels", batch["offset"].tolist())
+
+
 PDNORM_BACKBONE = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_channels=16,
                        context_channels=32, channels=(16, 32, 48, 64, 64, 48, 32, 32),
                        layers=(1, 1, 1, 1, 1, 1, 1, 1), conditions=("ScanNet", "S3DIS", "Structured3D"),
@@ -480,8 +562,6 @@ def transform_chain_case():
     print("transform_chain:", {k: v.shape for k, v in out.items()})
 
 
-PPT_CONDITIONS = ("Structured3D", "ScanNet", "S3DIS")
-PPT_VALID = (tuple(range(0, 13)), tuple(range(5, 25)), tuple(range(20, 36)))
 
 
 def ponder_ppt_case(ConfigDict):
@@ -544,7 +624,9 @@ def main():
                  indoor=lambda: ponder_indoor_case(ConfigDict), lidar=lidar_transform_case, pdnorm=spunet_pdnorm_case, transforms=transform_chain_case, ppt=lambda: ponder_ppt_case(ConfigDict),
                  outdoor=lambda: ponder_outdoor_case(ConfigDict),
                  cfg0=lambda: ponder_indoor_cfg0_case(ConfigDict),
-                 cfg1=lambda: ponder_indoor_cfg1_case(ConfigDict))
+                 cfg1=lambda: ponder_indoor_cfg1_case(ConfigDict),
+                 ppt_full=lambda: ponder_ppt_full_case(ConfigDict),
+                 outdoor_full=lambda: ponder_outdoor_full_case(ConfigDict))
     for name, fn in cases.items():
         if not only or name in only:
             fn()

@@ -211,16 +211,36 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     float* __restrict__ Y, int tile_base, int skip_lo, int skip_len, int store) {
   constexpr int NT = 32 * NB;
   constexpr int LDT = NT + 4;  // row stride of the reduction-major (TRANS) slab
-  __shared__ __attribute__((aligned(16))) float sW[2][NT * kWPad];
+  // two weight slabs; the product-row epilogue re-uses the space as four 32 x 32 staging tiles
+  constexpr int kSlabFloats = NT * kWPad;
+  constexpr int kStageFloats = 32 * kWPad;
+  constexpr int kLdsFloats = 2 * kSlabFloats > 4 * kStageFloats ? 2 * kSlabFloats : 4 * kStageFloats;
+  __shared__ __attribute__((aligned(16))) float sBuf[kLdsFloats];
+  float(*sW)[kSlabFloats] = reinterpret_cast<float(*)[kSlabFloats]>(sBuf);
   static_assert(kKC * LDT <= NT * kWPad, "TRANS slab fits the same buffer");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int tile = blockIdx.x / n_groups + tile_base;
   if (tile >= skip_lo) tile += skip_len;  // the tiles of the centre offset ran in the store pass
   const int grp = blockIdx.x % n_groups;
-  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
-  const int k = find_offset(tile_start, K, tile);
-  const int p0 = kstart[k] + (tile - tile_start[k]) * kFwdTile;
-  const int pend = kstart[k + 1];
+  int k, p0, pend;
+  if (K < 64) {
+    // offset of this tile: ONE round of loads - lane l holds the l-th entries of both prefixes, the
+    // offset is the last lane whose tile prefix is <= tile (a ballot), its pair range comes from
+    // lane reads - instead of a five-step binary search of dependent loads: every workgroup of the
+    // launch sits in this prologue at the same time, nothing overlaps it
+    const int ts_l = lane <= K ? tile_start[lane] : 0x7fffffff;
+    const int ks_l = lane <= K ? kstart[lane] : 0;
+    if (tile >= __builtin_amdgcn_readlane(ts_l, K)) return;  // grid sized from an upper bound
+    const unsigned long long m = __ballot(ts_l <= tile);
+    k = 63 - __builtin_clzll(m);
+    p0 = __builtin_amdgcn_readlane(ks_l, k) + (tile - __builtin_amdgcn_readlane(ts_l, k)) * kFwdTile;
+    pend = __builtin_amdgcn_readlane(ks_l, k + 1);
+  } else {
+    if (tile >= tile_start[K]) return;
+    k = find_offset(tile_start, K, tile);
+    p0 = kstart[k] + (tile - tile_start[k]) * kFwdTile;
+    pend = kstart[k + 1];
+  }
   const int i = lane & 31, h = lane >> 5;
   const int p = p0 + wave * 32 + i;
   const bool pv = p < pend;
@@ -306,6 +326,33 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     __syncthreads();
   }
 
+  if (store == 2 && (c_out & 3) == 0) {
+    // product rows: the wave's 32 result rows are CONSECUTIVE rows of Y (row = pair index), so each
+    // 32 x 32 block goes through a wave-private LDS tile and leaves as 16-byte stores - 4 store
+    // instructions per block instead of 16 (the epilogue is store-issue bound, and every
+    // workgroup of the launch reaches it at about the same time).  The slab buffers are free: the
+    // loop above ended with a barrier.
+    float* stage = sBuf + wave * kStageFloats;
+    const int c4 = lane & 7, r8 = lane >> 3;
+    const int64_t row_base = (int64_t)p0 + wave * 32;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * h) * kWPad + i] = acc[nb][r];
+      __builtin_amdgcn_wave_barrier();
+      const int n = n0 + nb * 32 + 4 * c4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = r8 + 8 * j;
+        const float4 v = *reinterpret_cast<const float4*>(&stage[row * kWPad + 4 * c4]);
+        if (row_base + row < pend && n < c_out)
+          *reinterpret_cast<float4*>(Y + (row_base + row) * c_out + n) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   int orow[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) orow[r] = __shfl(row_out, (r & 3) + 8 * (r >> 2) + 4 * h);

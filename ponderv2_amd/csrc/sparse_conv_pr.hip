@@ -87,33 +87,59 @@ __device__ __forceinline__ void sum_row(const float4* __restrict__ T4, int c4n,
     acc[j] = a;
   }
   int q = 0;
-  for (; q + 4 <= cnt; q += 4) {  // four product rows in flight, added in list order
-    const int64_t p0 = list[q], p1 = list[q + 1], p2 = list[q + 2], p3 = list[q + 3];
-    float4 v0[NJ], v1[NJ], v2[NJ], v3[NJ];
+  for (; q + 8 <= cnt; q += 8) {  // eight product rows in flight, added in list order
+    int64_t p[8];
+    float4 v[8][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = l + j * TS;
-      const bool ok = col < c4n;
-      v0[j] = ok ? T4[p0 * c4n + col] : zero;
-      v1[j] = ok ? T4[p1 * c4n + col] : zero;
-      v2[j] = ok ? T4[p2 * c4n + col] : zero;
-      v3[j] = ok ? T4[p3 * c4n + col] : zero;
-    }
+    for (int u = 0; u < 8; ++u) p[u] = list[q + u];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      add4(acc[j], v0[j]);
-      add4(acc[j], v1[j]);
-      add4(acc[j], v2[j]);
-      add4(acc[j], v3[j]);
-    }
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = l + j * TS;
+        v[u][j] = col < c4n ? T4[p[u] * c4n + col] : zero;
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
   }
-  for (; q < cnt; ++q) {
-    const int64_t p = list[q];
+  if (q + 4 <= cnt) {  // four
+    int64_t p[4];
+    float4 v[4][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = l + j * TS;
-      if (col < c4n) add4(acc[j], T4[p * c4n + col]);
+    for (int u = 0; u < 4; ++u) p[u] = list[q + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = l + j * TS;
+        v[u][j] = col < c4n ? T4[p[u] * c4n + col] : zero;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
+    q += 4;
+  }
+  {  // up to three left: issued together, added in order
+    const int rest = cnt - q;
+    float4 v[3][NJ];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int64_t p = u < rest ? list[q + u] : 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = l + j * TS;
+        v[u][j] = (u < rest && col < c4n) ? T4[p * c4n + col] : zero;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u < rest) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
+      }
   }
 }
 
@@ -248,9 +274,15 @@ int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K
   PV2_REQUIRE(n_rows >= 0 && pos_stride >= n_rows, "pv2_spconv_reduce_rows: bad row count");
   if (bn_blocks) *bn_blocks = 0;
   if (n_rows == 0) return PV2_OK;
-  int blocks;
-  int64_t rpb;
-  pv2::bn_partial_geometry(n_rows, c, &blocks, &rpb);
+  // One row per team and pass wherever the row count allows it: the sum of a row is a chain of
+  // dependent loads (table -> list -> product rows), so a team that walks many rows is latency-bound
+  // (measured 20-27 us per launch regardless of size with >= 16 KB of output per workgroup).  At
+  // most 1024 workgroups: the BatchNorm statistics leave one partial row each.
+  const int c4n = c / 4;
+  const int nt = 256 / (c4n <= 8 ? 8 : c4n <= 16 ? 16 : c4n <= 32 ? 32 : 64);
+  int64_t rpb = (n_rows + 1023) / 1024;
+  rpb = (rpb + nt - 1) / nt * nt;
+  const int blocks = (int)((n_rows + rpb - 1) / rpb);
   if (bn_partial) {
     launch_reduce<true>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,
                         bn_partial, s);

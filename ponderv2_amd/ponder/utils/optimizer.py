@@ -62,6 +62,59 @@ def _ready_for_fused(optimizer):
     return optimizer
 
 
+def _lean_fused_sgd_step(optimizer):
+    """Replace the per-step Python of torch's fused SGD (``_init_group`` walks every parameter,
+    re-checks its state and regroups the lists by device and dtype on every call: ~1.3 ms of host
+    time per step for this model's ~240 tensors, on a step that is host-bound) by a direct call of
+    the same fused multi-tensor kernel (``torch._fused_sgd_``) on lists that are built once.  Same
+    update rule, same state (the momentum buffers are the ones in ``optimizer.state``, so
+    checkpoints are unchanged); hyper-parameters are read from the group every step (the OneCycle
+    schedule moves ``lr`` and ``momentum``).  Parameters without a gradient are skipped, as torch
+    does.  Falls back to torch's own step when called with a closure."""
+    if not (isinstance(optimizer, torch.optim.SGD) and optimizer.defaults.get("fused")
+            and hasattr(torch, "_fused_sgd_")):
+        return optimizer
+    torch_step = optimizer.step
+    cache = {}
+
+    def lists(group_index, group):
+        key = (group_index, len(group["params"]))
+        if key not in cache:
+            ps = list(group["params"])
+            cache[key] = (ps, [optimizer.state[p].get("momentum_buffer") for p in ps])
+        return cache[key]
+
+    @torch.no_grad()
+    def step(closure=None):
+        if closure is not None:
+            return torch_step(closure)
+        grad_scale = getattr(optimizer, "grad_scale", None)
+        found_inf = getattr(optimizer, "found_inf", None)
+        for gi, group in enumerate(optimizer.param_groups):
+            if not group.get("fused") or group.get("dampening", 0) != 0:
+                return torch_step()
+            ps, bufs = lists(gi, group)
+            if group["momentum"] != 0 and any(b is None for b in bufs):
+                cache.clear()           # (state replaced by load_state_dict: rebuild next call)
+                return torch_step()
+            sel = [i for i, p in enumerate(ps) if p.grad is not None]
+            if not sel:
+                continue
+            full = len(sel) == len(ps)
+            params = ps if full else [ps[i] for i in sel]
+            torch._fused_sgd_(params, [p.grad for p in params],
+                              [] if group["momentum"] == 0 else (bufs if full else [bufs[i] for i in sel]),
+                              weight_decay=group["weight_decay"], momentum=group["momentum"],
+                              lr=group["lr"], dampening=0.0, nesterov=group["nesterov"],
+                              maximize=group.get("maximize", False), is_first_step=False,
+                              grad_scale=grad_scale, found_inf=found_inf)
+        return None
+
+    optimizer.register_load_state_dict_post_hook(lambda opt: cache.clear())
+    optimizer.step = step
+    return optimizer
+
+
 def build_optimizer(cfg, model, param_dicts=None):
     """``param_dicts=[dict(keyword=..., lr=..., momentum=..., weight_decay=...)]`` puts the
     parameters whose name contains ``keyword`` into their own group with those ABSOLUTE settings
@@ -72,7 +125,7 @@ def build_optimizer(cfg, model, param_dicts=None):
     cfg = _prefer_fused(cfg, model.parameters())
     if param_dicts is None:
         cfg["params"] = model.parameters()
-        return _ready_for_fused(OPTIMIZERS.build(cfg=cfg))
+        return _lean_fused_sgd_step(_ready_for_fused(OPTIMIZERS.build(cfg=cfg)))
     groups, names = [dict(params=[], lr=cfg["lr"])], [[]]
     for d in param_dicts:
         g = dict(params=[])
@@ -97,7 +150,7 @@ def build_optimizer(cfg, model, param_dicts=None):
         settings = "".join(f" {k}: {v};" for k, v in g.items() if k != "params")
         log.info(f"Params Group {i + 1} -{settings} Params: {names[i]}.")
     cfg["params"] = groups
-    return _ready_for_fused(OPTIMIZERS.build(cfg=cfg))
+    return _lean_fused_sgd_step(_ready_for_fused(OPTIMIZERS.build(cfg=cfg)))
 
 
 @SCHEDULERS.register_module()

@@ -207,14 +207,14 @@ FULL_BACKBONE = dict(type="SpUNet-v1m1", in_channels=6, num_classes=0,
                      channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
 
 
-def run_ponder_indoor_cfg1(device):
+def run_ponder_indoor_cfg1(device, with_float64=True):
     """BASELINE.json configs[1] (the bench workload) at full size: 2 scenes, 512 rays each."""
     return run_ponder_indoor_cfg0(device, scenes=2, rays_per_view=256, n_voxels=None,
-                                  name="ponder_indoor_cfg1")
+                                  name="ponder_indoor_cfg1", with_float64=with_float64)
 
 
 def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
-                           name="ponder_indoor_cfg0"):
+                           name="ponder_indoor_cfg0", with_float64=True):
     """BASELINE.json configs[0] at full size against the reference's own run of it
     (oracle/make_golden.py::ponder_indoor_cfg0_case): one scene, 20 000 voxels, 128 rays, the
     shipped backbone / grid / head.  Returns relative errors of every loss term, of the rendered
@@ -265,7 +265,47 @@ def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
     flips = -1
     if "idx" in capture:
         flips = int((capture["idx"].cpu().numpy() != g["pdf_bins"]).sum())
+    if "g64_names" in g.files and with_float64:
+        errs["float64"] = float64_gradient_errors(params, g)
     return errs, flips
+
+
+def float64_gradient_errors(params, g):
+    """Every parameter gradient of the step against the reference's FLOAT64 pass
+    (oracle/make_golden.py::float64_gradient_record): the fixture holds each gradient's norm and
+    GRAD_PROBES random projections; for e = g - g_ref and iid standard-normal probes
+    E[(probe . e)^2] = |e|^2, so |e| is estimated by the root mean square of the projection
+    differences (8 probes: +-25 % on a single tensor, far tighter on the global figures).  Returns
+    the global relative error ||g - g_ref|| / ||g_ref|| over all parameters and over the backbone
+    alone, the worst single tensor, and the largest relative error of a gradient NORM."""
+    from oracle.detweights import GRAD_PROBES, grad_probe
+
+    num = {"all": 0.0, "backbone": 0.0}
+    den = {"all": 0.0, "backbone": 0.0}
+    worst, worst_name, norm_err = 0.0, "", 0.0
+    for name, ref_norm, ref_proj in zip(g["g64_names"], g["g64_norm"], g["g64_proj"]):
+        name = str(name)
+        grad = params[name].grad
+        assert grad is not None, name
+        flat = grad.detach().double().reshape(-1)
+        e2 = 0.0
+        for i in range(GRAD_PROBES):
+            probe = grad_probe(name, i, grad.shape).to(grad.device).double().reshape(-1)
+            e2 += (float(flat @ probe) - float(ref_proj[i])) ** 2
+        e2 /= GRAD_PROBES
+        for key in num:
+            if key == "all" or name.startswith("backbone."):
+                num[key] += e2
+                den[key] += float(ref_norm) ** 2
+        if ref_norm > 0:
+            rel = (e2 ** 0.5) / float(ref_norm)
+            if rel > worst:
+                worst, worst_name = rel, name
+            norm_err = max(norm_err, abs(float(flat.norm()) - float(ref_norm)) / float(ref_norm))
+    return dict(global_rel=(num["all"] / den["all"]) ** 0.5,
+                backbone_rel=(num["backbone"] / den["backbone"]) ** 0.5,
+                worst_tensor_rel=worst, worst_tensor=worst_name, worst_norm_rel=norm_err,
+                tensors=len(g["g64_names"]))
 
 
 # model section of configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py (reference :20-92)

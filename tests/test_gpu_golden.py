@@ -77,7 +77,8 @@ def test_ponder_ppt_gpu_vs_reference_golden(device):
 
 
 def _check_full_size(errs, flips):
-    print(errs, "bin flips", flips)
+    f64 = errs.pop("float64", None)
+    print(errs, "bin flips", flips, "float64 gradient record", f64)
     assert flips == 0
     losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render_"))}
     assert max(losses.values()) < 1e-4, errs
@@ -87,17 +88,49 @@ def _check_full_size(errs, flips):
     assert errs["render_normal"] < 5e-3, errs
     head = {k: v for k, v in errs.items() if k.startswith(("grad_renderer", "grad_proj_net"))}
     assert max(head.values()) < 1e-3, errs
-    # gradients at the far end of the backbone's backward chain (~60 BatchNorm layers, the deepest
-    # over 2 k rows): fp32 summation order alone moves them by percents while the loss moves by
-    # 1e-6 (measured 1.2e-2 / 3.3e-2 on configs[0] / [1]; identical on every run in this mode)
+    # the eight gradient tensors stored in full come from the reference's FP32 pass: at the far
+    # end of the backbone's backward chain (~60 BatchNorm layers) fp32 summation order alone moves
+    # them by percents on EITHER side, so this bound is loose ...
     deep = {k: v for k, v in errs.items() if k.startswith("grad_backbone")}
     assert max(deep.values()) < 6e-2, errs
+    # ... and the tight statement is against the reference's FLOAT64 pass, over ALL ~230 gradient
+    # tensors of the step (norm + random projections in the fixture): global relative error
+    # ||g - g_ref|| / ||g_ref||, for the whole model and for the backbone alone
+    if f64 is not None:
+        assert f64["tensors"] > 200
+        assert f64["global_rel"] < 1e-3, f64
+        assert f64["backbone_rel"] < 1e-3, f64
+        assert f64["worst_norm_rel"] < 2e-2, f64
 
 
 def test_ponder_indoor_full_size_config1_vs_reference(device):
     """BASELINE.json configs[1] - the bench workload - at FULL size: 2 scenes (46 842 voxels), 512
     rays per scene, rendered in one batched pass here and scene by scene in the reference."""
     _check_full_size(*gc.run_ponder_indoor_cfg1(device))
+
+
+def test_ponder_indoor_full_size_config1_default_kernels_five_runs(device):
+    """The configuration bench.py times - default kernel selection (product-row convs, fused
+    conv + BatchNorm units, deterministic weight gradient), backward side stream ON, final
+    convolution FOLDED into the ray march - on the configs[1] fixture, FIVE times in a row: every
+    loss term and the rendered RGB-D within 1e-4 on every run, the importance sampler's bins
+    bit-exact on every run, and (the sparse backbone being free of atomics) the same loss to the
+    last few bits from run to run."""
+    from ponderv2_amd import fused_head as fhd, kernels as K, sidestream
+
+    assert K.USE_PR == "all" and K.USE_CONVBN and K.USE_WGRAD_DET and K.USE_OS == "auto"
+    assert sidestream.ENABLED and fhd.ENABLED and fhd.FOLD_ENABLED
+    losses = []
+    for run in range(5):
+        errs, flips = gc.run_ponder_indoor_cfg1(device, with_float64=(run == 0))
+        errs.pop("float64", None)
+        terms = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render_"))}
+        assert flips == 0, (run, flips)
+        assert max(terms.values()) < 1e-4, (run, errs)
+        assert max(errs["render_rgb"], errs["render_depth"]) < 1e-4, (run, errs)
+        losses.append(errs["loss"])
+    print("loss error per run:", losses)
+    assert max(losses) - min(losses) < 2e-6, losses
 
 
 def test_ponder_indoor_full_size_config0_vs_reference(device):
