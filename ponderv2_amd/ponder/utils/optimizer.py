@@ -85,7 +85,7 @@ def _lean_fused_sgd_step(optimizer):
         return cache[key]
 
     @torch.no_grad()
-    def step(closure=None):
+    def step(self, closure=None):   # (bound below: lr schedulers wrap ``optimizer.step.__func__``)
         if closure is not None:
             return torch_step(closure)
         grad_scale = getattr(optimizer, "grad_scale", None)
@@ -110,8 +110,10 @@ def _lean_fused_sgd_step(optimizer):
                               grad_scale=grad_scale, found_inf=found_inf)
         return None
 
+    import types
+
     optimizer.register_load_state_dict_post_hook(lambda opt: cache.clear())
-    optimizer.step = step
+    optimizer.step = types.MethodType(step, optimizer)
     return optimizer
 
 

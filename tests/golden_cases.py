@@ -213,6 +213,23 @@ def run_ponder_indoor_cfg1(device, with_float64=True):
                                   name="ponder_indoor_cfg1", with_float64=with_float64)
 
 
+def run_ponder_ppt_full(device, condition_index, with_float64=True):
+    """BASELINE.json configs[3] at FULL size, one batch of one condition: the shipped multi-dataset
+    model (SpUNet-v1m3 PDNorm at full width and depth, 128x128x32 grid, UNet3D-v1m2, NeuS head, 512
+    rays per scene) against the reference's own step (oracle/make_golden.py::ponder_ppt_full_case)."""
+    from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    cond = PPT_CONDITIONS[condition_index]
+    cfg = indoor_model_cfg(dict(PDNORM_BACKBONE, base_channels=32, context_channels=256,
+                                channels=FULL_BACKBONE["channels"], layers=FULL_BACKBONE["layers"]),
+                           grid_shape=(128, 128, 32), ray_nsample=256)
+    cfg.update(conditions=PPT_CONDITIONS, class_name=tuple(f"class {i}" for i in range(36)),
+               valid_index=PPT_VALID, template=("a", "b"))
+    kw = dict(num_views=2, image_hw=(480, 640), condition=cond, num_classes=len(PPT_VALID[condition_index]))
+    batch = collate_fn([make_scene(700 + 10 * condition_index + i, **kw) for i in range(2)])
+    return _run_indoor_full(device, cfg, batch, "ponder_ppt_full_" + cond.lower(), with_float64)
+
+
 def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
                            name="ponder_indoor_cfg0", with_float64=True):
     """BASELINE.json configs[0] at full size against the reference's own run of it
@@ -220,21 +237,27 @@ def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
     shipped backbone / grid / head.  Returns relative errors of every loss term, of the rendered
     RGB / depth / normal per ray, of the gradient probes, and the number of importance-sampling bin
     indices that differ from the reference's ``searchsorted`` result."""
-    from ponderv2_amd import fused_head as fhd
     from ponderv2_amd.ponder.datasets import collate_fn, make_scene
+
+    cfg = indoor_model_cfg(FULL_BACKBONE, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
+    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
+                        for i in range(scenes)])
+    return _run_indoor_full(device, cfg, batch, name, with_float64)
+
+
+def _run_indoor_full(device, cfg, batch, name, with_float64=True):
+    """One training step of a full-size PonderIndoor model against tests/golden/<name>.npz."""
+    from ponderv2_amd import fused_head as fhd
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    cfg = indoor_model_cfg(FULL_BACKBONE, grid_shape=(128, 128, 32), ray_nsample=rays_per_view)
     model = build_model(ConfigDict(cfg))
     fill_deterministic(model)
     model = model.to(device).train()
     replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
     model.renderer.sampler.initial_sampler.rand = replay
     model.renderer.sampler.pdf_sampler.rand = replay
-    batch = collate_fn([make_scene(i, num_views=2, image_hw=(480, 640), n_voxels=n_voxels)
-                        for i in range(scenes)])
     assert int(batch["offset"][-1]) == int(g["n_voxels"])
     batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     batch["ray_pixels"] = torch.from_numpy(g["ray_pixels"])
@@ -370,6 +393,40 @@ def run_ponder_outdoor(device):
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    return errs
+
+
+def run_ponder_outdoor_full(device, with_float64=True):
+    """BASELINE.json configs[4] at FULL size, one sweep: the reference's nuScenes model section
+    unchanged (SpUNet-v1m1 32..256 over a 1080 x 1080 x 80 voxel range, 180 x 180 x 5 dense grid,
+    SimpleConv3D, 16-wide five-block SDF MLP, 72 + 24 samples, 6 x 512 rays, mask ratio 0.8) against
+    the reference's own step (oracle/make_golden.py::ponder_outdoor_full_case)."""
+    from ponderv2_amd.ponder.datasets import lidar_collate_fn, make_lidar_scene
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    g = np.load(os.path.join(GOLDEN, "ponder_outdoor_full.npz"))
+    cfg = outdoor_model_cfg(dict(FULL_BACKBONE, in_channels=4))
+    model = build_model(ConfigDict(cfg))
+    fill_deterministic(model)
+    model = model.to(device).train()
+    replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
+    model.renderer.sampler.initial_sampler.rand = replay
+    model.renderer.sampler.pdf_sampler.rand = replay
+    batch = lidar_collate_fn([make_lidar_scene(900, point_nsample=512)])
+    assert int(batch["offset"][-1]) == int(g["n_voxels"]) and int(batch["ray_offset"][-1]) == int(g["n_rays"])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch["mask_rand"] = torch.from_numpy(g["mask_rand"]).to(device)
+    out = model(batch)
+    out["loss"].backward()
+    errs = {}
+    for name, val in zip(g["out_names"], g["out_values"]):
+        errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
+    params = dict(model.named_parameters())
+    for i, name in enumerate(g["grad_names"]):
+        errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
+    if with_float64:
+        errs["float64"] = float64_gradient_errors(params, g)
     return errs
 
 
