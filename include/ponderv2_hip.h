@@ -317,6 +317,19 @@ int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, co
                                  float* grad_weight, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 2 x 2 x 2 max-pooling of a channels-last dense grid x[B, Z, Y, X, C] -> y[B, Z/2, Y/2, X/2, C]
+ * (floor sizes, no padding): nn.MaxPool3d(kernel_size=2) of the projection network's encoders
+ * (ponder/models/ponder/unet3d.py:326-330) without ATen's transposes through NCDHW.  idx: one
+ * uint32 per 4 output channels = four 8-bit window positions (z*4 + y*2 + x) of the maxima (first
+ * maximum wins, as max_pool3d_with_indices).  backward writes EVERY element of grad_x (zeros
+ * outside the maxima): nothing to clear, no atomics.  C % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_maxpool3d_cl_forward(const float* x, int B, int Z, int Y, int X, int C, float* y,
+                             uint32_t* idx, pv2_stream_t stream);
+int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, int Z, int Y, int X,
+                              int C, float* grad_x, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d over the active-voxel feature matrix x[n, c], fused with the optional
  * residual add and ReLU that follow it in SpUNet's blocks; and a column sum.
  * Replaces the ATen batch_norm / add / relu kernels behind BasicBlock.forward

@@ -302,20 +302,30 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // all NB fragments of this reduction step first, then the MFMAs ROUND-ROBIN over the NB
+      // accumulators: consecutive MFMAs of a wave never wait for each other's result
+      float4 b[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float4 b;
         if (!TRANS) {
-          b = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
+          b[nb] = *reinterpret_cast<const float4*>(&sW[buf][(nb * 32 + i) * kWPad + 8 * s + 4 * h]);
         } else {
           const float* col = &sW[buf][(8 * s + 4 * h) * LDT + nb * 32 + i];
-          b = make_float4(col[0], col[LDT], col[2 * LDT], col[3 * LDT]);
+          b[nb] = make_float4(col[0], col[LDT], col[2 * LDT], col[3 * LDT]);
         }
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b.x, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b.y, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b.z, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, b.w, acc[nb], 0, 0, 0);
       }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, b[nb].w, acc[nb], 0, 0, 0);
     }
     if (more) {
 #pragma unroll

@@ -231,19 +231,54 @@ class SingleConv(nn.Sequential):
 
 # ATen has no channels-last kernel for max_pool3d: it transposes the input to (N, T, C, H, W) and the
 # gradient back - at the full-resolution level one 0.50 ms strided copy forward and a 0.20 ms strided
-# ReLU backward behind it per step.  ``channels_last_max_pool3d`` gets the same
-# pooling from kernels that DO know the layout.  Not measured on MI355X yet (written after the
-# round's GPU budget was spent), hence opt-in: PV2_CL_MAXPOOL=1.
-CL_MAXPOOL = os.environ.get("PV2_CL_MAXPOOL", "0") == "1"
+# ReLU backward behind it per step.  The HIP kernels of csrc/dense_pool.hip pool the channels-last
+# grid where it lies (one launch per direction, every gradient element written once).
+# PV2_CL_MAXPOOL=0 restores nn.MaxPool3d.
+CL_MAXPOOL = os.environ.get("PV2_CL_MAXPOOL", "1") != "0"
+
+
+class _MaxPoolCL(torch.autograd.Function):
+    """F.max_pool3d(x, 2) for a float32 channels-last-3d device tensor (B, C, Z, Y, X)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from ponderv2_amd import _lib
+        from ponderv2_amd.kernels import _ptr, _stream
+
+        b, c, z, y, xx = x.shape
+        out = torch.empty((b, z // 2, y // 2, xx // 2, c), dtype=torch.float32, device=x.device)
+        idx = torch.empty((b, z // 2, y // 2, xx // 2, c // 4), dtype=torch.int32, device=x.device)
+        _lib.check(_lib.lib().pv2_maxpool3d_cl_forward(_ptr(x), b, z, y, xx, c, _ptr(out), _ptr(idx),
+                                                       _stream(x)), "pv2_maxpool3d_cl_forward")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, c, z, y, xx)
+        return out.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from ponderv2_amd import _lib
+        from ponderv2_amd.kernels import _ptr, _stream
+
+        (idx,) = ctx.saved_tensors
+        b, c, z, y, xx = ctx.shape
+        g = grad_out.permute(0, 2, 3, 4, 1).contiguous()   # channels-last storage: a no-op view
+        gx = torch.empty((b, z, y, xx, c), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().pv2_maxpool3d_cl_backward(_ptr(g), _ptr(idx), b, z, y, xx, c, _ptr(gx),
+                                                        _stream(g)), "pv2_maxpool3d_cl_backward")
+        return gx.permute(0, 4, 1, 2, 3)
 
 
 def channels_last_max_pool3d(x):
     """``F.max_pool3d(x, 2)`` for a channels-last-3d ``x`` (B, C, Z, Y, X) without leaving the
-    layout: a 2x2 ``max_pool2d`` over (Y, X) on the ``(B*Z, C, Y, X)`` channels-last-2d view of the
-    same memory (ATen's NHWC kernel), then the maximum over pairs of z-slices.  Same values; the
-    gradient goes to one maximum per window as in max_pool3d (they can only differ in WHICH one on
-    exact ties, which after a ReLU are zeros whose gradient the ReLU drops anyway)."""
+    layout.  Device float32 tensors with C % 4 == 0 run the kernels of csrc/dense_pool.hip (same
+    values, same choice among tied maxima as max_pool3d_with_indices: the first in window order);
+    anything else takes a layout-aware composite of stock ops - a 2x2 ``max_pool2d`` over (Y, X) on
+    the ``(B*Z, C, Y, X)`` channels-last-2d view of the same memory, then the maximum over pairs of
+    z-slices (same values; ties may resolve to another member of the window)."""
     b, c, z, y, xx = x.shape
+    if (x.is_cuda and x.dtype == torch.float32 and c % 4 == 0 and min(z, y, xx) >= 2
+            and x.is_contiguous(memory_format=torch.channels_last_3d)):
+        return _MaxPoolCL.apply(x)
     z2 = z // 2
     rows = x.permute(0, 2, 3, 4, 1)[:, :2 * z2]                       # (B, 2*z2, Y, X, C), a view
     planes = rows.reshape(b * 2 * z2, y, xx, c).permute(0, 3, 1, 2)    # (B*Z, C, Y, X) channels-last

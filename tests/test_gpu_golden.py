@@ -140,3 +140,29 @@ def test_ponder_indoor_full_size_config0_vs_reference(device):
     importance sampler's bin indices bit-exact, gradient probes from the variance network back to
     the backbone's stem."""
     _check_full_size(*gc.run_ponder_indoor_cfg0(device))
+
+
+@pytest.mark.parametrize("condition_index", [0, 1, 2])
+def test_ponder_ppt_full_size_vs_reference(device, condition_index):
+    """BASELINE.json configs[3] at FULL size: the shipped multi-dataset model (SpUNet-v1m3 PDNorm
+    32..256 channels, (2,3,4,6,2,2,2,2) blocks, 128x128x32 grid, UNet3D-v1m2, NeuS head, 2 scenes x
+    512 rays), one batch per condition, against the reference's own step: losses and rendered
+    RGB-D to 1e-4, sampler bins bit-exact, every gradient against the float64 record."""
+    _check_full_size(*gc.run_ponder_ppt_full(device, condition_index))
+
+
+def test_ponder_outdoor_full_size_vs_reference(device):
+    """BASELINE.json configs[4] at FULL size, one lidar sweep: the reference's nuScenes model
+    section unchanged (1080 x 1080 x 80 voxel range, 180 x 180 x 5 grid, SimpleConv3D, 16-wide
+    five-block SDF MLP, 72 + 24 samples, 6 x 512 rays, mask ratio 0.8)."""
+    errs = gc.run_ponder_outdoor_full(device)
+    f64 = errs.pop("float64")
+    print(errs, "float64 gradient record", f64)
+    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
+    assert max(losses.values()) < 1e-4, errs
+    head = {k: v for k, v in errs.items() if k.startswith(("grad_renderer", "grad_proj_net"))}
+    assert max(head.values()) < 1e-3, errs
+    deep = {k: v for k, v in errs.items() if k.startswith(("grad_backbone", "grad_mtoken"))}
+    assert max(deep.values()) < 6e-2, errs
+    assert f64["tensors"] > 200
+    assert f64["global_rel"] < 1e-3 and f64["backbone_rel"] < 1e-3, f64

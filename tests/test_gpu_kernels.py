@@ -684,3 +684,29 @@ def test_pointwise_conv_equals_the_library_conv(device, shape, c_in, c_out, bias
     assert rel(conv.weight.grad, conv64.weight.grad) < 2e-5     # sums over up to 524 288 rows
     if bias:
         assert rel(conv.bias.grad, conv64.bias.grad) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 12, 16), (1, 64, 5, 7, 9), (2, 128, 4, 4, 4)])
+def test_channels_last_max_pool_kernels_equal_max_pool3d(device, shape):
+    """csrc/dense_pool.hip against F.max_pool3d(x, 2): values and gradients EQUAL, also where a
+    window holds several equal maxima (zeros after a ReLU: the first in window order gets the
+    gradient on both sides), odd extents floored, layout kept channels-last."""
+    import torch.nn.functional as F
+
+    from ponderv2_amd.ponder.models.ponder.unet3d import _MaxPoolCL, channels_last_max_pool3d
+
+    torch.manual_seed(0)
+    for relu in (False, True):
+        x = torch.randn(*shape, device=device)
+        if relu:
+            x = x.relu()
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        got, ref = channels_last_max_pool3d(a), F.max_pool3d(b, 2)
+        assert isinstance(got.grad_fn, _MaxPoolCL._backward_cls)
+        assert torch.equal(got, ref) and got.is_contiguous(memory_format=torch.channels_last_3d)
+        probe = torch.randn_like(ref)
+        (got * probe).sum().backward()
+        (ref * probe).sum().backward()
+        assert torch.equal(a.grad, b.grad)
