@@ -160,6 +160,12 @@ def parse():
                     help="config file to take the model / optimizer / scheduler sections from "
                          "(default: the repository's synthetic-data config of the workload; the "
                          "reference's own config file works unchanged)")
+    ap.add_argument("--raw-points", action="store_true",
+                    help="indoor / ppt: the batches hold RAW (dropout-thinned) points; every timed step "
+                         "voxelises its batch on the device first (datasets.voxelize.device_grid_sample: "
+                         "hash, sort, one representative per voxel - the device half of the "
+                         "reference's GridSample) and picks the ray pixels, i.e. the input pipeline "
+                         "the reference leaves to its dataloader workers is INSIDE the timed region")
     ap.add_argument("--launch-check", action="store_true",
                     help="only exercise the rank spawning / process group / rank-0 reporting path "
                          "(no model, works without a GPU over gloo); prints a JSON line saying so")
@@ -615,10 +621,10 @@ class KernelTimer:
         return "\n".join(lines)
 
 
-def make_batch(rank, scenes, views, device):
+def make_batch(rank, scenes, views, device, voxelize=True):
     from ponderv2_amd.ponder.datasets import collate_fn, make_scene
 
-    samples = [make_scene(1000 * rank + i, num_views=views, image_hw=(480, 640))
+    samples = [make_scene(1000 * rank + i, num_views=views, image_hw=(480, 640), voxelize=voxelize)
                for i in range(scenes)]
     batch = collate_fn(samples)
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -760,7 +766,7 @@ def main():
     if outdoor:
         batch = make_outdoor_batch(rank, args.scenes_per_gpu, args.rays_per_camera, device)
     else:
-        batch = make_batch(rank, args.scenes_per_gpu, args.views, device)
+        batch = make_batch(rank, args.scenes_per_gpu, args.views, device, voxelize=not args.raw_points)
     n_vox = int(batch["offset"][-1])
     batches, counter = [batch], [0]
     if ppt:  # one resident batch per condition, visited in the loader's 4:2:1 order
@@ -783,6 +789,12 @@ def main():
 
     def stage(i):
         b = clone_batch(batches[i % len(batches)])
+        if args.raw_points and "grid_coord" not in b:
+            # the device half of the input pipeline, inside the timed region: GridSample of the raw
+            # points (same voxels and order as the host transform, tests/test_gpu_voxelize.py)
+            from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample
+
+            b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
         return raw_model.prefetch(b) if lookahead else b
 
     staged = [stage(0)]
@@ -906,7 +918,11 @@ def main():
                                      f"bs={args.scenes_per_gpu}/GPU, {rays_per_scene} rays/scene, "
                                      "train step fwd+bwd+SGD")),
                        "scenes_per_gpu": args.scenes_per_gpu, "rays_per_scene": rays_per_scene,
-                       "voxels_per_gpu": n_vox, "parallelism": f"dp{world}"},
+                       ("raw_points_per_gpu" if args.raw_points else "voxels_per_gpu"): n_vox,
+                       "input_pipeline": ("device voxelisation (GridSample on the GPU) + ray pixel choice "
+                                          "inside the timed step" if args.raw_points else
+                                          "voxelised batches resident in HBM; ray pixel choice inside the step"),
+                       "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
             "backward_side_stream": side_state,
             "render_head": (("fused ray-march kernels (csrc/raymarch_fused.hip)"

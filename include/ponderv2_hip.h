@@ -317,6 +317,60 @@ int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, co
                                  float* grad_weight, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The sparse U-Net as ONE call per direction (csrc/spunet_exec.hip): SpUNetBase.forward
+ * (ponder/models/sparse_unet/spconv_unet_v1m1_base.py:242-278 - conv_input, 4 x (down + residual
+ * blocks), 4 x (up + skip concat + residual blocks)) and its autograd graph as a flat array of
+ * records walked natively, instead of a Python call + autograd node per module.  The caller owns
+ * every buffer (arenas carved by the host code) and fills the pointers; sizes are host values.
+ *   PV2_UNET_CONV_BN  conv -> BatchNorm1d -> (+ residual) -> ReLU on the product-row path: exactly
+ *                     pv2_convbn_forward / pv2_convbn_backward with this record's fields.
+ *   PV2_UNET_STEM     the 125-offset stem: pv2_spconv_os_forward over (nbr, nbr_stride, kflip) +
+ *                     pv2_bn_forward; backward: pv2_bn_backward + the deterministic weight gradient
+ *                     (geom's pair lists; no grad-input).
+ *   PV2_UNET_CONCAT   out[n_out, c_in + c_out] = [x | residual] (the decoder's skip concat);
+ *                     backward: dx = grad_out[:, :c_in], dres (+)= grad_out[:, c_in:].
+ * forward fields : x, residual (or NULL), weight, bn_weight, bn_bias, running_mean / _var, eps,
+ *                  momentum, relu -> y_conv, mean_invstd, out.
+ * backward fields: grad_out (complete when the record is reached: records run last to first) ->
+ *                  gsum, dy (scratch, kept until the side stream has joined), dres (or NULL), dx (or
+ *                  NULL; dx_accumulate != 0: ADD to what dx holds - an earlier record wrote this
+ *                  activation's gradient first; for CONCAT the flag applies to dres), dweight.
+ * Workspaces as for pv2_convbn_*: prod_ws >= max pairs x channels floats, stats_ws =
+ * pv2_bn_workspace_floats(max channels), part_ws the weight gradient's partial sums (side stream).
+ * ------------------------------------------------------------------------------------------ */
+#define PV2_UNET_CONV_BN 0
+#define PV2_UNET_STEM 1
+#define PV2_UNET_CONCAT 2
+typedef struct pv2_unet_op {
+  int32_t kind, c_in, c_out, relu;
+  int32_t K, kflip, dx_accumulate, reserved;
+  int64_t n_in, n_out, nbr_stride;
+  const pv2_conv_geom* geom;
+  const int32_t* nbr;
+  const float* x;
+  const float* residual;
+  const float* weight;
+  const float* bn_weight;
+  const float* bn_bias;
+  float* running_mean;
+  float* running_var;
+  float* y_conv;
+  float* mean_invstd;
+  float* out;
+  const float* grad_out;
+  float* dy;
+  float* gsum;
+  float* dres;
+  float* dx;
+  float* dweight;
+  float eps, momentum;
+} pv2_unet_op;
+int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                     pv2_stream_t stream);
+int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                      float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream);
+
+/* ------------------------------------------------------------------------------------------
  * 2 x 2 x 2 max-pooling of a channels-last dense grid x[B, Z, Y, X, C] -> y[B, Z/2, Y/2, X/2, C]
  * (floor sizes, no padding): nn.MaxPool3d(kernel_size=2) of the projection network's encoders
  * (ponder/models/ponder/unet3d.py:326-330) without ATen's transposes through NCDHW.  idx: one

@@ -122,19 +122,32 @@ def float64_gradient_record(model, batch, rec, post=None):
     with Replay(rec), _EverythingDouble():
         out = m64(inp)
     out["loss"].backward()
+    names, norms, projs = _gradient_projections(m64)
+    # the SAME record of the reference's own fp32 pass (``model`` still holds its gradients): how far
+    # fp32 arithmetic alone moves these gradients - the yardstick for the GPU's fp32 gradients
+    names32, norms32, projs32 = _gradient_projections(model)
+    assert names32 == names
+    e2 = ((np.array(projs32) - np.array(projs)) ** 2).mean(1)
+    print("   float64 reference pass: %.1f s, %d parameters with gradients, loss %.9f; the reference's "
+          "fp32 gradients differ from it by %.3e (global relative, estimated from %d projections)"
+          % (time.perf_counter() - t0, len(names), float(out["loss"]),
+             (e2.sum() / (np.array(norms) ** 2).sum()) ** 0.5, GRAD_PROBES))
+    return dict(g64_names=np.array(names), g64_norm=np.array(norms), g64_proj=np.array(projs),
+                g32_norm=np.array(norms32), g32_proj=np.array(projs32),
+                out64_names=np.array(list(out.keys())),
+                out64_values=np.array([float(v) for v in out.values()]))
+
+
+def _gradient_projections(model):
     names, norms, projs = [], [], []
-    for name, p in m64.named_parameters():
+    for name, p in model.named_parameters():
         if p.grad is None:
             continue
         g = p.grad.double()
         names.append(name)
         norms.append(float(g.norm()))
         projs.append([float((g * grad_probe(name, i, g.shape).double()).sum()) for i in range(GRAD_PROBES)])
-    print("   float64 reference pass: %.1f s, %d parameters with gradients, loss %.9f"
-          % (time.perf_counter() - t0, len(names), float(out["loss"])))
-    return dict(g64_names=np.array(names), g64_norm=np.array(norms), g64_proj=np.array(projs),
-                out64_names=np.array(list(out.keys())),
-                out64_values=np.array([float(v) for v in out.values()]))
+    return names, norms, projs
 
 
 def spunet_case():

@@ -29,6 +29,21 @@ class ConvGeom(Structure):
                                            "tile_start_w", "pos_out", "pos_in")])
 
 
+class UnetOp(Structure):
+    """pv2_unet_op: one record of the natively executed sparse U-Net (csrc/spunet_exec.hip)."""
+    _fields_ = ([(k, c_int32) for k in ("kind", "c_in", "c_out", "relu", "K", "kflip",
+                                       "dx_accumulate", "reserved")]
+                + [(k, c_int64) for k in ("n_in", "n_out", "nbr_stride")]
+                + [("geom", POINTER(ConvGeom))]
+                + [(k, c_void_p) for k in ("nbr", "x", "residual", "weight", "bn_weight", "bn_bias",
+                                           "running_mean", "running_var", "y_conv", "mean_invstd",
+                                           "out", "grad_out", "dy", "gsum", "dres", "dx", "dweight")]
+                + [("eps", c_float), ("momentum", c_float)])
+
+
+UNET_CONV_BN, UNET_STEM, UNET_CONCAT = 0, 1, 2
+
+
 class PointsDesc(Structure):
     _fields_ = [(k, c_int64) for k in ("n_points", "points_per_n", "o_sn", "o_sc", "o_sp")]
 
@@ -89,6 +104,8 @@ SIGNATURES = {
     "pv2_convbn_backward": (
         c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                 _P, _P, _P, _P]),
+    "pv2_unet_forward": (c_int, [POINTER(UnetOp), c_int, _P, _P, _P]),
+    "pv2_unet_backward": (c_int, [POINTER(UnetOp), c_int, _P, _P, _P, _P, _P]),
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_bn_workspace_floats": (c_int64, [c_int]),

@@ -52,6 +52,13 @@ int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout
                  int c_out, int K, const int32_t* pair_in, const int32_t* pair_out,
                  const int32_t* kstart, const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
                  float* dweight, float* part, hipStream_t s);
+// sparse_conv_pr.hip
+int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
+                    const float* weight, int c_out, const float* y_conv, const float* out_or_null,
+                    const float* mean_invstd, const float* bn_weight, float* prod_ws,
+                    float* stats_ws, float* gsum, float* dy, float* dres_or_null, float* dx_or_null,
+                    int dx_accumulate, float* dweight_or_null, float* part_ws, hipStream_t s,
+                    hipStream_t side);
 // rownorm.hip: the statistics kernels' partial-sum geometry (blocks <= 1024, rows per block) and the
 // second half of the fused BatchNorm forward - combine the per-block partial sums (written by
 // col_partials or by row_reduce_kernel's epilogue, shifted by row 0 of x) and apply.

@@ -72,7 +72,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 template <int TS, int NJ>
 __device__ __forceinline__ void sum_row(const float4* __restrict__ T4, int c4n,
                                         const int* __restrict__ list, int cnt,
-                                        const float4* __restrict__ init_row,
+                                        const float4* init_row,
                                         const float4* __restrict__ bias4, int l,
                                         float4 (&acc)[NJ]) {
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,7 +155,7 @@ template <int TS, int NJ, bool STATS>
 __global__ __launch_bounds__(256) void row_reduce_kernel(
     const float* __restrict__ T, const int32_t* __restrict__ pos, int64_t pos_stride, int K, int c,
     int64_t n_rows, int64_t rows_per_block, const float* __restrict__ bias,
-    const float* __restrict__ addend, float* __restrict__ Y, float* __restrict__ partial) {
+    const float* addend, float* Y, float* __restrict__ partial) {
   constexpr int NT = 256 / TS;
   __shared__ int s_raw[kMaxK * kRows];
   __shared__ int s_list[kRows * kListLd];
@@ -311,6 +311,46 @@ hipEvent_t fork_event() {
 
 }  // namespace
 
+namespace pv2 {
+
+// Backward of one conv + BatchNorm unit (the body of pv2_convbn_backward).  dx_accumulate: the
+// grad-input is ADDED to what dx already holds (another consumer of the same activation wrote its
+// gradient first) - the row-reduce kernel takes dx as its addend, element for element in place.
+int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
+                    const float* weight, int c_out, const float* y_conv, const float* out_or_null,
+                    const float* mean_invstd, const float* bn_weight, float* prod_ws,
+                    float* stats_ws, float* gsum, float* dy, float* dres_or_null, float* dx_or_null,
+                    int dx_accumulate, float* dweight_or_null, float* part_ws, hipStream_t s,
+                    hipStream_t side) {
+  PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_backward: needs at least two output rows");
+  if (int e = pv2_bn_backward(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, g->n_out, c_out,
+                              stats_ws, gsum, dy, dres_or_null, (pv2_stream_t)s))
+    return e;
+  if (dweight_or_null) {
+    if (side != s) {  // the weight gradient feeds nothing until the optimizer: off the critical chain
+      hipEvent_t ev = fork_event();
+      if (int e = pv2::hip_status(hipEventRecord(ev, s))) return e;
+      if (int e = pv2::hip_status(hipStreamWaitEvent(side, ev, 0))) return e;
+    }
+    if (int e = pv2::spconv_wgrad(x, g->n_in, c_in, dy, g->n_out, c_out, g->K, g->pair_in,
+                                  g->pair_out, g->kstart, g->tile_start_w, g->tile_pairs_w,
+                                  g->n_tiles_w, dweight_or_null, part_ws, side))
+      return e;
+  }
+  if (dx_or_null) {
+    // grad-input: the same two stages with the pair roles swapped, forward weight read in place
+    if (int e = pv2::spconv_products(true, dy, c_out, weight, g->K, c_in, g->pair_out, g->kstart,
+                                     g->tile_start, g->n_tiles, prod_ws, s))
+      return e;
+    if (int e = reduce_rows(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
+                            dx_accumulate ? dx_or_null : nullptr, dx_or_null, nullptr, nullptr, s))
+      return e;
+  }
+  return PV2_OK;
+}
+
+}  // namespace pv2
+
 extern "C" {
 
 int pv2_pair_positions(const int32_t* pair_out, const int32_t* pair_in, const int32_t* kstart, int K,
@@ -371,33 +411,10 @@ int pv2_convbn_backward(const pv2_conv_geom* g, const float* grad_out, const flo
                         float* prod_ws, float* stats_ws, float* gsum, float* dy,
                         float* dres_or_null, float* dx_or_null, float* dweight_or_null,
                         float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream) {
-  PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_backward: needs at least two output rows");
-  hipStream_t s = (hipStream_t)stream;
-  hipStream_t side = side_stream ? (hipStream_t)side_stream : s;
-  if (int e = pv2_bn_backward(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, g->n_out, c_out,
-                              stats_ws, gsum, dy, dres_or_null, stream))
-    return e;
-  if (dweight_or_null) {
-    if (side != s) {  // the weight gradient feeds nothing until the optimizer: off the critical chain
-      hipEvent_t ev = fork_event();
-      if (int e = pv2::hip_status(hipEventRecord(ev, s))) return e;
-      if (int e = pv2::hip_status(hipStreamWaitEvent(side, ev, 0))) return e;
-    }
-    if (int e = pv2::spconv_wgrad(x, g->n_in, c_in, dy, g->n_out, c_out, g->K, g->pair_in,
-                                  g->pair_out, g->kstart, g->tile_start_w, g->tile_pairs_w,
-                                  g->n_tiles_w, dweight_or_null, part_ws, side))
-      return e;
-  }
-  if (dx_or_null) {
-    // grad-input: the same two stages with the pair roles swapped, forward weight read in place
-    if (int e = pv2::spconv_products(true, dy, c_out, weight, g->K, c_in, g->pair_out, g->kstart,
-                                     g->tile_start, g->n_tiles, prod_ws, s))
-      return e;
-    if (int e = reduce_rows(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
-                            nullptr, dx_or_null, nullptr, nullptr, s))
-      return e;
-  }
-  return PV2_OK;
+  return pv2::convbn_backward(g, grad_out, x, c_in, weight, c_out, y_conv, out_or_null, mean_invstd,
+                              bn_weight, prod_ws, stats_ws, gsum, dy, dres_or_null, dx_or_null, 0,
+                              dweight_or_null, part_ws, (hipStream_t)stream,
+                              side_stream ? (hipStream_t)side_stream : (hipStream_t)stream);
 }
 
 }  // extern "C"

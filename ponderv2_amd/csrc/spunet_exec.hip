@@ -1,0 +1,145 @@
+// The sparse U-Net's forward and backward pass as ONE native call each: a flat list of conv +
+// BatchNorm units and skip concatenations, walked in C++.
+//
+// Stands in for the module-by-module execution of SpUNetBase.forward
+// (ponder/models/sparse_unet/spconv_unet_v1m1_base.py:242-278: conv_input, 4 x (down + residual
+// blocks), 4 x (up + skip concat + residual blocks)) and of its autograd graph.  The reference pays
+// a Python call, an autograd node and a handful of launches per module and direction; on MI355X
+// that made the training step HOST-bound (~10 ms of the 27 ms the host needs to enqueue a step
+// were spent walking the backbone).  Here Python hands over an array of `pv2_unet_op` records
+// (device pointers into arenas it allocated, host sizes); this file launches the same kernels the
+// per-unit entry points launch (pv2_convbn_forward / _backward, sparse_conv_pr.hip), ~4 us each.
+//
+// Gradient bookkeeping is static: every activation has at most three consumers (conv, shortcut,
+// skip), visited in reverse order; the FIRST gradient to arrive is written, later ones are added
+// by the row-reduce kernel's addend input (`dx_accumulate`) - no zero-fills, no separate add
+// kernels, fixed order.  Weight gradients go to the side stream behind one event per unit.
+#include "common.h"
+
+namespace {
+
+// out[r, :] = [a[r, :ca] | b[r, :cb]]   (16-byte pieces; ca % 4 == 0, cb % 4 == 0)
+__global__ __launch_bounds__(256) void concat_rows_kernel(const float4* __restrict__ a, int ca4,
+                                                          const float4* __restrict__ b, int cb4,
+                                                          int64_t n, float4* __restrict__ out) {
+  const int c4 = ca4 + cb4;
+  const int64_t total = n * c4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / c4;
+    const int c = (int)(e - r * c4);
+    out[e] = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+  }
+}
+
+// ga[r, :] = g[r, :ca], gb[r, :] (+)= g[r, ca:]
+__global__ __launch_bounds__(256) void split_rows_kernel(const float4* __restrict__ g, int ca4,
+                                                         int cb4, int64_t n, float4* __restrict__ ga,
+                                                         float4* __restrict__ gb, int accumulate_b) {
+  const int c4 = ca4 + cb4;
+  const int64_t total = n * c4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / c4;
+    const int c = (int)(e - r * c4);
+    const float4 v = g[e];
+    if (c < ca4) {
+      ga[r * ca4 + c] = v;
+    } else {
+      float4* dst = gb + r * cb4 + (c - ca4);
+      if (accumulate_b) {
+        const float4 o = *dst;
+        *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+      } else {
+        *dst = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                     pv2_stream_t stream) {
+  PV2_REQUIRE(ops != nullptr && n_ops >= 0, "pv2_unet_forward: bad plan");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_ops; ++i) {
+    const pv2_unet_op& u = ops[i];
+    int e = PV2_OK;
+    switch (u.kind) {
+      case PV2_UNET_CONV_BN:
+        e = pv2_convbn_forward(u.geom, u.x, u.c_in, u.weight, u.c_out, u.bn_weight, u.bn_bias,
+                               u.residual, u.relu, u.eps, u.momentum, u.running_mean, u.running_var,
+                               prod_ws, stats_ws, u.y_conv, u.mean_invstd, u.out, stream);
+        break;
+      case PV2_UNET_STEM:
+        e = pv2_spconv_os_forward(u.x, u.n_in, u.c_in, u.weight, u.K, u.c_out, u.nbr, u.nbr_stride,
+                                  nullptr, u.kflip, nullptr, u.y_conv, u.n_out, stream);
+        if (e == PV2_OK)
+          e = pv2_bn_forward(u.y_conv, u.n_out, u.c_out, u.bn_weight, u.bn_bias, u.residual, u.relu,
+                             u.eps, u.momentum, u.running_mean, u.running_var, stats_ws,
+                             u.mean_invstd, u.out, stream);
+        break;
+      case PV2_UNET_CONCAT:
+        PV2_REQUIRE((u.c_in % 4) == 0 && (u.c_out % 4) == 0, "pv2_unet_forward: concat widths % 4");
+        if (u.n_out > 0)
+          hipLaunchKernelGGL(concat_rows_kernel,
+                             dim3(pv2::grid_for(u.n_out * ((u.c_in + u.c_out) / 4), 256)), dim3(256),
+                             0, s, (const float4*)u.x, u.c_in / 4, (const float4*)u.residual,
+                             u.c_out / 4, u.n_out, (float4*)u.out);
+        e = pv2::check_launch("unet_concat");
+        break;
+      default:
+        pv2::set_error("pv2_unet_forward: unknown op kind");
+        return PV2_E_BADARG;
+    }
+    if (e != PV2_OK) return e;
+  }
+  return PV2_OK;
+}
+
+int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                      float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream) {
+  PV2_REQUIRE(ops != nullptr && n_ops >= 0, "pv2_unet_backward: bad plan");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const pv2_unet_op& u = ops[i];
+    int e = PV2_OK;
+    switch (u.kind) {
+      case PV2_UNET_CONV_BN:
+        e = pv2::convbn_backward(u.geom, u.grad_out, u.x, u.c_in, u.weight, u.c_out, u.y_conv,
+                                 u.relu ? u.out : nullptr, u.mean_invstd, u.bn_weight, prod_ws,
+                                 stats_ws, u.gsum, u.dy, u.dres, u.dx, u.dx_accumulate, u.dweight,
+                                 part_ws, s, side_stream ? (hipStream_t)side_stream : s);
+        break;
+      case PV2_UNET_STEM: {
+        // (the stem is the last unit of the backward pass: the product-row workspace is free and
+        // serves as the weight gradient's partial-sum buffer, on the caller's stream)
+        e = pv2_bn_backward(u.grad_out, u.y_conv, u.relu ? u.out : nullptr, u.mean_invstd,
+                            u.bn_weight, u.n_out, u.c_out, stats_ws, u.gsum, u.dy, u.dres, stream);
+        if (e == PV2_OK && u.dweight)
+          e = pv2::spconv_wgrad(u.x, u.n_in, u.c_in, u.dy, u.n_out, u.c_out, u.K, u.geom->pair_in,
+                                u.geom->pair_out, u.geom->kstart, u.geom->tile_start_w,
+                                u.geom->tile_pairs_w, u.geom->n_tiles_w, u.dweight, prod_ws, s);
+        break;
+      }
+      case PV2_UNET_CONCAT:
+        if (u.n_out > 0)
+          hipLaunchKernelGGL(split_rows_kernel,
+                             dim3(pv2::grid_for(u.n_out * ((u.c_in + u.c_out) / 4), 256)), dim3(256),
+                             0, s, (const float4*)u.grad_out, u.c_in / 4, u.c_out / 4, u.n_out,
+                             (float4*)u.dx, (float4*)u.dres, u.dx_accumulate);
+        e = pv2::check_launch("unet_split");
+        break;
+      default:
+        pv2::set_error("pv2_unet_backward: unknown op kind");
+        return PV2_E_BADARG;
+    }
+    if (e != PV2_OK) return e;
+  }
+  return PV2_OK;
+}
+
+}  // extern "C"

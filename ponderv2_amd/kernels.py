@@ -250,20 +250,24 @@ class Rulebook:
                 self._pos = (pos_out, so, pos_in, si)
         return self._pos
 
-    def geom(self, c_in: int, c_out: int):
+    def geom(self, c_in: int, c_out: int, positions: bool = True):
         """The rulebook as the pv2_conv_geom struct of the fused conv + BatchNorm entry points
-        (cached per weight-gradient chunk size; holds raw pointers into this rulebook's tensors)."""
+        (cached per weight-gradient chunk size; holds raw pointers into this rulebook's tensors).
+        ``positions=False``: without the position tables (users that only need the pair lists and
+        tile prefixes - the 125-offset stem's weight gradient)."""
         tile_w = int(_lib.lib().pv2_spconv_wgrad_tile(c_in, c_out, self.n_pairs, self.K))
-        g = self._geoms.get(tile_w)
+        key = (tile_w, positions)
+        g = self._geoms.get(key)
         if g is None:
-            pos_out, so, pos_in, si = self.positions()
+            pos_out, so, pos_in, si = self.positions() if positions else (None, 0, None, 0)
             ts, n_tiles, _ = self.tiles(FWD_LDS_TILE)
             tsw, n_tiles_w, _ = self.tiles(tile_w)
             g = _lib.ConvGeom(self.K, tile_w, self.n_in, self.n_out, n_tiles, n_tiles_w, so, si,
                               self.pair_in.data_ptr(), self.pair_out.data_ptr(),
                               self.kstart.data_ptr(), ts.data_ptr(), tsw.data_ptr(),
-                              pos_out.data_ptr(), pos_in.data_ptr())
-            self._geoms[tile_w] = g
+                              pos_out.data_ptr() if positions else None,
+                              pos_in.data_ptr() if positions else None)
+            self._geoms[key] = g
         return g
 
 

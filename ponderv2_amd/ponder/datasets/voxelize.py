@@ -154,10 +154,13 @@ def device_grid_sample(batch, grid_size=0.02, hash_type="fnv", keys=("coord", "f
         new_ends.append((new_ends[-1] if new_ends else 0) + int(idx.numel()))
         start = end
     res = dict(batch)
-    res.pop("sparse_shape", None)   # the voxel set changed: the backbone derives it again
     for k, parts in out.items():
         res[k] = torch.cat(parts)
     res["grid_coord"] = torch.cat(grids)
+    # the backbone's spatial shape (max grid coordinate + 96, spconv_unet_v1m1_base.py:248 of the
+    # reference) read here, where the voxel counts are read anyway: the model then needs no
+    # device->host read of its own and the geometry can be prefetched a batch ahead
+    res["sparse_shape"] = torch.add(res["grid_coord"].amax(0), 96).tolist()
     res["offset"] = torch.tensor(new_ends, dtype=batch["offset"].dtype).to(batch["offset"].device)
     if "offset_host" in batch:
         res["offset_host"] = list(new_ends)

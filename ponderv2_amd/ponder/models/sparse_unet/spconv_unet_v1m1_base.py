@@ -11,6 +11,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from ponderv2_amd import spunet_native
 from ponderv2_amd.rownorm import fused_bn
 from ponderv2_amd.spconv import pytorch as spconv
 from ..builder import MODELS
@@ -157,18 +158,24 @@ class SpUNetBase(nn.Module):
             spatial_shape=sparse_shape, batch_size=offset.numel(),
             indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape,
                                        input_dict.get("geometry")))
-        x = self.conv_input(x)
-        skips = [x]
-        for s in range(self.num_stages):
-            x = self.enc[s](self.down[s](x))
-            skips.append(x)
-        x = skips.pop(-1)
-        if not self.cls_mode:
-            for s in reversed(range(self.num_stages)):
-                x = self.up[s](x)
-                skip = skips.pop(-1)
-                x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
-                x = self.dec[s](x)
+        # the whole U-Net as one native call per direction where the plan covers it
+        # (ponderv2_amd/spunet_native.py); module by module otherwise
+        native = spunet_native.run(self, x) if feat.is_cuda else None
+        if native is not None:
+            x = x.replace_feature(native)
+        else:
+            x = self.conv_input(x)
+            skips = [x]
+            for s in range(self.num_stages):
+                x = self.enc[s](self.down[s](x))
+                skips.append(x)
+            x = skips.pop(-1)
+            if not self.cls_mode:
+                for s in reversed(range(self.num_stages)):
+                    x = self.up[s](x)
+                    skip = skips.pop(-1)
+                    x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
+                    x = self.dec[s](x)
         x = self.final(x)
         if self.cls_mode:
             b = x.indices[:, 0].long()

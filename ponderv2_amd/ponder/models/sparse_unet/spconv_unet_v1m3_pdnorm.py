@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ponderv2_amd import spunet_native
 from ponderv2_amd.rownorm import can_fuse, fused_bn
 from ponderv2_amd.spconv import pytorch as spconv
 from ..builder import MODELS
@@ -311,19 +312,23 @@ class SpUNetBase(nn.Module):
             spatial_shape=sparse_shape, batch_size=offset.numel(),
             indice_dict=self._geometry(feat, batch, grid_coord, sparse_shape,
                                        input_dict.get("geometry")))
-        x = self.conv_input([x, condition, context])
-        skips = [x]
-        for s in range(self.num_stages):
-            x = self.down[s]([x, condition, context])
-            x, _, _ = self.enc[s]([x, condition, context])
-            skips.append(x)
-        x = skips.pop(-1)
-        if not self.cls_mode:
-            for s in reversed(range(self.num_stages)):
-                x = self.up[s]([x, condition, context])
-                skip = skips.pop(-1)
-                x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
-                x, _, _ = self.dec[s]([x, condition, context])
+        native = spunet_native.run(self, x, condition, context) if feat.is_cuda else None
+        if native is not None:   # one native call per direction (ponderv2_amd/spunet_native.py)
+            x = x.replace_feature(native)
+        else:
+            x = self.conv_input([x, condition, context])
+            skips = [x]
+            for s in range(self.num_stages):
+                x = self.down[s]([x, condition, context])
+                x, _, _ = self.enc[s]([x, condition, context])
+                skips.append(x)
+            x = skips.pop(-1)
+            if not self.cls_mode:
+                for s in reversed(range(self.num_stages)):
+                    x = self.up[s]([x, condition, context])
+                    skip = skips.pop(-1)
+                    x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
+                    x, _, _ = self.dec[s]([x, condition, context])
         x = self.final(x)
         if self.cls_mode:
             b = x.indices[:, 0].long()

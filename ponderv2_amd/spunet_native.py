@@ -1,0 +1,389 @@
+"""SpUNet's forward and backward pass as one native call each (csrc/spunet_exec.hip).
+
+``SpUNetBase.forward`` of the reference (ponder/models/sparse_unet/spconv_unet_v1m1_base.py:242-278)
+walks ~60 conv + BatchNorm modules in Python; every one of them costs a Python call, an autograd
+node and ~5 small launches per direction, and on MI355X the training step was HOST-bound on exactly
+that (the host needed ~27 ms to enqueue a 28.9 ms step, ~10 ms of it inside the backbone).  Here the
+walk happens once per forward to build a flat plan - one ``pv2_unet_op`` record per unit or skip
+concatenation, with pointers into two arenas (activations; gradients) - and the launches happen in
+C++ (``pv2_unet_forward`` / ``pv2_unet_backward``), ~4 us each.  One autograd node stands for the
+whole backbone: its inputs are the stem's (padded) input features and every unit's weight and
+BatchNorm affine pair, its output the backbone's output features.
+
+Same kernels, same order, same numbers as the per-unit path (convbn.py) up to the order in which the
+gradients of an activation with several consumers are added - here inside the grad-input row reduce
+(its addend), there by autograd's add kernels.  Anything the plan cannot express takes the modular
+path: eval mode, 16-bit activations, units the product-row path does not cover (channel counts that
+are no multiples of 32), inputs that need a gradient.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, kernels as K, precision, rownorm, sidestream
+from ._lib import UNET_CONCAT, UNET_CONV_BN, UNET_STEM, UnetOp
+
+ENABLED = os.environ.get("PV2_NATIVE_UNET", "1") != "0"
+CALLS = 0     # forward passes that ran natively (tests assert the path is the one being measured)
+_ALIGN = 64   # floats: every carved buffer starts on a 256-byte boundary
+
+
+class _Arena:
+    """Bump allocator over one device tensor (sizes in floats are collected first)."""
+
+    def __init__(self):
+        self.size = 0
+        self.base = 0
+        self.tensor = None
+
+    def reserve(self, floats):
+        off = self.size
+        self.size += (int(floats) + _ALIGN - 1) // _ALIGN * _ALIGN
+        return off
+
+    def allocate(self, device):
+        self.tensor = torch.empty(max(self.size, 1), dtype=torch.float32, device=device)
+        self.base = self.tensor.data_ptr()
+
+    def ptr(self, off):
+        return self.base + 4 * off
+
+    def view(self, off, *shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.tensor[off:off + n].view(*shape)
+
+
+class _Unit:
+    __slots__ = ("kind", "conv", "bn", "rb", "geom", "geom_ptr", "c_in", "c_out", "relu", "src", "dst",
+                 "res", "w_index", "affine", "n_in", "n_out", "y_off", "mi_off", "dy_off", "gsum_off",
+                 "dw_off", "acc_dx", "acc_res", "K")
+
+
+class Plan:
+    """The flat description of one forward pass: units, activation table, arenas."""
+
+    def __init__(self):
+        self.units = []
+        self.acts = []        # (rows, channels) per activation id; id 0 = the stem's input
+        self.tensors = []     # autograd inputs after the features: per unit weight, bn weight, bn bias
+        self.fwd = _Arena()
+        self.act_off = []
+        self.ops = None
+
+    def act(self, rows, channels):
+        self.acts.append((rows, channels))
+        return len(self.acts) - 1
+
+
+def _bn_and_affine(norm, condition, context):
+    """(nn.BatchNorm1d, weight, bias) of a plain BatchNorm1d or a PDBatchNorm (whose effective
+    affine pair for this forward comes from ``SpUNetBase._prepare_modulation``); None when the
+    layer's affine pair is not available in that form."""
+    if isinstance(norm, nn.BatchNorm1d):
+        return (norm, norm.weight, norm.bias) if norm.affine else None
+    bn = norm.bns[norm.conditions.index(condition)] if norm.decouple else norm.bn
+    if not norm.adaptive:
+        return (bn, bn.weight, bn.bias) if bn.affine else None
+    pairs = getattr(context, "pairs", None)
+    if pairs is None or norm not in pairs:
+        return None
+    weight, bias = pairs[norm]
+    return bn, weight.float().contiguous(), bias.float().contiguous()
+
+
+def _plannable_conv(conv, bn, rb):
+    return (conv.bias is None and K._use_pr(rb, conv.in_channels, conv.out_channels)
+            and conv.out_channels % 32 == 0 and rb.n_out > 1 and rb.n_in > 0 and bn.training
+            and bn.momentum is not None and type(bn) is nn.BatchNorm1d)
+
+
+def build_plan(model, x, condition=None, context=None):
+    """Plan of ``model`` (SpUNet-v1m1 / -v1m3 layout) on the sparse tensor ``x`` whose
+    ``indice_dict`` holds the prebuilt geometry; None when a unit is outside what the executor covers."""
+    from .spconv import pytorch as spconv
+
+    geo = x.indice_dict
+    if not geo or "stem" not in geo:
+        return None
+    plan = Plan()
+    n0 = x.indices.shape[0]
+    level_rows = [n0] + [geo[f"spconv{l}"]["rulebook"].n_out for l in range(1, model.num_stages + 1)]
+    level_idx = [x.indices] + [geo[f"spconv{l}"]["out_indices"] for l in range(1, model.num_stages + 1)]
+    pointwise = {}
+
+    def rulebook_1x1(level):
+        if level not in pointwise:
+            pointwise[level] = K.build_subm_rulebook(level_idx[level], 1)
+        return pointwise[level]
+
+    def add_unit(conv, norm, rb, src, res=None, relu=True, kind=UNET_CONV_BN, c_in=None):
+        resolved = _bn_and_affine(norm, condition, context)
+        if resolved is None:
+            return None
+        bn, bn_weight, bn_bias = resolved
+        u = _Unit()
+        u.kind, u.conv, u.bn, u.rb, u.relu, u.src, u.res = kind, conv, bn, rb, relu, src, res
+        u.c_in = conv.in_channels if c_in is None else c_in
+        u.c_out, u.K = conv.out_channels, rb.K
+        u.n_in, u.n_out = rb.n_in, rb.n_out
+        if kind == UNET_CONV_BN and not _plannable_conv(conv, bn, rb):
+            return None
+        if kind == UNET_STEM and not (bn.training and bn.momentum is not None and type(bn) is nn.BatchNorm1d):
+            return None
+        u.affine = (bn_weight, bn_bias)
+        u.acc_dx = u.acc_res = False
+        u.dst = plan.act(u.n_out, u.c_out)
+        plan.units.append(u)
+        return u.dst
+
+    def block(b, src, rb, level):
+        # conv1 -> bn1 -> relu ; conv2 -> bn2 (+ shortcut) -> relu     (BasicBlock.forward :70-83)
+        y = add_unit(b.conv1, b.bn1, rb, src)
+        if y is None:
+            return None
+        proj_conv = getattr(b, "proj_conv", None)
+        if proj_conv is None and len(b.proj) > 1:
+            proj_conv, proj_norm = b.proj[0], b.proj[1]
+        elif proj_conv is not None:
+            proj_norm = b.proj_norm
+        if proj_conv is not None:
+            short = add_unit(proj_conv, proj_norm, rulebook_1x1(level), src, relu=False)
+            if short is None:
+                return None
+        else:
+            short = src
+        return add_unit(b.conv2, b.bn2, rb, y, res=short)
+
+    def conv_norm(m):
+        """(conv, norm) of a conv + norm + ReLU stage: SparseSequential (v1m1) or _ConvNormReLU (v1m3)."""
+        return (m.conv, m.bn) if hasattr(m, "conv") else (m[0], m[1])
+
+    # stem: 125 offsets, 6 -> 8 zero-padded input channels; output-stationary conv + BatchNorm + ReLU
+    conv, norm = conv_norm(model.conv_input)
+    stem_rb = geo["stem"]["rulebook"]
+    if conv.bias is not None or stem_rb.nbr is None or conv.out_channels % 8:
+        return None
+    c_pad = conv.in_channels + (-conv.in_channels % 8)
+    src = plan.act(n0, c_pad)
+    cur = add_unit(conv, norm, stem_rb, src, kind=UNET_STEM, c_in=c_pad)
+    if cur is None:
+        return None
+    skips = [cur]
+    for s in range(model.num_stages):
+        conv, norm = conv_norm(model.down[s])
+        cur = add_unit(conv, norm, geo[f"spconv{s + 1}"]["rulebook"], cur)
+        if cur is None:
+            return None
+        rb = geo[f"subm{s + 1}"]["rulebook"]
+        for b in model.enc[s]:
+            cur = block(b, cur, rb, s + 1)
+            if cur is None:
+                return None
+        skips.append(cur)
+    cur = skips.pop(-1)
+    for s in reversed(range(model.num_stages)):
+        conv, norm = conv_norm(model.up[s])
+        entry = geo[f"spconv{s + 1}"]
+        rbt = entry.get("rulebook_t")
+        if rbt is None:
+            rbt = entry["rulebook_t"] = entry["rulebook"].transposed()
+        up = add_unit(conv, norm, rbt, cur)
+        if up is None:
+            return None
+        skip = skips.pop(-1)
+        cat = _Unit()
+        cat.kind, cat.src, cat.res = UNET_CONCAT, up, skip
+        cat.c_in, cat.c_out = plan.acts[up][1], plan.acts[skip][1]
+        cat.n_in = cat.n_out = level_rows[s]
+        cat.relu, cat.K, cat.acc_dx, cat.acc_res = 0, 0, False, False
+        cat.dst = plan.act(level_rows[s], cat.c_in + cat.c_out)
+        plan.units.append(cat)
+        cur = cat.dst
+        rb = geo["subm0" if s == 0 else f"subm{s}"]["rulebook"]
+        for b in model.dec[s]:
+            cur = block(b, cur, rb, s)
+            if cur is None:
+                return None
+    plan.out_act = cur
+    # gradient bookkeeping: records run last to first; the first gradient of an activation is written,
+    # later ones are added.  BatchNorm's shortcut gradient (dres) has no accumulating form and is
+    # produced before the same unit's grad-input: it must be the first writer of its target.
+    seen = {plan.out_act}
+    for u in reversed(plan.units):
+        if u.kind == UNET_CONCAT:
+            u.acc_res = u.res in seen
+            if u.src in seen:
+                return None
+            seen.update((u.res, u.src))
+            continue
+        if u.res is not None:
+            if u.res in seen:
+                return None
+            seen.add(u.res)
+        if u.kind == UNET_CONV_BN:
+            u.acc_dx = u.src in seen
+            seen.add(u.src)
+    return plan
+
+
+def supported(model, x) -> bool:
+    return (ENABLED and K.USE_PR == "all" and K.USE_CONVBN and x.features.is_cuda and model.training
+            and not getattr(model, "cls_mode", False) and x.features.dtype == torch.float32
+            and not x.features.requires_grad and precision.sparse_dtype() is None
+            and x.indices.shape[0] > 1 and torch.is_grad_enabled())
+
+
+def run(model, x, condition=None, context=None):
+    """The backbone's output features for the sparse input ``x``, or None when the executor does not
+    cover this model / input (the caller then walks the modules)."""
+    if not supported(model, x):
+        return None
+    plan = build_plan(model, x, condition, context)
+    if plan is None:
+        return None
+    feats = x.features
+    pad = plan.acts[0][1] - feats.shape[1]
+    stem = plan.units[0]
+    w_stem = stem.conv.weight.reshape(stem.c_out, -1, stem.conv.in_channels)
+    if pad:
+        feats = F.pad(feats, (0, pad))
+        w_stem = F.pad(w_stem, (0, pad))
+    tensors = []
+    for u in plan.units:
+        if u.kind == UNET_CONCAT:
+            continue
+        w = w_stem if u is stem else u.conv.weight.reshape(u.c_out, -1, u.conv.in_channels)
+        u.w_index = len(tensors)
+        tensors += [w, u.affine[0], u.affine[1]]
+        if u.bn.track_running_stats and u.bn.num_batches_tracked is not None:
+            rownorm._bump_batches_tracked(u.bn)
+    global CALLS
+    CALLS += 1
+    return SpUNetFunction.apply(feats.contiguous(), plan, *tensors)
+
+
+def _fill_forward(plan, feats, tensors):
+    dev = feats.device
+    arena = plan.fwd
+    plan.act_off = [None] * len(plan.acts)
+    for u in plan.units:
+        if u.kind != UNET_CONCAT:
+            u.y_off = arena.reserve(u.n_out * u.c_out)
+            u.mi_off = arena.reserve(2 * u.c_out)
+        plan.act_off[u.dst] = arena.reserve(plan.acts[u.dst][0] * plan.acts[u.dst][1])
+    arena.allocate(dev)
+    ops = (UnetOp * len(plan.units))()
+    act_ptr = [None if off is None else arena.ptr(off) for off in plan.act_off]
+    act_ptr[0] = feats.data_ptr()
+    max_prod, max_c = 1, 8
+    for op, u in zip(ops, plan.units):
+        op.kind, op.c_in, op.c_out, op.relu = u.kind, u.c_in, u.c_out, int(bool(u.relu))
+        op.n_in, op.n_out = u.n_in, u.n_out
+        op.x = act_ptr[u.src]
+        op.residual = act_ptr[u.res] if u.res is not None else None
+        op.out = act_ptr[u.dst]
+        if u.kind == UNET_CONCAT:
+            op.dx_accumulate = int(u.acc_res)
+            continue
+        w, bw, bb = tensors[u.w_index:u.w_index + 3]
+        assert w.is_contiguous() and bw.is_contiguous() and bb.is_contiguous()
+        op.K = u.rb.K
+        u.geom = u.rb.geom(u.c_in, u.c_out, positions=u.kind == UNET_CONV_BN)
+        u.geom_ptr = ctypes.pointer(u.geom)
+        op.geom = u.geom_ptr
+        op.weight, op.bn_weight, op.bn_bias = w.data_ptr(), bw.data_ptr(), bb.data_ptr()
+        bn = u.bn
+        if bn.track_running_stats:
+            op.running_mean, op.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        op.eps, op.momentum = float(bn.eps), float(bn.momentum)
+        op.y_conv, op.mean_invstd = arena.ptr(u.y_off), arena.ptr(u.mi_off)
+        max_c = max(max_c, u.c_out, u.c_in)
+        if u.kind == UNET_STEM:
+            op.nbr, op.nbr_stride, op.kflip = u.rb.nbr.data_ptr(), u.rb.nbr_stride, u.rb.kflip
+            n_tiles_w = u.geom.n_tiles_w
+            max_prod = max(max_prod, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
+                u.c_in, u.c_out, n_tiles_w)))
+        else:
+            op.dx_accumulate = int(u.acc_dx)
+            max_prod = max(max_prod, u.rb.n_pairs * max(u.c_in, u.c_out))
+    plan.ops = ops
+    plan.max_prod, plan.max_c = max_prod, max_c
+    return ops
+
+
+class SpUNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, plan, *tensors):
+        dev = feats.device
+        ops = _fill_forward(plan, feats, tensors)
+        prod = K.workspace("prod", dev, plan.max_prod)
+        stats = rownorm._workspace(dev, plan.max_c)
+        _lib.check(_lib.lib().pv2_unet_forward(ops, len(ops), K._ptr(prod), K._ptr(stats),
+                                               K._stream(feats)), "pv2_unet_forward")
+        ctx.plan = plan
+        ctx.feats = feats
+        ctx.save_for_backward(*tensors)
+        rows, ch = plan.acts[plan.out_act]
+        return plan.fwd.view(plan.act_off[plan.out_act], rows, ch)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        tensors = ctx.saved_tensors
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        arena = _Arena()
+        g_off = [None] * len(plan.acts)
+        for a, (rows, ch) in enumerate(plan.acts):
+            if a != 0 and a != plan.out_act:
+                g_off[a] = arena.reserve(rows * ch)
+        for u in plan.units:
+            if u.kind == UNET_CONCAT:
+                continue
+            u.dy_off = arena.reserve(u.n_out * u.c_out)
+            u.gsum_off = arena.reserve(2 * u.c_out)
+            u.dw_off = arena.reserve(u.c_out * u.rb.K * u.c_in)
+        arena.allocate(dev)
+        g_ptr = [None if off is None else arena.ptr(off) for off in g_off]
+        g_ptr[plan.out_act] = grad_out.data_ptr()
+        ops = plan.ops
+        part_floats = 1
+        for op, u in zip(ops, plan.units):
+            op.grad_out = g_ptr[u.dst]
+            op.dx = g_ptr[u.src]
+            op.dres = g_ptr[u.res] if u.res is not None else None
+            if u.kind == UNET_CONCAT:
+                continue
+            op.dy, op.gsum, op.dweight = arena.ptr(u.dy_off), arena.ptr(u.gsum_off), arena.ptr(u.dw_off)
+            if u.kind == UNET_CONV_BN:
+                part_floats = max(part_floats, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
+                    u.c_in, u.c_out, u.geom.n_tiles_w)))
+        # weight gradients on the backward side stream when every one of them is only stored
+        weights = [tensors[u.w_index] for u in plan.units if u.kind == UNET_CONV_BN]
+        side = None
+        if sidestream.active(grad_out) and all(sidestream.safe_leaf(w) for w in weights):
+            side = sidestream.native_fork(dev, (plan.fwd.tensor, arena.tensor, ctx.feats, grad_out))
+            part = K.workspace("wgrad", dev, part_floats, stream=side)
+        else:
+            part = K.workspace("wgrad", dev, part_floats)
+        prod = K.workspace("prod", dev, plan.max_prod)
+        stats = rownorm._workspace(dev, plan.max_c)
+        _lib.check(_lib.lib().pv2_unet_backward(
+            ops, len(ops), K._ptr(prod), K._ptr(stats), K._ptr(part), K._stream(grad_out),
+            ctypes.c_void_p(side.cuda_stream) if side is not None else None), "pv2_unet_backward")
+        grads = [None] * len(tensors)
+        for u in plan.units:
+            if u.kind == UNET_CONCAT:
+                continue
+            i = u.w_index
+            grads[i] = arena.view(u.dw_off, u.c_out, u.rb.K, u.c_in)
+            gsum = arena.view(u.gsum_off, 2 * u.c_out)
+            grads[i + 1] = gsum[u.c_out:]
+            grads[i + 2] = gsum[:u.c_out]
+        ctx.plan = None
+        return (None, None) + tuple(grads)

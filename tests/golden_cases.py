@@ -298,15 +298,21 @@ def float64_gradient_errors(params, g):
     (oracle/make_golden.py::float64_gradient_record): the fixture holds each gradient's norm and
     GRAD_PROBES random projections; for e = g - g_ref and iid standard-normal probes
     E[(probe . e)^2] = |e|^2, so |e| is estimated by the root mean square of the projection
-    differences (8 probes: +-25 % on a single tensor, far tighter on the global figures).  Returns
-    the global relative error ||g - g_ref|| / ||g_ref|| over all parameters and over the backbone
-    alone, the worst single tensor, and the largest relative error of a gradient NORM."""
+    differences (8 probes: +-25 % on a single tensor, far tighter on the global figures).
+
+    Returns the global relative error ||g - g_ref|| / ||g_ref|| over all parameters and over the
+    backbone alone, each next to the SAME figure for the reference's own fp32 pass (``ref32_*``:
+    what fp32 arithmetic does to these gradients on the reference's side - the yardstick), and the
+    worst single tensor among those whose norm is not negligible (parameters in front of a
+    BatchNorm have an exactly-zero true gradient: pure rounding noise on either side)."""
     from oracle.detweights import GRAD_PROBES, grad_probe
 
-    num = {"all": 0.0, "backbone": 0.0}
-    den = {"all": 0.0, "backbone": 0.0}
-    worst, worst_name, norm_err = 0.0, "", 0.0
-    for name, ref_norm, ref_proj in zip(g["g64_names"], g["g64_norm"], g["g64_proj"]):
+    keys = ("all", "backbone")
+    num, num32, den = ({k: 0.0 for k in keys} for _ in range(3))
+    per_tensor = []
+    have32 = "g32_proj" in g.files
+    scale = float(np.sqrt((g["g64_norm"] ** 2).mean()))
+    for t, (name, ref_norm, ref_proj) in enumerate(zip(g["g64_names"], g["g64_norm"], g["g64_proj"])):
         name = str(name)
         grad = params[name].grad
         assert grad is not None, name
@@ -316,19 +322,34 @@ def float64_gradient_errors(params, g):
             probe = grad_probe(name, i, grad.shape).to(grad.device).double().reshape(-1)
             e2 += (float(flat @ probe) - float(ref_proj[i])) ** 2
         e2 /= GRAD_PROBES
-        for key in num:
+        e2_32 = float(((g["g32_proj"][t] - ref_proj) ** 2).mean()) if have32 else 0.0
+        for key in keys:
             if key == "all" or name.startswith("backbone."):
                 num[key] += e2
+                num32[key] += e2_32
                 den[key] += float(ref_norm) ** 2
-        if ref_norm > 0:
-            rel = (e2 ** 0.5) / float(ref_norm)
-            if rel > worst:
-                worst, worst_name = rel, name
-            norm_err = max(norm_err, abs(float(flat.norm()) - float(ref_norm)) / float(ref_norm))
+        if ref_norm > 1e-3 * scale:
+            per_tensor.append((e2 ** 0.5 / float(ref_norm), e2_32 ** 0.5 / float(ref_norm), name))
+    worst = max(per_tensor)
     return dict(global_rel=(num["all"] / den["all"]) ** 0.5,
                 backbone_rel=(num["backbone"] / den["backbone"]) ** 0.5,
-                worst_tensor_rel=worst, worst_tensor=worst_name, worst_norm_rel=norm_err,
+                ref32_global_rel=(num32["all"] / den["all"]) ** 0.5 if have32 else None,
+                ref32_backbone_rel=(num32["backbone"] / den["backbone"]) ** 0.5 if have32 else None,
+                worst_tensor_rel=worst[0], worst_tensor_ref32_rel=worst[1], worst_tensor=worst[2],
                 tensors=len(g["g64_names"]))
+
+
+def check_float64_gradients(f64):
+    """The GPU's fp32 gradients are as close to the reference's float64 gradients as the reference's
+    OWN fp32 gradients are (within a factor, plus a floor for well-conditioned cases): at the far end
+    of ~60 BatchNorm layers fp32 rounding alone moves the gradients by 1e-3..1e-1 on either side,
+    which is why no absolute bound of that size says anything - the comparison with the reference's
+    fp32 pass does."""
+    assert f64["tensors"] > 200, f64
+    for key in ("global_rel", "backbone_rel"):
+        ref = f64["ref32_" + key]
+        assert ref is not None, "fixture without the reference's fp32 record"
+        assert f64[key] <= max(3.0 * ref, 2e-3), f64
 
 
 # model section of configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py (reference :20-92)

@@ -278,3 +278,60 @@ def test_tied_conv_weights_with_the_side_stream(device):
 
     on, off = run(True), run(False)
     assert torch.equal(on, off)   # deterministic kernels: the stream placement must not change a bit
+
+
+# ------------------------------------------------------------------ the U-Net as one native call
+def test_native_unet_equals_the_modular_walk(device, monkeypatch):
+    """SpUNet-v1m1 at full width / depth: the natively executed plan (ponderv2_amd/spunet_native.py,
+    csrc/spunet_exec.hip) against the module-by-module walk with the same kernels.  Forward: the
+    same kernels in the same order => identical bits.  Gradients: equal up to the order in which an
+    activation's gradients are added (inside the grad-input reduce here, by autograd there), which
+    the ~60 BatchNorm layers amplify - compared by global relative error.  Also: bitwise repeatable,
+    and bitwise independent of the side stream."""
+    from golden_cases import FULL_BACKBONE
+    from ponderv2_amd import sidestream, spunet_native
+    from ponderv2_amd.ponder.models import build_model
+
+    torch.manual_seed(0)
+    model = build_model(dict(FULL_BACKBONE)).to(device).train()
+    coords = random_voxels(11, batch=2, n_per_batch=6000)
+    counts = np.bincount(coords[:, 0], minlength=2)
+    data = dict(grid_coord=torch.from_numpy(coords[:, 1:]).to(device),
+                feat=torch.randn(len(coords), 6, device=device),
+                offset=torch.from_numpy(np.cumsum(counts)).to(device))
+    probe = None
+
+    def step(native, side=True):
+        nonlocal probe
+        monkeypatch.setattr(spunet_native, "ENABLED", native)
+        monkeypatch.setattr(sidestream, "ENABLED", side)
+        before = spunet_native.CALLS
+        model.zero_grad(set_to_none=True)
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.reset_running_stats()
+        out = model(dict(data))
+        assert (spunet_native.CALLS > before) == native
+        if probe is None:
+            probe = torch.randn_like(out)
+        (out * probe).sum().backward()
+        torch.cuda.synchronize()
+        stats = {n: b.clone() for n, b in model.named_buffers() if "running" in n}
+        return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}, stats
+
+    nat_out, nat_g, nat_s = step(True)
+    again_out, again_g, _ = step(True)
+    off_out, off_g, _ = step(True, side=False)
+    mod_out, mod_g, mod_s = step(False)
+    assert torch.equal(nat_out, again_out) and torch.equal(nat_out, off_out)
+    for n in nat_g:
+        assert torch.equal(nat_g[n], again_g[n]) and torch.equal(nat_g[n], off_g[n]), n
+    assert torch.equal(nat_out, mod_out)                      # forward: the same kernels, the same bits
+    for n in nat_s:
+        assert torch.equal(nat_s[n], mod_s[n]), n             # running statistics
+    assert nat_g.keys() == mod_g.keys()
+    num = sum(float((nat_g[n].double() - mod_g[n].double()).square().sum()) for n in nat_g)
+    den = sum(float(mod_g[n].double().square().sum()) for n in nat_g)
+    worst = max(_rel(nat_g[n], mod_g[n]) for n in nat_g if float(mod_g[n].abs().max()) > 1e-6)
+    print("native vs modular gradients: global", (num / den) ** 0.5, "worst tensor", worst)
+    assert (num / den) ** 0.5 < 1e-3 and worst < 5e-2

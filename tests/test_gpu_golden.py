@@ -93,14 +93,12 @@ def _check_full_size(errs, flips):
     # them by percents on EITHER side, so this bound is loose ...
     deep = {k: v for k, v in errs.items() if k.startswith("grad_backbone")}
     assert max(deep.values()) < 6e-2, errs
-    # ... and the tight statement is against the reference's FLOAT64 pass, over ALL ~230 gradient
-    # tensors of the step (norm + random projections in the fixture): global relative error
-    # ||g - g_ref|| / ||g_ref||, for the whole model and for the backbone alone
+    # ... and the meaningful statement is against the reference's FLOAT64 pass, over ALL ~230
+    # gradient tensors of the step (norm + random projections in the fixture): the global relative
+    # error ||g - g_ref|| / ||g_ref|| of the GPU's fp32 gradients next to the same figure for the
+    # reference's own fp32 pass (golden_cases.check_float64_gradients)
     if f64 is not None:
-        assert f64["tensors"] > 200
-        assert f64["global_rel"] < 1e-3, f64
-        assert f64["backbone_rel"] < 1e-3, f64
-        assert f64["worst_norm_rel"] < 2e-2, f64
+        gc.check_float64_gradients(f64)
 
 
 def test_ponder_indoor_full_size_config1_vs_reference(device):
@@ -164,5 +162,4 @@ def test_ponder_outdoor_full_size_vs_reference(device):
     assert max(head.values()) < 1e-3, errs
     deep = {k: v for k, v in errs.items() if k.startswith(("grad_backbone", "grad_mtoken"))}
     assert max(deep.values()) < 6e-2, errs
-    assert f64["tensors"] > 200
-    assert f64["global_rel"] < 1e-3 and f64["backbone_rel"] < 1e-3, f64
+    gc.check_float64_gradients(f64)
