@@ -96,7 +96,7 @@ template <> __device__ __forceinline__ void st8<H16>(unsigned short* p, int64_t 
 // MODE 0: f0 = x - s, f1 = (x - s)^2 with the shift s = x[0, c] (forward statistics: the shifted form
 //         keeps E[x^2] - mean^2 accurate for columns whose mean is far larger than their spread)
 // MODE 1: g = dy * (y > 0 if y else 1);  f0 = g, f1 = g * xhat       (backward reductions)
-constexpr int kMaxPartialBlocks = 1024;
+constexpr int kMaxPartialBlocks = 2048;  // (the row reduce of sparse_conv_pr.hip writes up to this many)
 constexpr int kMaxChannels = 1024;
 
 // EA: element type of `a` (the input x in MODE 0, dy in MODE 1); EX / EY: of x and y in MODE 1.
@@ -432,7 +432,7 @@ inline void partial_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_bl
   const int rpi = c >= kThreads ? 1 : kThreads / c;
   int64_t want = (n * c * 4 + 16383) / 16384;
   if (want < 1) want = 1;
-  if (want > kMaxPartialBlocks) want = kMaxPartialBlocks;
+  if (want > 1024) want = 1024;   // (measured best for the stand-alone partials kernel)
   int64_t rpb = (n + want - 1) / want;
   rpb = (rpb + rpi - 1) / rpi * rpi;  // whole iterations
   *rows_per_block = rpb;

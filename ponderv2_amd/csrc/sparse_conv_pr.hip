@@ -31,9 +31,7 @@
 
 namespace {
 
-constexpr int kRows = 64;       // output rows a workgroup stages per pass
 constexpr int kMaxK = 32;       // offsets per rulebook on this path (27 submanifold, 8 strided)
-constexpr int kListLd = kMaxK + 1;
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -67,103 +65,91 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
   a.w += b.w;
 }
 
-// acc = (init_row + bias) + prod[list[0]] + prod[list[1]] + ...   (this order, always)
-// Lane l of a TS-lane team owns the 16-byte columns l, l + TS, ... (NJ of them) of the row.
-template <int TS, int NJ>
-__device__ __forceinline__ void sum_row(const float4* __restrict__ T4, int c4n,
-                                        const int* __restrict__ list, int cnt,
-                                        const float4* init_row,
-                                        const float4* __restrict__ bias4, int l,
-                                        float4 (&acc)[NJ]) {
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+// Stage two.  A team of TS lanes sums one output row: out[o] = (addend[o] + bias) + sum over the
+// offsets k present at o, ascending, of prod[pos[k][o]].  No shared memory and no barrier on the way:
+// lane l of the team loads the position-table entries k = l, l + TS, ... of its row (one strided
+// load each), a ballot turns them into the team's bit mask of present offsets, and the team walks
+// the set bits in ascending order - the pair index comes from the owning lane by a shuffle, up to
+// FOUR product rows per output row are in flight, and every team works on TWO output rows at a
+// time (its row of this pass and of the next), so that eight 16-byte loads per lane are
+// outstanding while the dependent chain table -> product rows -> store is only three round trips
+// long.  (The first version staged the table through LDS and compacted it with one thread per row
+// behind two barriers: 18-27 us per launch regardless of size, all of it exposed latency.)
+//
+// STATS: the BatchNorm forward statistics of the result in the same pass - per-block partial column
+// sums of (y - s) and (y - s)^2 with the shift s = y[0, :] (every team recomputes row 0 with the
+// same instruction sequence, hence the same bits - as the second row of its first pass), written
+// as partial[block][0..2c) exactly as col_partials_kernel<0> (rownorm.hip) does, for
+// col_combine_kernel<0> to finish.
+template <int TS>
+struct RowState {
+  static constexpr int NE = TS >= 32 ? 1 : 32 / TS;   // table entries per lane (K <= 32)
+  int e[NE];
+  uint32_t mask;
+};
+
+template <int TS>
+__device__ __forceinline__ void load_entries(RowState<TS>& st, const int32_t* __restrict__ pos,
+                                             int64_t pos_stride, int K, int64_t row, bool valid,
+                                             int l, int team_base) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int col = l + j * TS;
-    float4 a = zero;
-    if (col < c4n) {
-      if (init_row) a = init_row[col];
-      if (bias4) add4(a, bias4[col]);
+  for (int j = 0; j < RowState<TS>::NE; ++j) {
+    const int k = l + j * TS;
+    st.e[j] = (valid && k < K) ? pos[(int64_t)k * pos_stride + row] : -1;
+  }
+  uint32_t m = 0;
+  if constexpr (TS >= 32) {
+    m = (uint32_t)(__ballot(st.e[0] >= 0) >> team_base);   // the team's 32 (or 64) lanes: bit k = offset k
+  } else {
+#pragma unroll
+    for (int j = 0; j < RowState<TS>::NE; ++j) {
+      const uint32_t part = (uint32_t)(__ballot(st.e[j] >= 0) >> team_base) & ((1u << TS) - 1u);
+      m |= part << (j * TS);
     }
-    acc[j] = a;
   }
-  int q = 0;
-  for (; q + 8 <= cnt; q += 8) {  // eight product rows in flight, added in list order
-    int64_t p[8];
-    float4 v[8][NJ];
+  st.mask = m;
+}
+
+// pair index of offset k of this row, from the lane that holds it (k is uniform within the team)
+template <int TS>
+__device__ __forceinline__ int entry_of(const RowState<TS>& st, int k) {
+  if constexpr (RowState<TS>::NE == 1) {
+    return __shfl(st.e[0], k, TS);
+  } else {
+    int p = -1;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) p[u] = list[q + u];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = l + j * TS;
-        v[u][j] = col < c4n ? T4[p[u] * c4n + col] : zero;
-      }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
-  }
-  if (q + 4 <= cnt) {  // four
-    int64_t p[4];
-    float4 v[4][NJ];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) p[u] = list[q + u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = l + j * TS;
-        v[u][j] = col < c4n ? T4[p[u] * c4n + col] : zero;
-      }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
-    q += 4;
-  }
-  {  // up to three left: issued together, added in order
-    const int rest = cnt - q;
-    float4 v[3][NJ];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int64_t p = u < rest ? list[q + u] : 0;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = l + j * TS;
-        v[u][j] = (u < rest && col < c4n) ? T4[p * c4n + col] : zero;
-      }
+    for (int j = 0; j < RowState<TS>::NE; ++j) {
+      const int v = __shfl(st.e[j], k & (TS - 1), TS);
+      if ((k / TS) == j) p = v;
     }
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-      if (u < rest) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) add4(acc[j], v[u][j]);
-      }
+    return p;
   }
 }
 
-// Stage two.  A workgroup owns `rows_per_block` consecutive output rows; per pass of <= 64 rows
-// their position-table columns are read coalesced into LDS and compacted (per row, ascending k) by
-// one thread per row; then a team of TS lanes sums one row at a time.
-//
-// STATS: the BatchNorm forward statistics of the result in the same pass - per-block partial column
-// sums of (y - s) and (y - s)^2 with the shift s = y[0, :] (every workgroup recomputes row 0 with
-// the same instruction sequence, hence the same bits), written as partial[block][0..2c) exactly as
-// col_partials_kernel<0> (rownorm.hip) does, for col_combine_kernel<0> to finish.
+// next (up to) four pair indices of the row, in ascending offset order; -1 past the end
+template <int TS>
+__device__ __forceinline__ void next4(RowState<TS>& st, int (&p)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (st.mask) {
+      const int k = __builtin_ctz(st.mask);
+      st.mask &= st.mask - 1;
+      p[u] = entry_of<TS>(st, k);
+    } else {
+      p[u] = -1;
+    }
+  }
+}
+
 template <int TS, int NJ, bool STATS>
 __global__ __launch_bounds__(256) void row_reduce_kernel(
     const float* __restrict__ T, const int32_t* __restrict__ pos, int64_t pos_stride, int K, int c,
     int64_t n_rows, int64_t rows_per_block, const float* __restrict__ bias,
     const float* addend, float* Y, float* __restrict__ partial) {
   constexpr int NT = 256 / TS;
-  __shared__ int s_raw[kMaxK * kRows];
-  __shared__ int s_list[kRows * kListLd];
-  __shared__ int s_cnt[kRows];
-  __shared__ int s_list0[kMaxK];
-  __shared__ int s_cnt0;
   __shared__ float s_red[STATS ? 2048 * NJ : 1];
   const int tid = threadIdx.x, team = tid / TS, l = tid % TS;
+  const int team_base = (tid & 63) / TS * TS;
   const int c4n = c >> 2;
   const float4* T4 = reinterpret_cast<const float4*>(T);
   const float4* bias4 = reinterpret_cast<const float4*>(bias);
@@ -171,62 +157,86 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
   float4* Y4 = reinterpret_cast<float4*>(Y);
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = min(n_rows, r_begin + rows_per_block);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 sh[NJ], a0[NJ], a1[NJ];
-  if (STATS) {
-    if (tid < K) s_raw[tid] = pos[(int64_t)tid * pos_stride];  // row 0: the shift
-    __syncthreads();
-    if (tid == 0) {
-      int cnt = 0;
-      for (int k = 0; k < K; ++k) {
-        const int p = s_raw[k];
-        if (p >= 0) s_list0[cnt++] = p;
-      }
-      s_cnt0 = cnt;
-    }
-    __syncthreads();
-    sum_row<TS, NJ>(T4, c4n, s_list0, s_cnt0, add4p, bias4, l, sh);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) a0[j] = a1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();  // s_raw is reused below
-  }
+  for (int j = 0; j < NJ; ++j) sh[j] = a0[j] = a1[j] = zero;
 
-  for (int64_t base = r_begin; base < r_end; base += kRows) {
-    const int rows = (int)min((int64_t)kRows, r_end - base);
-    for (int e = tid; e < K * rows; e += 256) {
-      const int k = e / rows, rr = e - k * rows;
-      s_raw[k * kRows + rr] = pos[(int64_t)k * pos_stride + base + rr];
-    }
-    __syncthreads();
-    for (int rr = tid; rr < rows; rr += 256) {
-      int cnt = 0;
-      for (int k = 0; k < K; ++k) {
-        const int p = s_raw[k * kRows + rr];
-        if (p >= 0) s_list[rr * kListLd + cnt++] = p;
-      }
-      s_cnt[rr] = cnt;
-    }
-    __syncthreads();
-    for (int rr = team; rr < rows; rr += NT) {
-      const int64_t row = base + rr;
-      float4 acc[NJ];
-      sum_row<TS, NJ>(T4, c4n, &s_list[rr * kListLd], s_cnt[rr],
-                      add4p ? add4p + row * c4n : nullptr, bias4, l, acc);
+  // rows come in pairs (A, B); the very first B of a STATS launch is row 0 (the shift)
+  bool need_shift = STATS;
+  for (int64_t ra = r_begin + team; ra < r_end || need_shift; ra += 2 * NT) {
+    const int64_t rb = need_shift ? 0 : ra + NT;
+    const bool va = ra < r_end, vb = need_shift || rb < r_end;
+    RowState<TS> sa, sb;
+    load_entries<TS>(sa, pos, pos_stride, K, va ? ra : 0, va, l, team_base);
+    load_entries<TS>(sb, pos, pos_stride, K, vb ? rb : 0, vb, l, team_base);
+    float4 accA[NJ], accB[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = l + j * TS;
-        if (col < c4n) {
-          Y4[row * c4n + col] = acc[j];
-          if (STATS) {
-            const float4 d = make_float4(acc[j].x - sh[j].x, acc[j].y - sh[j].y,
-                                         acc[j].z - sh[j].z, acc[j].w - sh[j].w);
-            add4(a0[j], d);
-            add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
-          }
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      float4 ia = zero, ib = zero;
+      if (col < c4n) {
+        if (add4p) {
+          if (va) ia = add4p[ra * c4n + col];
+          if (vb) ib = add4p[rb * c4n + col];
+        }
+        if (bias4) {
+          const float4 bv = bias4[col];
+          add4(ia, bv);
+          add4(ib, bv);
+        }
+      }
+      accA[j] = ia;
+      accB[j] = ib;
+    }
+    while (sa.mask | sb.mask) {   // (uniform within the team; teams of a wave diverge)
+      int pa[4], pb[4];
+      next4<TS>(sa, pa);
+      next4<TS>(sb, pb);
+      float4 vA[4][NJ], vB[4][NJ];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = l + j * TS;
+          vA[u][j] = (pa[u] >= 0 && col < c4n) ? T4[(int64_t)pa[u] * c4n + col] : zero;
+          vB[u][j] = (pb[u] >= 0 && col < c4n) ? T4[(int64_t)pb[u] * c4n + col] : zero;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (pa[u] >= 0) add4(accA[j], vA[u][j]);   // (adding +0 would turn a -0 sum into +0)
+          if (pb[u] >= 0) add4(accB[j], vB[u][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      if (col >= c4n) continue;
+      if (need_shift) sh[j] = accB[j];                 // row 0: the shift (block 0 also stores it below)
+      if (va) Y4[ra * c4n + col] = accA[j];
+      if (!need_shift && vb) Y4[rb * c4n + col] = accB[j];
+      if (STATS) {
+        if (va) {
+          const float4 d = make_float4(accA[j].x - sh[j].x, accA[j].y - sh[j].y, accA[j].z - sh[j].z,
+                                       accA[j].w - sh[j].w);
+          add4(a0[j], d);
+          add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
+        }
+        if (!need_shift && vb) {
+          const float4 d = make_float4(accB[j].x - sh[j].x, accB[j].y - sh[j].y, accB[j].z - sh[j].z,
+                                       accB[j].w - sh[j].w);
+          add4(a0[j], d);
+          add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
         }
       }
     }
-    __syncthreads();  // the staging arrays are rewritten by the next pass
+    if (need_shift) {
+      need_shift = false;
+      ra -= NT;   // the B slot of this pass went to row 0: the next pass starts one team-stride on
+    }
   }
 
   if (STATS) {
@@ -274,14 +284,13 @@ int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K
   PV2_REQUIRE(n_rows >= 0 && pos_stride >= n_rows, "pv2_spconv_reduce_rows: bad row count");
   if (bn_blocks) *bn_blocks = 0;
   if (n_rows == 0) return PV2_OK;
-  // One row per team and pass wherever the row count allows it: the sum of a row is a chain of
-  // dependent loads (table -> list -> product rows), so a team that walks many rows is latency-bound
-  // (measured 20-27 us per launch regardless of size with >= 16 KB of output per workgroup).  At
-  // most 1024 workgroups: the BatchNorm statistics leave one partial row each.
+  // Two rows per team and pass; as many workgroups as that takes, up to 2048 when the BatchNorm
+  // statistics ride along (one partial row per workgroup, pv2_bn_workspace_floats) and 16384 otherwise.
   const int c4n = c / 4;
   const int nt = 256 / (c4n <= 8 ? 8 : c4n <= 16 ? 16 : c4n <= 32 ? 32 : 64);
-  int64_t rpb = (n_rows + 1023) / 1024;
-  rpb = (rpb + nt - 1) / nt * nt;
+  const int64_t cap = bn_partial ? 2048 : 16384;
+  int64_t rpb = (n_rows + cap - 1) / cap;
+  rpb = (rpb + 2 * nt - 1) / (2 * nt) * (2 * nt);
   const int blocks = (int)((n_rows + rpb - 1) / rpb);
   if (bn_partial) {
     launch_reduce<true>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,

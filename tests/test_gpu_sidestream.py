@@ -128,7 +128,9 @@ def test_side_stream_is_bitwise_invisible_on_the_backbone(device, monkeypatch):
     off_out, off_g = step(False)
     assert not forks
     on_out, on_g = step(True)
-    assert len(forks) >= 50, len(forks)          # every conv + BatchNorm unit of the U-Net
+    # (one fork per backward pass when the U-Net runs as one native call - spunet_native.py -, one
+    # per conv + BatchNorm unit when it is walked module by module)
+    assert len(forks) >= 1, len(forks)
     again_out, again_g = step(True)
     assert torch.equal(off_out, on_out) and torch.equal(on_out, again_out)
     assert off_g.keys() == on_g.keys()
