@@ -41,14 +41,16 @@ PMC_FILE = "profiles/r03_pmc_fetch_write_per_kernel.json"
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the kernel sources and the C ABI header: what a per-kernel PMC
-    measurement stays valid for.  tools/pmc_to_json.py stamps the same value into the PMC file."""
+    """sha256 (16 hex digits) over the sources of the sparse-conv kernels (csrc/sparse_conv*.hip +
+    common.h) - the kernels the `roofline` line is about: what their per-kernel PMC measurement
+    stays valid for.  tools/pmc_to_json.py stamps the same value into the PMC file."""
     import hashlib
 
     h = hashlib.sha256()
     src = os.path.join(ROOT, "ponderv2_amd", "csrc")
-    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h")))
-    for f in files + [os.path.join(ROOT, "include", "ponderv2_hip.h")]:
+    files = sorted(os.path.join(src, f) for f in os.listdir(src)
+                   if f.startswith("sparse_conv") and f.endswith(".hip"))
+    for f in files + [os.path.join(src, "common.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -257,7 +257,9 @@ def run(model, x, condition=None, context=None):
     for u in plan.units:
         if u.kind == UNET_CONCAT:
             continue
-        w = w_stem if u is stem else u.conv.weight.reshape(u.c_out, -1, u.conv.in_channels)
+        # (the parameter itself, [c_out, k, k, k, c_in] contiguous = [c_out, K, c_in] in memory: no view
+        # op per unit and step in front of the node, no view-backward node behind it)
+        w = w_stem if u is stem else u.conv.weight
         u.w_index = len(tensors)
         tensors += [w, u.affine[0], u.affine[1]]
         if u.bn.track_running_stats and u.bn.num_batches_tracked is not None:
@@ -381,7 +383,7 @@ class SpUNetFunction(torch.autograd.Function):
             if u.kind == UNET_CONCAT:
                 continue
             i = u.w_index
-            grads[i] = arena.view(u.dw_off, u.c_out, u.rb.K, u.c_in)
+            grads[i] = arena.view(u.dw_off, *tensors[i].shape)
             gsum = arena.view(u.gsum_off, 2 * u.c_out)
             grads[i + 1] = gsum[u.c_out:]
             grads[i + 2] = gsum[:u.c_out]
