@@ -383,6 +383,12 @@ int pv2_maxpool3d_cl_forward(const float* x, int B, int Z, int Y, int X, int C, 
 int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, int Z, int Y, int X,
                               int C, float* grad_x, pv2_stream_t stream);
 
+/* Batched inverse of `batch` row-major n x n matrices, n <= 4 (one launch; Gauss-Jordan with partial
+ * pivoting in double precision, result rounded to fp32): the camera / unit-cube transforms of the
+ * ray set-up, torch.linalg.inv at ponder/models/ponder/ponder_indoor_base.py:380-470.  Singular
+ * input gives inf / nan entries, no error. */
+int pv2_small_inverse(const float* a, int64_t batch, int n, float* out, pv2_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d over the active-voxel feature matrix x[n, c], fused with the optional
  * residual add and ReLU that follow it in SpUNet's blocks; and a column sum.

@@ -107,3 +107,62 @@ int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, i
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Batched inverse of tiny matrices (n <= 4): the camera / scene transforms of the ray set-up
+// (ponder/models/ponder/ponder_indoor_base.py:380-470 of the reference: torch.linalg.inv on (V, 4, 4)
+// poses, (3, 3) intrinsics and the per-scene unit-cube transform).  The library route
+// (rocSOLVER getrf + getri behind torch.linalg.inv_ex) is 11 launches per call for a dozen 4x4
+// matrices; here one thread inverts one matrix by Gauss-Jordan elimination with partial pivoting in
+// double precision and rounds the result to fp32 (at least as accurate as an fp32 LU).
+namespace {
+
+__global__ void small_inverse_kernel(const float* __restrict__ a, int64_t batch, int n,
+                                     float* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= batch) return;
+  double w[4][8];
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      w[r][c] = (double)a[(m * n + r) * n + c];
+      w[r][n + c] = r == c ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    double best = fabs(w[col][col]);
+    for (int r = col + 1; r < n; ++r)
+      if (fabs(w[r][col]) > best) {
+        best = fabs(w[r][col]);
+        piv = r;
+      }
+    if (piv != col)
+      for (int c = 0; c < 2 * n; ++c) {
+        const double t = w[col][c];
+        w[col][c] = w[piv][c];
+        w[piv][c] = t;
+      }
+    const double inv = 1.0 / w[col][col];   // (a singular input gives inf / nan, as the library does)
+    for (int c = 0; c < 2 * n; ++c) w[col][c] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == col) continue;
+      const double f = w[r][col];
+      for (int c = 0; c < 2 * n; ++c) w[r][c] -= f * w[col][c];
+    }
+  }
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) out[(m * n + r) * n + c] = (float)w[r][n + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv2_small_inverse(const float* a, int64_t batch, int n, float* out, pv2_stream_t stream) {
+  PV2_REQUIRE(n >= 1 && n <= 4 && batch >= 0, "pv2_small_inverse: 1 <= n <= 4");
+  if (batch == 0) return PV2_OK;
+  hipLaunchKernelGGL(small_inverse_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0,
+                     (hipStream_t)stream, a, batch, n, out);
+  return pv2::check_launch("small_inverse");
+}
+
+}  // extern "C"

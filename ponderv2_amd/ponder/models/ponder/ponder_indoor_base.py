@@ -46,8 +46,21 @@ def stub_text_embeddings(num_classes, dim=512, seed=0):
 
 
 def _inv(a):
-    """torch.linalg.inv without its error check: that check reads a status word back from the
-    device, i.e. stalls the host once per call (camera matrices are invertible by construction)."""
+    """Inverse of a batch of camera / scene transforms (..., n, n), n <= 4.  On the device: ONE launch
+    (``pv2_small_inverse``: Gauss-Jordan in double precision per matrix) instead of the library's
+    11 (rocSOLVER getrf + getri behind torch.linalg.inv_ex, four calls per step).  Elsewhere
+    torch.linalg.inv without its error check - that check reads a status word back, i.e. stalls the
+    host once per call (camera matrices are invertible by construction)."""
+    n = a.shape[-1]
+    if a.is_cuda and a.dtype == torch.float32 and n <= 4 and a.shape[-2] == n and not a.requires_grad:
+        from ponderv2_amd import _lib
+        from ponderv2_amd.kernels import _ptr, _stream
+
+        src = a.contiguous()
+        out = torch.empty_like(src)
+        _lib.check(_lib.lib().pv2_small_inverse(_ptr(src), src.numel() // (n * n), n, _ptr(out),
+                                                _stream(src)), "pv2_small_inverse")
+        return out
     return torch.linalg.inv_ex(a, check_errors=False).inverse
 
 

@@ -710,3 +710,29 @@ def test_channels_last_max_pool_kernels_equal_max_pool3d(device, shape):
         (got * probe).sum().backward()
         (ref * probe).sum().backward()
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("n,batch", [(4, 13), (3, 2), (4, 1), (2, 700)])
+def test_small_inverse_matches_float64_inverse(device, n, batch):
+    """pv2_small_inverse (the camera / unit-cube transforms of the ray set-up: torch.linalg.inv at
+    ponder_indoor_base.py:380-470 of the reference) against numpy's float64 inverse: rigid poses with
+    large translations, scaled intrinsics-like matrices and rows that need pivoting."""
+    from ponderv2_amd.ponder.models.ponder.ponder_indoor_base import _inv
+
+    rng = np.random.default_rng(n * 100 + batch)
+    a = rng.normal(size=(batch, n, n))
+    q, _ = np.linalg.qr(a)
+    a = q * rng.uniform(0.5, 600.0, size=(batch, 1, n))          # well conditioned, mixed scales
+    a[:, :-1, -1] += rng.uniform(-40, 40, size=(batch, n - 1))   # pose-like translation column
+    a[0] = a[0][::-1].copy()                                      # a zero-ish leading pivot
+    a32 = a.astype(np.float32)
+    ref = np.linalg.inv(a32.astype(np.float64))
+    x = torch.from_numpy(a32).to(device)
+    got = _inv(x)
+    assert got.shape == x.shape and got.dtype == torch.float32
+    err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+    assert err.max() < 2e-6, err.max()
+    lib_err = np.abs(torch.linalg.inv(x).cpu().numpy().astype(np.float64) - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+    assert err.max() <= max(2 * lib_err.max(), 3e-7)            # at least as accurate as the library's fp32 LU
+    # batch dimensions are kept: (B, V, n, n) as the pose stack arrives
+    assert torch.equal(_inv(x[None]), got[None])

@@ -9,7 +9,8 @@ import csv
 import sys
 
 RULES = (  # first match wins
-    ("sparse conv weight gradient", ("spconv_wgrad",)),
+    ("sparse conv weight gradient (partials + ordered reduce)", ("spconv_wgrad", "wgrad_reduce")),
+    ("ordered row reduce (+ fused BN statistics)", ("row_reduce",)),
     ("weight packing (16-bit)", ("pack_weights",)),
     ("sparse conv forward / grad-input", ("spconv_",)),
     ("tall / skinny GEMMs (heads, 1x1x1 conv)", ("tall_gemm", "skinny_gemm")),
@@ -18,7 +19,8 @@ RULES = (  # first match wins
     ("sparse BatchNorm + column sums", ("col_partials", "col_combine", "bn_", "col_sum")),
     ("fused ray march", ("field_", "coarse_sample", "volume_scatter", "weights_", "accumulate_", "fold_")),
     ("optimizer", ("multi_tensor", "sgd", "Sgd")),
-    ("rulebook build", ("rocprim", "table", "hash", "down_", "tile_prefix", "fill_i32")),
+    ("rulebook build", ("rocprim", "table", "hash", "down_", "tile_prefix", "fill_i32", "pair_positions")),
+    ("dense max-pool / concat / split (hand-written)", ("maxpool3d", "concat_rows", "split_rows", "small_inverse")),
     ("ATen elementwise / copies / reductions", ("at::native", "copyBuffer")),
 )
 
