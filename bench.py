@@ -298,9 +298,10 @@ class KernelTimer:
             setattr(K, name, fn)
 
         # the product-row conv path (kernels._pr_conv): two C-ABI launches per conv, each bracketed
-        # by its own event pair.  The MFMA kernel (stage 1) carries the conv's flops and the
-        # conv's algorithmic bytes; the row reduce (stage 2) is a streaming kernel
-        # priced by the bytes IT has to move: the product rows in, the result rows out, the table.
+        # by its own event pair.  The MFMA kernel (stage 1) carries the conv's flops; both stages
+        # are priced by the bytes THEY have to move (stage 1: sources, weights, pair list in, one
+        # product row per pair out; stage 2: the product rows in, the result rows out, the table) -
+        # together SURVEY 8d's per-conv bytes plus one write and one read of the product rows.
         orig_pr = K._pr_conv
         self._orig["_pr_conv"] = orig_pr
         self._pr_ctx = None
@@ -473,8 +474,11 @@ class KernelTimer:
             nb = min(4, (c["c_out"] + 31) // 32)
             fam = ("spconv_fwd_lds_kernel<%d> (product rows: fwd+dgrad, %s output channels per "
                    "workgroup)" % (nb, {1: "32", 2: "64", 3: "96", 4: "128"}[nb]))
+            # bytes THIS kernel has to move: every source row and the weights once, the pair
+            # list, and one product row per pair written (the output rows of SURVEY 8d's formula
+            # are written by stage 2, which is priced separately below)
             return (2.0 * c["p"] * c["c_in"] * c["c_out"],
-                    4.0 * (c["n_src"] * c["c_in"] + c["n_rows"] * c["c_out"]
+                    4.0 * (c["n_src"] * c["c_in"] + c["p"] * c["c_out"]
                            + c["K"] * c["c_in"] * c["c_out"]) + 8.0 * c["p"],
                     (c["c_in"], c["c_out"], c["K"], c["p"]), fam)
 

@@ -447,6 +447,13 @@ def run_ponder_outdoor_full(device, with_float64=True):
     errs = {}
     for name, val in zip(g["out_names"], g["out_values"]):
         errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
+    # the reference's own float64 pass of the same step: how far ITS fp32 loss is from the exact
+    # one (1.1e-4 here: a depth loss over 3 072 rays of 96 samples), and how far ours is
+    ref64 = dict(zip((str(n) for n in g["out64_names"]), g["out64_values"]))
+    ref32 = dict(zip((str(n) for n in g["out_names"]), g["out_values"]))
+    for name, val in ref64.items():
+        errs["f64_" + name] = abs(float(out[name].detach()) - val) / abs(val)
+        errs["ref32_f64_" + name] = abs(ref32[name] - val) / abs(val)
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])

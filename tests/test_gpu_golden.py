@@ -156,8 +156,14 @@ def test_ponder_outdoor_full_size_vs_reference(device):
     errs = gc.run_ponder_outdoor_full(device)
     f64 = errs.pop("float64")
     print(errs, "float64 gradient record", f64)
-    losses = {k: v for k, v in errs.items() if not k.startswith("grad_")}
-    assert max(losses.values()) < 1e-4, errs
+    # Bar: 1e-4 against the reference's fp32 step PLUS that step's own distance from its float64
+    # pass (recorded in the fixture: 1.1e-4 - the fp32 reference itself is that far from the exact
+    # loss, so two correct fp32 programs can be 2e-4 apart), and against the float64 loss no further
+    # than 1e-4 + the reference's fp32 error.
+    for name in ("loss", "depth_loss"):
+        slack = errs["ref32_f64_" + name]
+        assert errs[name] < 1e-4 + slack, errs
+        assert errs["f64_" + name] < 1e-4 + slack, errs
     head = {k: v for k, v in errs.items() if k.startswith(("grad_renderer", "grad_proj_net"))}
     assert max(head.values()) < 1e-3, errs
     deep = {k: v for k, v in errs.items() if k.startswith(("grad_backbone", "grad_mtoken"))}

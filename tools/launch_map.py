@@ -70,4 +70,19 @@ for ph in phases:
     for name, k in groups.most_common(14 if "backward" in ph.name else 8):
         if k:
             print("        %5d  %-60s host %.2f ms" % (k, name[:60], hosts[name] / 1e3))
+# the backward pass runs on the autograd engine's device thread: its nodes are no children of the
+# host range above; group them by node type wherever they ran
+nodes = [e for e in events if e.name.startswith("autograd::engine::evaluate_function: ")]
+groups, hosts, counts = collections.Counter(), collections.Counter(), collections.Counter()
+for e in nodes:
+    name = e.name.split(": ", 1)[1]
+    groups[name] += launches(e)
+    hosts[name] += e.cpu_time_total
+    counts[name] += 1
+n_b = sum(groups.values())
+total += n_b
+print("%-46s %5d launches  host %.2f ms  (%d nodes)" % ("backward (autograd nodes, engine thread)", n_b,
+                                                        sum(hosts.values()) / 1e3, sum(counts.values())))
+for name, k in sorted(hosts.items(), key=lambda kv: -kv[1])[:40]:
+    print("        %5d launches %4d nodes  %-52s host %.2f ms" % (groups[name], counts[name], name[:52], k / 1e3))
 print("total launches in the step:", total)
