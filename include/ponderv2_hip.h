@@ -522,6 +522,54 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
                             pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The NeuS head for NARROW SDF decoders (csrc/raymarch_narrow.hip): the head of the reference's
+ * nuScenes configuration (configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py: SDFField with
+ * sdf_decoder = dict(in_dim=32, out_dim=16+1, hidden_size=16, n_blocks=5), no colour / semantic
+ * decoder, depth loss).  Replaces, per call, what the reference runs as ~500 small autograd ops:
+ * ponder/models/ponder/render_utils/decoders.py:6-36 (SDFDecoder: x = fc_p(p) * points_factor,
+ * x = lin_l(x + fc_c[l](feat)), Softplus(beta=100)), fields/sdf_field.py:185-197, 211-284, 122-146
+ * (get_sdf, grad sdf by autograd, NeuS alphas), rays.py:83-105, renderers.py:33-45 (weights,
+ * expected depth) and ray_samplers.py:355-463 (coarse pass + importance sampling).
+ *   theta [theta_len]: Wp [H,3] bp [H] | l = 0..L-1: Wc_l [H,C] bc_l [H] | l = 0..L-2: W_l [H,H]
+ *     b_l [H] | w_last [H] b_last  (fc_p, fc_c[l], lin_l, row 0 of the last lin; C, H, L and
+ *     theta_len from pv2_narrow_head_dims: 32, 16, 6, 4609).  points_factor multiplies fc_p(p).
+ *   volume: channels-last [B, Z, Y, X, C]; rays are scene-major, n_rays / B per scene; zeros
+ *     padding, align_corners, points NOT normalised (SDFField.norm_pts = False).
+ *   coarse_sample: as pv2_neus_coarse_sample (same outputs, same random-number inputs).
+ *   field_forward: sdf [N], grad [N,3] (N = n_rays * n_samples, sample n = ray * n_samples + k),
+ *     weights [N], trans [N] (transmittance in front of sample k), comp [n_rays, 2] =
+ *     [sum_k w_k starts_k, sum_k w_k]; inv_s: one device float.
+ *   field_backward: upstream g_comp [n_rays,2] and optional (NULL = zero) g_weights [N], g_sdf [N],
+ *     g_grad [N,3].  Writes work [N,4] (scratch), ADDS the volume gradient into g_volume (caller
+ *     zero-initialises; NULL skips it), writes g_theta_slabs [pv2_narrow_backward_slabs(..),
+ *     theta_len] - the caller sums the slabs in order - and g_inv_s_part [n_rays] (sum = d/d inv_s).
+ *     Second-order terms through grad sdf are included (hand-derived; oracle/narrow_head.py).
+ * ------------------------------------------------------------------------------------------ */
+int pv2_narrow_head_dims(int* channels, int* hidden, int* layers, int* theta_len);
+int pv2_narrow_coarse_sample(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                             const float* origins, const float* dirs, const float* nears,
+                             const float* fars, int64_t n_rays, int n_coarse, int n_importance,
+                             const float* lin_bins, const float* t_rand, int t_rand_cols,
+                             const float* lin_u, const float* u_rand, int u_rand_cols,
+                             const float* theta, float points_factor, float base_inv_s, float* bins_out,
+                             float* starts_out, float* deltas_out, int32_t* dbg_idx, float* dbg_sdf,
+                             float* dbg_w, pv2_stream_t stream);
+int pv2_narrow_field_forward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                             const float* origins, const float* dirs, const float* starts,
+                             const float* deltas, int64_t n_rays, int n_samples, const float* theta,
+                             float points_factor, const float* inv_s, float* sdf, float* grad,
+                             float* weights, float* trans, float* comp, pv2_stream_t stream);
+int64_t pv2_narrow_backward_slabs(int64_t n_rays, int n_samples);
+int pv2_narrow_field_backward(const float* volume, int vol_b, int vol_z, int vol_y, int vol_x, int vol_c,
+                              const float* origins, const float* dirs, const float* starts,
+                              const float* deltas, int64_t n_rays, int n_samples, const float* theta,
+                              float points_factor, const float* inv_s, const float* sdf,
+                              const float* grad, const float* weights, const float* trans,
+                              const float* g_comp, const float* g_weights, const float* g_sdf,
+                              const float* g_grad, float* work, float* g_volume, float* g_theta_slabs,
+                              float* g_inv_s_part, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * The same head with the projection network's final 1x1x1 convolution FOLDED into it.
  * ponder/models/ponder/unet3d.py:637-641,703 (``final_conv = nn.Conv3d(f_maps[0], out_channels,
  * 1)``) writes V = Wf X + bf on every grid cell and ponder/models/ponder/render_utils/fields/

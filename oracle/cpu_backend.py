@@ -176,6 +176,51 @@ def _host_coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_
     return (bins, starts, deltas, dbg) if debug else (bins, starts, deltas)
 
 
+class _HostNarrowRender(torch.autograd.Function):
+    """Host double of ponderv2_amd.narrow_head.field_render: forward from the restatement, backward
+    from the HAND-DERIVED formulas csrc/raymarch_narrow.hip implements (oracle/narrow_head.py)."""
+
+    @staticmethod
+    def forward(ctx, vol5, theta, inv_s, origins, dirs, starts, deltas, points_factor):
+        from oracle import narrow_head as nh
+        from ponderv2_amd import narrow_head as prod
+
+        args = [t.detach() for t in (vol5, origins, dirs, starts, deltas, theta, inv_s.reshape(()))]
+        ctx.save_for_backward(*args)
+        ctx.pf = float(points_factor)
+        ctx.hl = (prod.H, prod.L)
+        ctx.inv_s_shape = inv_s.shape
+        with torch.no_grad():
+            out = nh.field_render(*args, *ctx.hl, ctx.pf)
+        return out["sdf"], out["grad"], out["weights"], out["comp"]
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad, g_w, g_comp):
+        from oracle import narrow_head as nh
+
+        args = ctx.saved_tensors
+        R, S = args[3].shape
+        z = lambda g, shape: torch.zeros(shape, dtype=args[0].dtype) if g is None else g
+        g = nh.field_render_backward(*args, *ctx.hl, ctx.pf, z(g_sdf, (R, S)), z(g_grad, (R, S, 3)),
+                                     z(g_w, (R, S)), z(g_comp, (R, 2)))
+        return (g["vol"], g["theta"], g["inv_s"].reshape(ctx.inv_s_shape), None, None, None, None,
+                None)
+
+
+def _host_narrow_coarse_sample(vol5, origins, dirs, nears, fars, lin_bins, t_rand, lin_u, u_rand,
+                               n_importance, theta, points_factor, base_inv_s, debug=False):
+    from oracle import fused_head as fh, narrow_head as nh
+    from ponderv2_amd import narrow_head as prod
+
+    with torch.no_grad():
+        res = nh.coarse_sample(vol5.detach(), origins, dirs, nears, fars, lin_bins.to(vol5.dtype),
+                               t_rand, u_rand, n_importance, theta.detach().to(vol5.dtype), prod.H,
+                               prod.L, float(points_factor), base_inv_s, return_debug=debug)
+        bins, dbg = res if debug else (res, None)
+        starts, deltas = fh.bins_to_samples(bins, nears, fars)
+    return (bins, starts, deltas, dbg) if debug else (bins, starts, deltas)
+
+
 class _Patcher:
     """Minimal monkeypatch look-alike for use outside pytest."""
 
@@ -228,3 +273,9 @@ def install(monkeypatch):
     monkeypatch.setattr(fhead, "field_render", _HostFieldRender.apply)
     monkeypatch.setattr(fhead, "field_render_folded", _host_field_render_folded)
     monkeypatch.setattr(fhead, "fold_supported", fhead.fold_shape_ok)
+    # the narrow-decoder head (csrc/raymarch_narrow.hip): host doubles from oracle/narrow_head.py
+    import ponderv2_amd.narrow_head as nhead
+
+    monkeypatch.setattr(nhead, "device_ok", lambda t: True)
+    monkeypatch.setattr(nhead, "coarse_sample", _host_narrow_coarse_sample)
+    monkeypatch.setattr(nhead, "field_render", _HostNarrowRender.apply)

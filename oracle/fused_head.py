@@ -104,7 +104,7 @@ def sdf_only(vol_rows, p, scene, vol_shape, MW, c0, bc1, v1, b1_0):
 
 
 def coarse_sample(vol, origins, dirs, nears, fars, lin_bins, t_rand, u_rand, n_importance,
-                  MW, c0, bc1, v1, b1_0, base_inv_s=64.0, return_debug=False):
+                  MW, c0, bc1, v1, b1_0, base_inv_s=64.0, return_debug=False, sdf_fn=None):
     """vol (B,Z,Y,X,C); origins/dirs (R,3); nears/fars (R,); lin_bins (S0+1,) = linspace(0,1);
     t_rand (R,S0+1) | (R,1) | None; u_rand (R,n_importance+1) | (R,1) | None.
     Returns bins (R, S0+n_importance+1): the sorted spacing edges of the merged samples."""
@@ -122,8 +122,12 @@ def coarse_sample(vol, origins, dirs, nears, fars, lin_bins, t_rand, u_rand, n_i
     e = bins * far + (1 - bins) * near
     starts, ends = e[:, :-1], e[:, 1:]
     pts = origins[:, None, :] + dirs[:, None, :] * starts[..., None]          # NOT normalised (Q1)
-    sdf = sdf_only(vol.reshape(-1, C), pts.reshape(-1, 3), scene.repeat_interleave(S0),
-                   (B, Z, Y, X), MW, c0, bc1, v1, b1_0).reshape(R, S0)
+    if sdf_fn is not None:   # another head's SDF (oracle/narrow_head.py), same sampling logic
+        sdf = sdf_fn(vol.reshape(-1, C), pts.reshape(-1, 3), scene.repeat_interleave(S0),
+                     (B, Z, Y, X)).reshape(R, S0)
+    else:
+        sdf = sdf_only(vol.reshape(-1, C), pts.reshape(-1, 3), scene.repeat_interleave(S0),
+                       (B, Z, Y, X), MW, c0, bc1, v1, b1_0).reshape(R, S0)
     prev_sdf, next_sdf = sdf[:, :-1], sdf[:, 1:]
     dist = (ends - starts)[:, :-1]
     mid = (prev_sdf + next_sdf) * 0.5

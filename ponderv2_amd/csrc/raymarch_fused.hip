@@ -37,8 +37,11 @@
 // channels-last volume.  The coarse pass is one workgroup per ray: its S0 <= 128 samples are staged
 // in LDS, and the fixed-inv_s weights, the inverse-CDF samples and the sorted merge never leave it.
 #include "common.h"
+#include "raymarch_sampling.h"
 
 namespace {
+using namespace pv2rm;
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -51,12 +54,6 @@ constexpr int kNV = 140;  // per-sample value row: f'(64) geo(64) g(3) n(3) rgb(
 constexpr int kLd = kC + 4;       // LDS row stride of a 32-row tile (conflict-free b128 reads)
 constexpr int kNA = 3 + kF2 + kG + 3;  // colour head input width (134)
 constexpr int kGH = 68;   // row width of the [gsdf, ggeo] operand (1+G padded to a multiple of 4)
-
-struct Vol {
-  const float* p;
-  int B, Z, Y, X;
-  int64_t rays_per_scene;
-};
 
 struct Head {
   const float* MW;    // [2H, F]
@@ -73,67 +70,6 @@ struct Head {
   const float* Wc1t;  // [F, H]   (MW[H:])^T        (backward only)
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-// torch.nn.Softplus(beta=100, threshold=20) and its first two derivatives
-__device__ __forceinline__ void softplus100(float h, float* sp, float* d1, float* d2) {
-  const float bx = 100.f * h;
-  if (bx > 20.f) {
-    *sp = h;
-    *d1 = 1.f;
-    *d2 = 0.f;
-  } else {
-    const float e = expf(bx);
-    *sp = log1pf(e) * 0.01f;
-    const float s = e / (1.f + e);
-    *d1 = s;
-    *d2 = 100.f * s * (1.f - s);
-  }
-}
-
-// Trilinear corner model, zeros padding, align_corners, no smoothstep.  p in [0,1]^3 (x, y, z).
-struct Axes {
-  int ix, iy, iz;
-  float tx, ty, tz;
-};
-
-__device__ __forceinline__ Axes make_axes(float px, float py, float pz, const Vol& v) {
-  Axes a;
-  const float x = px * (float)(v.X - 1), y = py * (float)(v.Y - 1), z = pz * (float)(v.Z - 1);
-  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-  a.tx = x - fx;
-  a.ty = y - fy;
-  a.tz = z - fz;
-  // clamp before the int conversion: far-away points (the coarse pass samples un-normalised
-  // coordinates) must not overflow; any index outside [-1, size] is out of bounds either way
-  a.ix = (int)fminf(fmaxf(fx, -2.f), (float)v.X + 1.f);
-  a.iy = (int)fminf(fmaxf(fy, -2.f), (float)v.Y + 1.f);
-  a.iz = (int)fminf(fmaxf(fz, -2.f), (float)v.Z + 1.f);
-  return a;
-}
-
-// corner c (bit0 = x, bit1 = y, bit2 = z) of a channels-last volume with nch channels: in-bounds
-// flag, element offset of its channel 0, weight and d weight / d p (0 when out of bounds)
-__device__ __forceinline__ bool corner(const Axes& a, const Vol& v, int scene, int c, int nch,
-                                       int64_t* off, float* w, float* dx, float* dy, float* dz) {
-  const int bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-  const int x = a.ix + bx, y = a.iy + by, z = a.iz + bz;
-  const bool ok = x >= 0 && x < v.X && y >= 0 && y < v.Y && z >= 0 && z < v.Z;
-  const float wx = bx ? a.tx : 1.f - a.tx, wy = by ? a.ty : 1.f - a.ty, wz = bz ? a.tz : 1.f - a.tz;
-  const float sx = (bx ? 1.f : -1.f) * (float)(v.X - 1);
-  const float sy = (by ? 1.f : -1.f) * (float)(v.Y - 1);
-  const float sz = (bz ? 1.f : -1.f) * (float)(v.Z - 1);
-  *off = ok ? ((((int64_t)scene * v.Z + z) * v.Y + y) * v.X + x) * nch : 0;
-  *w = ok ? wx * wy * wz : 0.f;
-  *dx = ok ? sx * wy * wz : 0.f;
-  *dy = ok ? wx * sy * wz : 0.f;
-  *dz = ok ? wx * wy * sz : 0.f;
-  return ok;
-}
-
-__device__ __forceinline__ float4 ldg4(const float* p) {
-  return *reinterpret_cast<const float4*>(p);
-}
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
@@ -900,16 +836,7 @@ __global__ __launch_bounds__(256) void fold_scatter_kernel(
 // ------------------------------------------------------------------------------------------
 // Coarse pass + importance sampling: one workgroup per ray, one wave per 32 coarse samples.
 // ------------------------------------------------------------------------------------------
-constexpr int kMaxS0 = 128;
-constexpr int kMaxImp = 63;
 constexpr int kLdF = kF + 4;
-
-__device__ __forceinline__ float lerp_rn(float lo, float hi, float t) {
-  return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t));
-}
-__device__ __forceinline__ float to_euclid(float x, float nearv, float farv) {
-  return __fadd_rn(__fmul_rn(x, farv), __fmul_rn(__fsub_rn(1.f, x), nearv));
-}
 
 __global__ __launch_bounds__(256) void coarse_sample_kernel(
     Vol vol, Head P, const float* __restrict__ origins, const float* __restrict__ dirs,
@@ -922,28 +849,13 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
   // wfs != NULL: the volume has kX channels and wfs = [Wf_sdf | bf_sdf | 0] (kF x kXP) turns the
   // gathered [xt, s] rows into the kF SDF features (folded final convolution, see above)
   __shared__ __attribute__((aligned(16))) float s_f[4][32 * kLdF];
-  __shared__ float s_bins[kMaxS0 + 1], s_e[kMaxS0 + 1], s_sdf[kMaxS0], s_cos[kMaxS0],
-      s_alpha[kMaxS0], s_w[kMaxS0], s_cdf[kMaxS0 + 1], s_new[kMaxImp + 1],
-      s_out[kMaxS0 + kMaxImp + 2];
-  __shared__ float s_scalar[2];
+  __shared__ SampleLds L;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t ray = blockIdx.x;
   const float nearv = nears[ray], farv = fars[ray];
   const int nthreads = blockDim.x;
 
-  // spacing bin edges (ray_samplers.py:70-88) and their ray distances
-  for (int j = tid; j <= S0; j += nthreads) {
-    float b = lin_bins[j];
-    if (t_rand) {
-      const float lo = j == 0 ? lin_bins[0] : __fmul_rn(__fadd_rn(lin_bins[j], lin_bins[j - 1]), 0.5f);
-      const float hi = j == S0 ? lin_bins[S0] : __fmul_rn(__fadd_rn(lin_bins[j + 1], lin_bins[j]), 0.5f);
-      const float t = t_rand[ray * t_rand_cols + (t_rand_cols == 1 ? 0 : j)];
-      b = lerp_rn(lo, hi, t);
-    }
-    s_bins[j] = b;
-    s_e[j] = to_euclid(b, nearv, farv);
-  }
-  __syncthreads();
+  coarse_bins(L, ray, nearv, farv, S0, lin_bins, t_rand, t_rand_cols, tid, nthreads);
 
   // SDF at the start positions (NOT normalised: neus.py:17-21 / SURVEY Q1)
   if (wave * 32 < S0) {
@@ -959,7 +871,7 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
         const int k = wave * 32 + s;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < S0) {
-          const float t = s_e[k];
+          const float t = L.e[k];
           const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
@@ -985,7 +897,7 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float wsum = 0.f;
         if (k < S0) {
-          const float t = s_e[k];
+          const float t = L.e[k];
           const Axes ax = make_axes(o0 + d0 * t, o1 + d1 * t, o2 + d2 * t, vol);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
@@ -1020,133 +932,13 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
   if (wave * 32 < S0) {
     f32x16 a1[4], tt[4];
     mlp_hidden(s_f[wave], kLdF, P, lane, a1, tt, nullptr, 0, 0);
-    // (s_sdf rows beyond S0 land in the padding of the kMaxS0 array)
-    sdf_rows(a1, P, lane, s_sdf + wave * 32);
+    // (L.sdf rows beyond S0 land in the padding of the kMaxS0 array)
+    sdf_rows(a1, P, lane, L.sdf + wave * 32);
   }
   __syncthreads();
 
-  // fixed-inv_s section alphas (ray_samplers.py:426-463)
-  const int n1 = S0 - 1;
-  for (int j = tid; j < n1; j += nthreads) {
-    const float dist = __fsub_rn(s_e[j + 1], s_e[j]);
-    s_cos[j] = (s_sdf[j + 1] - s_sdf[j]) / (dist + 1e-5f);
-  }
-  __syncthreads();
-  for (int j = tid; j < n1; j += nthreads) {
-    const float dist = __fsub_rn(s_e[j + 1], s_e[j]);
-    const float prev = j > 0 ? s_cos[j - 1] : 0.f;
-    const float cv = fminf(fmaxf(fminf(prev, s_cos[j]), -1e3f), 0.f);
-    const float mid = (s_sdf[j] + s_sdf[j + 1]) * 0.5f;
-    const float pc = sigmoidf_((mid - cv * dist * 0.5f) * base_inv_s);
-    const float nc = sigmoidf_((mid + cv * dist * 0.5f) * base_inv_s);
-    s_alpha[j] = (pc - nc + 1e-5f) / (pc + 1e-5f);
-  }
-  __syncthreads();
-
-  // weights (rays.py:83-105) and the padded pdf / cdf of PDFSampler (ray_samplers.py:243-262)
-  if (wave == 0) {
-    float a[2], x[2];
-    float prod = 1.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = lane * 2 + u;
-      a[u] = j < n1 ? s_alpha[j] : 0.f;
-      x[u] = j < n1 ? 1.f - a[u] + 1e-7f : 1.f;
-      prod *= x[u];
-    }
-    float incl = prod;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const float up = __shfl_up(incl, o);
-      if (lane >= o) incl *= up;
-    }
-    float T = __shfl_up(incl, 1);
-    if (lane == 0) T = 1.f;
-    float w[2], wsum = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      w[u] = a[u] * T;   // 0 for j >= n1 (a = 0): the appended zero weight of sample S0-1
-      T *= x[u];
-      wsum += w[u];
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) wsum += __shfl_xor(wsum, o);
-    const float pad = fmaxf(1e-5f - wsum, 0.f);
-    const float den = wsum + pad;
-    float pdf[2], run = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = lane * 2 + u;
-      if (j < S0) s_w[j] = w[u];
-      pdf[u] = j < S0 ? (w[u] + pad / (float)S0) / den : 0.f;
-      run += pdf[u];
-    }
-    float incs = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const float up = __shfl_up(incs, o);
-      if (lane >= o) incs += up;
-    }
-    float before = incs - run;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = lane * 2 + u;
-      before += pdf[u];
-      if (j < S0) s_cdf[j + 1] = fminf(1.f, before);
-    }
-    if (lane == 0) s_cdf[0] = 0.f;
-  }
-  __syncthreads();
-
-  // inverse-CDF samples (ray_samplers.py:263-313)
-  const int nb = n_imp + 1;
-  for (int m = tid; m < nb; m += nthreads) {
-    float u = lin_u[m];
-    if (u_rand) u = __fadd_rn(u, u_rand[ray * u_rand_cols + (u_rand_cols == 1 ? 0 : m)] / (float)nb);
-    else u = __fadd_rn(u, 1.f / (float)(2 * nb));
-    int idx = 0;  // searchsorted(cdf, u, right=True): number of entries <= u
-    for (int j = 0; j <= S0; ++j) idx += s_cdf[j] <= u ? 1 : 0;
-    const int below = min(max(idx - 1, 0), S0), above = min(max(idx, 0), S0);
-    const float c0 = s_cdf[below], c1 = s_cdf[above], b0 = s_bins[below], b1 = s_bins[above];
-    float den = __fsub_rn(c1, c0);
-    if (den < 1e-5f) den = 1.f;
-    const float t = fminf(fmaxf(__fsub_rn(u, c0) / den, 0.f), 1.f);
-    s_new[m] = lerp_rn(b0, b1, t);
-    if (dbg_idx) dbg_idx[ray * nb + m] = idx;
-  }
-  __syncthreads();
-
-  // sorted merge of the S0 coarse and n_imp new spacing starts (rays.py:118-153); both lists are
-  // non-decreasing, so every element's output slot is its own index plus a count in the other list
-  for (int j = tid; j < S0; j += nthreads) {
-    const float v = s_bins[j];
-    int pos = j;
-    for (int m = 0; m < n_imp; ++m) pos += s_new[m] < v ? 1 : 0;
-    s_out[pos] = v;
-  }
-  for (int m = tid; m < n_imp; m += nthreads) {
-    const float v = s_new[m];
-    int pos = m;
-    for (int j = 0; j < S0; ++j) pos += s_bins[j] <= v ? 1 : 0;
-    s_out[pos] = v;
-  }
-  const int S = S0 + n_imp;
-  if (tid == 0) s_out[S] = fmaxf(s_bins[S0], s_new[n_imp]);
-  __syncthreads();
-  for (int j = tid; j <= S; j += nthreads) {
-    bins_out[ray * (S + 1) + j] = s_out[j];
-    if (j < S) {
-      const float e0 = to_euclid(s_out[j], nearv, farv), e1 = to_euclid(s_out[j + 1], nearv, farv);
-      starts_out[ray * S + j] = e0;
-      deltas_out[ray * S + j] = __fsub_rn(e1, e0);
-    }
-  }
-  if (dbg_sdf)
-    for (int j = tid; j < S0; j += nthreads) {
-      dbg_sdf[ray * S0 + j] = s_sdf[j];
-      dbg_w[ray * S0 + j] = s_w[j];
-    }
-  (void)s_scalar;
+  importance_merge(L, ray, nearv, farv, S0, n_imp, lin_u, u_rand, u_rand_cols, base_inv_s, bins_out,
+                   starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w, tid, nthreads, wave, lane);
 }
 
 inline uint32_t scramble_for(int64_t n) {

@@ -2,7 +2,7 @@
 field's SDF as the proposal, then field evaluation with alphas and compositing weights."""
 from functools import partial
 
-from ponderv2_amd import fused_head
+from ponderv2_amd import fused_head, narrow_head
 from ..builder import RENDERERS
 from .base_surface_model import SurfaceModel
 
@@ -18,6 +18,9 @@ class NeuSModel(SurfaceModel):
         # every other configuration keeps the modular path below
         if fused_head.usable(self, ray_bundle, volume_feature):
             return fused_head.render_outputs(self, ray_bundle, volume_feature)
+        # narrow SDF-only heads (the nuScenes configuration): csrc/raymarch_narrow.hip
+        if narrow_head.usable(self, ray_bundle, volume_feature):
+            return narrow_head.render_outputs(self, ray_bundle, volume_feature)
         # (a projection network that left its final convolution to the fused head applies it now)
         return super().get_outputs(ray_bundle, fused_head.unfold(volume_feature), **kwargs)
 
