@@ -20,14 +20,20 @@
 //     z_l = W_l u_l + b_l                     Z_l = W_l U_l
 //     x_{l+1} = softplus(z_l)                 X_{l+1} = softplus'(z_l) * Z_l
 //     sdf = w_last . u_{L-1} + b_last         grad sdf = U_{L-1}^T w_last
-// The value and its three tangents obey the SAME linear recursion, so ONE SAMPLE = ONE QUAD OF LANES:
-// lane 0 of the quad carries (p, 1 | f), lane j = 1..3 carries (e_j, 0 | F'[:, j]); every lane runs the
-// same 16-wide multiply-adds with the weights as SCALAR operands (uniform addresses: s_load), the
-// activation slope crosses the quad by DPP.  fp32 MFMA has no rate advantage over fp32 FMA on this
-// machine, so the forward is plain VALU work; the matrix cores do the one thing that needs a
-// reduction ACROSS samples, the weight gradients:
-//     dWc_l = sum_k ub_l[k] (x) fk[k]         dW_l = sum_k zb_l[k] (x) u_l[k]      k = 4 sample + slot
-// with both operands staged once per layer in LDS as [k][16] and fed to v_mfma_f32_16x16x4_f32;
+// The value and its three tangents obey the SAME linear recursion, so a sample is FOUR SLOTS - slot 0
+// carries (p, 1 | f), slot j = 1..3 carries (e_j, 0 | F'[:, j]) - and a wave runs 64 slots (main pass) as the
+// columns of 16 x 16 x 4 fp32 MFMA products: activations stay in the accumulator layout from layer to
+// layer (the accumulator registers ARE the next product's B operand when the weight columns are read in
+// the matching order, see below), the weights are the A operands - 16 bytes per lane per product, read
+// from L1 (forward) or from an LDS copy (backward).  The four slots of a sample sit on four adjacent
+// lanes, so the activation slope crosses from the value slot to its tangents by DPP (quad_perm).
+// A first version ran the same recursion as scalar-weight FMAs (one lane = one slot, weights through
+// s_load): 18 ms for the backward - every product waited on a scalar load with one wave per SIMD;
+// the MFMA form with vector weight loads: 6.4 ms; exp / log / rcp on the hardware units instead of libm
+// (the activation was longer than the products): forward 1.8 -> 0.95 ms; parameters in LDS: 4.8 ms.
+// The weight gradients need a reduction ACROSS samples,
+//     dWc_l = sum_k ub_l[k] (x) fk[k]         dW_l = sum_k zb_l[k] (x) u_l[k]      k = slot,
+// which is one more MFMA product with both operands staged once per layer in LDS as [k][16];
 // accumulators stay in registers over a persistent loop and leave as one slab per workgroup (summed
 // in slab order afterwards: reproducible).  Backward = reverse mode through value AND tangent
 // recursion (second-order terms through grad sdf included), hand-derived; oracle/narrow_head.py states
@@ -53,7 +59,9 @@ constexpr int sW = kHd * kHd + kHd;          // W_l then b_l
 constexpr int oWl = oW + (kL - 1) * sW;
 constexpr int oBl = oWl + kHd;
 constexpr int kTheta = oBl + 1;              // 4609
-constexpr int kMaxSlabs = 1024;
+constexpr int kMaxSlabs = 2048;
+constexpr int kBwdNcb = 2;   // column blocks per round of the backward: 32 slots = 8 samples.  Measured: 4.8 ms against
+                             // 8.1 ms with 4 - its LDS tiles (56 KB with the parameters) leave two waves per CU
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -62,105 +70,200 @@ __device__ __forceinline__ float dpp_f(float v) {
 }
 #define PV2_QUAD_BCAST0(v) dpp_f<0x00>(v)                                         /* quad_perm [0,0,0,0] */
 #define PV2_QUAD_SUM(v) ((v) = (v) + dpp_f<0xB1>(v), (v) = (v) + dpp_f<0x4E>(v))  /* [1,0,3,2], [2,3,0,1] */
+#define PV2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// this lane's feature vector: f (slot 0) or d f / d p_j (slot j) - the trilinear corner model with the
-// lane's own corner coefficients; `offs` / `coef` are kept for the scatter of the backward
-__device__ __forceinline__ void gather_fk(const Vol& vol, int scene, float px, float py, float pz, int q,
-                                          float (&fk)[kC], int64_t (&offs)[8], float (&coef)[8]) {
+// ------------------------------------------------------------------------------------------
+// One wave = 64 SLOTS = four column blocks of 16.  Lane (n = lane & 15, g = lane >> 4) owns column n
+// of every block.  Matrices [rows x slots] live in the MFMA accumulator layout: f32x4 D[cb], component
+// r = row 4 g + r of slot 16 cb + n.  The same registers are the B operand of the NEXT product when
+// component r is fed at reduction step r: the MFMA then reads it as B[k = 4 r + g], so the A operand of
+// step r must carry the weight column of row-unit 4 kq + r - for lane (m, kq) that is W[m][4 kq + r],
+// four CONSECUTIVE floats of row m.  No value ever moves between lanes on the way through the layers.
+// Features use the same trick on 32 channels: lane (n, g) holds channels 8 g .. 8 g + 7 of its slots
+// (two 16-byte loads per corner), step s of 8 pairs them with A = Wc[m][8 kq + s].
+// In the main pass a slot is (sample, q): q = n & 3 = 0 the value, 1..3 the tangents d/dp_q, so the
+// four slots of a sample are four adjacent lanes; in the coarse pass every slot is a value.
+// ------------------------------------------------------------------------------------------
+template <int NCB>
+struct Feat {
+  float v[NCB][8];   // [cb][s] = channel 8 g + s of slot 16 cb + n
+};
+
+// Softplus(beta = 100, threshold = 20) with its first two derivatives on the hardware exp / log / rcp
+// units (1 ulp each): ~8 instructions per element where the libm forms take ~50 - the activation, not
+// the matrix products, was the longest part of a layer.  log(1 + e) instead of log1p(e) costs at most
+// 6e-8 / 100 ABSOLUTE on a value that is >= 0 and enters sums of O(1) terms.
+__device__ __forceinline__ void softplus_fast(float h, float* sp, float* d1, float* d2) {
+  const float bx = 100.f * h;
+  const float e = __expf(fminf(bx, 20.f));
+  const float r = __frcp_rn(1.f + e);
+  const bool lin = bx > 20.f;
+  const float s = e * r;
+  *sp = lin ? h : __logf(1.f + e) * 0.01f;
+  *d1 = lin ? 1.f : s;
+  *d2 = lin ? 0.f : 100.f * s * r;    // s (1 - s) = e / (1 + e)^2
+}
+
+// trilinear feature (q = 0) or its derivative along p_q of one slot, this lane's 8 channels
+__device__ __forceinline__ void gather8(const Vol& vol, int scene, float px, float py, float pz, int q,
+                                        int g, float (&f)[8]) {
   const Axes ax = make_axes(px, py, pz, vol);
 #pragma unroll
-  for (int j = 0; j < kC; ++j) fk[j] = 0.f;
+  for (int j = 0; j < 8; ++j) f[j] = 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
+    int64_t off;
     float w, dx, dy, dz;
-    const bool ok = corner(ax, vol, scene, c, kC, &offs[c], &w, &dx, &dy, &dz);
-    coef[c] = q == 0 ? w : (q == 1 ? dx : (q == 2 ? dy : dz));
-    if (ok) {
-#pragma unroll
-      for (int j = 0; j < kC / 4; ++j) {
-        const float4 v = ldg4(vol.p + offs[c] + 4 * j);
-        fk[4 * j + 0] += coef[c] * v.x;
-        fk[4 * j + 1] += coef[c] * v.y;
-        fk[4 * j + 2] += coef[c] * v.z;
-        fk[4 * j + 3] += coef[c] * v.w;
-      }
-    } else {
-      offs[c] = -1;
+    if (corner(ax, vol, scene, c, kC, &off, &w, &dx, &dy, &dz)) {
+      const float cf = q == 0 ? w : (q == 1 ? dx : (q == 2 ? dy : dz));
+      const float4 a = ldg4(vol.p + off + 8 * g), b = ldg4(vol.p + off + 8 * g + 4);
+      f[0] += cf * a.x;
+      f[1] += cf * a.y;
+      f[2] += cf * a.z;
+      f[3] += cf * a.w;
+      f[4] += cf * b.x;
+      f[5] += cf * b.y;
+      f[6] += cf * b.z;
+      f[7] += cf * b.w;
     }
   }
 }
 
-// u = x + Wc_l fk + bc_l a3   (a3 = 1 on value lanes, 0 on tangent lanes)
-__device__ __forceinline__ void layer_in(const float* __restrict__ wc, const float (&x)[kHd],
-                                         const float (&fk)[kC], float a3, float (&u)[kHd]) {
+// D[cb] += Wc F   (Wc [H, C] row-major)
+template <int NCB>
+__device__ __forceinline__ void mm_in(const float* __restrict__ wc, int n, int g, const Feat<NCB>& F,
+                                      f32x4 (&D)[NCB]) {
+  const float4 a0 = ldg4(wc + n * kC + 8 * g), a1 = ldg4(wc + n * kC + 8 * g + 4);
+  const float A[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-  for (int m = 0; m < kHd; ++m) {
-    float acc = fmaf(wc[kHd * kC + m], a3, x[m]);
+  for (int s = 0; s < 8; ++s)
 #pragma unroll
-    for (int c = 0; c < kC; ++c) acc = fmaf(wc[m * kC + c], fk[c], acc);
-    u[m] = acc;
+    for (int cb = 0; cb < NCB; ++cb) D[cb] = PV2_MFMA(A[s], F.v[cb][s], D[cb]);
+}
+// D[cb] += W U   (W [H, H] row-major; U in accumulator layout)
+template <int NCB>
+__device__ __forceinline__ void mm_lin(const float* __restrict__ w, int n, int g, const f32x4 (&U)[NCB],
+                                       f32x4 (&D)[NCB]) {
+  const float4 a = ldg4(w + n * kHd + 4 * g);
+  const float A[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) D[cb] = PV2_MFMA(A[r], U[cb][r], D[cb]);
+}
+// D[cb] += W^T Z
+template <int NCB>
+__device__ __forceinline__ void mm_lin_t(const float* __restrict__ w, int n, int g, const f32x4 (&Z)[NCB],
+                                         f32x4 (&D)[NCB]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float a = w[(4 * g + r) * kHd + n];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) D[cb] = PV2_MFMA(a, Z[cb][r], D[cb]);
   }
 }
-// z = W_l u + b_l a3
-__device__ __forceinline__ void layer_lin(const float* __restrict__ w, const float (&u)[kHd], float a3,
-                                          float (&z)[kHd]) {
+// Fb[rb][cb] += (Wc^T U)[16 rb .. 16 rb + 15]   (rows = channels)
+template <int NCB>
+__device__ __forceinline__ void mm_in_t(const float* __restrict__ wc, int n, int g, const f32x4 (&U)[NCB],
+                                        f32x4 (&Fb)[2][NCB]) {
 #pragma unroll
-  for (int m = 0; m < kHd; ++m) {
-    float acc = w[kHd * kHd + m] * a3;
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int h = 0; h < kHd; ++h) acc = fmaf(w[m * kHd + h], u[h], acc);
-    z[m] = acc;
+    for (int r = 0; r < 4; ++r) {
+      const float a = wc[(4 * g + r) * kC + 16 * rb + n];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) Fb[rb][cb] = PV2_MFMA(a, U[cb][r], Fb[rb][cb]);
+    }
+}
+
+__device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int g, float a3) {
+  const float4 v = ldg4(b + 4 * g);
+  return f32x4{v.x * a3, v.y * a3, v.z * a3, v.w * a3};
+}
+
+// x_0 = pf (Wp a + bp a3) as one K = 4 product: A = [Wp | bp], B = (a_0, a_1, a_2, a3) of the slot
+template <int NCB>
+__device__ __forceinline__ void first_layer(const float* __restrict__ th, float pf, int n, int g,
+                                            const float (&avec)[NCB], f32x4 (&X)[NCB]) {
+  const float a = g < 3 ? th[oWp + 3 * n + g] : th[oBp + n];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    X[cb] = PV2_MFMA(a, avec[cb], (f32x4{0.f, 0.f, 0.f, 0.f}));
+    X[cb] *= pf;
   }
 }
 
-// The recursion on one lane.  QUAD: lanes 1..3 of a quad are tangent lanes and take the activation
-// slope from lane 0; otherwise every lane is a value lane (coarse pass).  u_lds != nullptr: this
-// lane's u_l row is stored at u_lds + l * 64 * kHd (backward).  Returns sdf (value) / grad_j (tangent).
-template <bool QUAD>
-__device__ __forceinline__ float narrow_forward(const float* __restrict__ th, float pf,
-                                                const float (&fk)[kC], float a0, float a1, float a2,
-                                                float a3, bool is_value, float* u_lds) {
-  float x[kHd], u[kHd], z[kHd];
+// softplus(beta = 100) on the value slots, slope * Z on the tangent slots (QUAD); value everywhere otherwise
+template <bool QUAD, int NCB>
+__device__ __forceinline__ void activate(const f32x4 (&Z)[NCB], bool is_value, f32x4 (&X)[NCB]) {
 #pragma unroll
-  for (int m = 0; m < kHd; ++m)
-    x[m] = pf * (th[oWp + 3 * m] * a0 + th[oWp + 3 * m + 1] * a1 + th[oWp + 3 * m + 2] * a2 +
-                 th[oBp + m] * a3);
-#pragma unroll 1
-  for (int l = 0; l < kL - 1; ++l) {
-    layer_in(th + oWc + l * sWc, x, fk, a3, u);
-    if (u_lds) {
+  for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int m = 0; m < kHd; m += 4)
-        *reinterpret_cast<float4*>(u_lds + l * 64 * kHd + m) = make_float4(u[m], u[m + 1], u[m + 2], u[m + 3]);
-    }
-    layer_lin(th + oW + l * sW, u, a3, z);
-#pragma unroll
-    for (int m = 0; m < kHd; ++m) {
+    for (int r = 0; r < 4; ++r) {
       float sp, d1, d2;
-      softplus100(z[m], &sp, &d1, &d2);
+      softplus_fast(Z[cb][r], &sp, &d1, &d2);
       if (QUAD) {
         const float s = PV2_QUAD_BCAST0(d1);
-        x[m] = is_value ? sp : s * z[m];
+        X[cb][r] = is_value ? sp : s * Z[cb][r];
       } else {
-        x[m] = sp;
+        X[cb][r] = sp;
       }
     }
-  }
-  layer_in(th + oWc + (kL - 1) * sWc, x, fk, a3, u);
-  if (u_lds) {
+}
+
+template <int NCB>
+__device__ __forceinline__ void store_rows16(float* base, int ld, int n, int g, const f32x4 (&D)[NCB]) {
 #pragma unroll
-    for (int m = 0; m < kHd; m += 4)
-      *reinterpret_cast<float4*>(u_lds + (kL - 1) * 64 * kHd + m) =
-          make_float4(u[m], u[m + 1], u[m + 2], u[m + 3]);
-  }
-  float out = th[oBl] * a3;
+  for (int cb = 0; cb < NCB; ++cb)
+    *reinterpret_cast<float4*>(base + (16 * cb + n) * ld + 4 * g) =
+        make_float4(D[cb][0], D[cb][1], D[cb][2], D[cb][3]);
+}
+
+// The recursion of one wave.  Returns, per column block, w_last . u_{L-1} (+ b_last a3) summed over the
+// lane's four rows ONLY - the caller adds the four row groups.  s_u != nullptr: every u_l is stored as
+// [l][slot][16] (backward).
+template <bool QUAD, int NCB>
+__device__ __forceinline__ void narrow_forward(const float* __restrict__ th, float pf, int n, int g,
+                                               const Feat<NCB>& F, const float (&avec)[NCB], float a3,
+                                               bool is_value, float* s_u, float (&out)[NCB]) {
+  f32x4 X[NCB], U[NCB], Z[NCB];
+  first_layer(th, pf, n, g, avec, X);
+#pragma unroll 1
+  for (int l = 0; l < kL - 1; ++l) {
+    const float* wc = th + oWc + l * sWc;
+    const f32x4 bc = bias4(wc + kHd * kC, g, a3);
 #pragma unroll
-  for (int m = 0; m < kHd; ++m) out = fmaf(th[oWl + m], u[m], out);
-  return out;
+    for (int cb = 0; cb < NCB; ++cb) U[cb] = X[cb] + bc;
+    mm_in(wc, n, g, F, U);
+    if (s_u) store_rows16(s_u + l * 16 * NCB * kHd, kHd, n, g, U);
+    const float* w = th + oW + l * sW;
+    const f32x4 bl = bias4(w + kHd * kHd, g, a3);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) Z[cb] = bl;
+    mm_lin(w, n, g, U, Z);
+    activate<QUAD, NCB>(Z, is_value, X);
+  }
+  const float* wc = th + oWc + (kL - 1) * sWc;
+  const f32x4 bc = bias4(wc + kHd * kC, g, a3);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) U[cb] = X[cb] + bc;
+  mm_in(wc, n, g, F, U);
+  if (s_u) store_rows16(s_u + (kL - 1) * 16 * NCB * kHd, kHd, n, g, U);
+  const float4 wl = ldg4(th + oWl + 4 * g);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+    out[cb] = wl.x * U[cb][0] + wl.y * U[cb][1] + wl.z * U[cb][2] + wl.w * U[cb][3] +
+              (g == 0 ? th[oBl] * a3 : 0.f);
+}
+
+__device__ __forceinline__ float rows_sum(float v) {   // over the four row groups of a column
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------
-// Coarse pass: one workgroup per ray, one THREAD per coarse sample (value only), then the shared
+// Coarse pass: one workgroup per ray, one slot per coarse sample (value only), then the shared
 // importance sampling / merge.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void narrow_coarse_kernel(
@@ -173,20 +276,32 @@ __global__ __launch_bounds__(128) void narrow_coarse_kernel(
     float* __restrict__ dbg_w) {
   __shared__ SampleLds L;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = lane & 15, g = lane >> 4;
   const int64_t ray = blockIdx.x;
   const float nearv = nears[ray], farv = fars[ray];
   const int nthreads = blockDim.x;
   coarse_bins(L, ray, nearv, farv, S0, lin_bins, t_rand, t_rand_cols, tid, nthreads);
-  if (tid < S0) {   // SDF at the start positions
+  if (wave * 64 < S0) {   // SDF at the start positions (wave-uniform)
     const int scene = (int)(ray / vol.rays_per_scene);
-    const float t = L.e[tid];
-    const float px = origins[ray * 3 + 0] + dirs[ray * 3 + 0] * t;
-    const float py = origins[ray * 3 + 1] + dirs[ray * 3 + 1] * t;
-    const float pz = origins[ray * 3 + 2] + dirs[ray * 3 + 2] * t;
-    float fk[kC], coef[8];
-    int64_t offs[8];
-    gather_fk(vol, scene, px, py, pz, 0, fk, offs, coef);
-    L.sdf[tid] = narrow_forward<false>(th, pf, fk, px, py, pz, 1.f, true, nullptr);
+    const float o0 = origins[ray * 3 + 0], o1 = origins[ray * 3 + 1], o2 = origins[ray * 3 + 2];
+    const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
+    Feat<4> F;
+    float avec[4], out[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int k = min(wave * 64 + 16 * cb + n, S0 - 1);
+      const float t = L.e[k];
+      const float px = o0 + d0 * t, py = o1 + d1 * t, pz = o2 + d2 * t;
+      gather8(vol, scene, px, py, pz, 0, g, F.v[cb]);
+      avec[cb] = g == 0 ? px : (g == 1 ? py : (g == 2 ? pz : 1.f));
+    }
+    narrow_forward<false, 4>(th, pf, n, g, F, avec, 1.f, true, nullptr, out);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const float v = rows_sum(out[cb]);
+      const int k = wave * 64 + 16 * cb + n;
+      if (g == 0 && k < S0) L.sdf[k] = v;
+    }
   }
   __syncthreads();
   importance_merge(L, ray, nearv, farv, S0, n_imp, lin_u, u_rand, u_rand_cols, base_inv_s, bins_out,
@@ -194,33 +309,62 @@ __global__ __launch_bounds__(128) void narrow_coarse_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Main pass, forward: sdf and grad sdf of every sample (one quad of lanes per sample).
+// Main pass, forward: sdf and grad sdf of every sample (16 samples = 64 slots per wave).
 // ------------------------------------------------------------------------------------------
+template <int NCB>
+struct Pos {
+  float x[NCB], y[NCB], z[NCB];
+  int scene[NCB];
+  bool valid[NCB];
+};
+
+// positions of this lane's slots (sample 4 cb + (n >> 2) of group `grp` of 4 NCB samples), their
+// features and the first layer's input vector
+template <int NCB>
+__device__ __forceinline__ void load_slots(const Vol& vol, const float* __restrict__ origins,
+                                           const float* __restrict__ dirs,
+                                           const float* __restrict__ starts, int64_t n_samples, int S,
+                                           int64_t grp, int n, int g, Pos<NCB>& P, Feat<NCB>& F,
+                                           float (&avec)[NCB]) {
+  const int q = n & 3;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int64_t smp = grp * (4 * NCB) + 4 * cb + (n >> 2);
+    P.valid[cb] = smp < n_samples;
+    const int64_t nn = P.valid[cb] ? smp : n_samples - 1;
+    const int64_t ray = nn / S;
+    P.scene[cb] = (int)(ray / vol.rays_per_scene);
+    const float t = starts[nn];
+    P.x[cb] = origins[ray * 3 + 0] + dirs[ray * 3 + 0] * t;
+    P.y[cb] = origins[ray * 3 + 1] + dirs[ray * 3 + 1] * t;
+    P.z[cb] = origins[ray * 3 + 2] + dirs[ray * 3 + 2] * t;
+    gather8(vol, P.scene[cb], P.x[cb], P.y[cb], P.z[cb], q, g, F.v[cb]);
+    if (q == 0) avec[cb] = g == 0 ? P.x[cb] : (g == 1 ? P.y[cb] : (g == 2 ? P.z[cb] : 1.f));
+    else avec[cb] = g == q - 1 ? 1.f : 0.f;
+  }
+}
+
+template <int NCB>
 __global__ __launch_bounds__(256) void narrow_field_fwd_kernel(
     Vol vol, const float* __restrict__ th, float pf, const float* __restrict__ origins,
     const float* __restrict__ dirs, const float* __restrict__ starts, int64_t n_samples, int S,
     float* __restrict__ sdf, float* __restrict__ grad) {
-  const int q = threadIdx.x & 3;
-  const int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const bool valid = n < n_samples;
-  const int64_t nn = valid ? n : n_samples - 1;
-  const int64_t ray = nn / S;
-  const int scene = (int)(ray / vol.rays_per_scene);
-  const float t = starts[nn];
-  const float px = origins[ray * 3 + 0] + dirs[ray * 3 + 0] * t;
-  const float py = origins[ray * 3 + 1] + dirs[ray * 3 + 1] * t;
-  const float pz = origins[ray * 3 + 2] + dirs[ray * 3 + 2] * t;
-  float fk[kC], coef[8];
-  int64_t offs[8];
-  gather_fk(vol, scene, px, py, pz, q, fk, offs, coef);
-  const bool is_value = q == 0;
-  const float out = narrow_forward<true>(th, pf, fk, is_value ? px : (q == 1 ? 1.f : 0.f),
-                                         is_value ? py : (q == 2 ? 1.f : 0.f),
-                                         is_value ? pz : (q == 3 ? 1.f : 0.f), is_value ? 1.f : 0.f,
-                                         is_value, nullptr);
-  if (valid) {
-    if (is_value) sdf[n] = out;
-    else grad[n * 3 + (q - 1)] = out;
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, q = n & 3;
+  const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grp * (4 * NCB) >= n_samples) return;   // (wave-uniform)
+  Pos<NCB> P;
+  Feat<NCB> F;
+  float avec[NCB], out[NCB];
+  load_slots<NCB>(vol, origins, dirs, starts, n_samples, S, grp, n, g, P, F, avec);
+  narrow_forward<true, NCB>(th, pf, n, g, F, avec, q == 0 ? 1.f : 0.f, q == 0, nullptr, out);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const float v = rows_sum(out[cb]);
+    const int64_t smp = grp * (4 * NCB) + 4 * cb + (n >> 2);
+    if (g == 0 && P.valid[cb]) {
+      if (q == 0) sdf[smp] = v;
+      else grad[smp * 3 + (q - 1)] = v;
+    }
   }
 }
 
@@ -313,49 +457,53 @@ constexpr int kLdS = 20;   // row stride of the staging tile (spreads the 16-byt
 __device__ __forceinline__ int fk_phys(int row, int col) { return row * kC + (col ^ ((row & 1) << 4)); }
 
 // dWc_l += stage^T fk,  dbc_l += column sums of the value rows of stage
+template <int NCB>
 __device__ __forceinline__ void accum_wc(const float* s_st, const float* s_fk, int lane, f32x4 (&acc)[2],
                                          float& bsum) {
   const int m16 = lane & 15, kk = lane >> 4;
 #pragma unroll
-  for (int step = 0; step < 16; ++step) {
+  for (int step = 0; step < 4 * NCB; ++step) {
     const int row = 4 * step + kk;
     const float a = s_st[row * kLdS + m16];
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s_fk[fk_phys(row, m16)], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s_fk[fk_phys(row, 16 + m16)], acc[1], 0, 0, 0);
+    acc[0] = PV2_MFMA(a, s_fk[fk_phys(row, m16)], acc[0]);
+    acc[1] = PV2_MFMA(a, s_fk[fk_phys(row, 16 + m16)], acc[1]);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bsum += s_st[(4 * (kk + 4 * i)) * kLdS + m16];   // value rows k = 4 s
+  for (int i = 0; i < NCB; ++i) bsum += s_st[(4 * (kk + 4 * i)) * kLdS + m16];   // value rows k = 4 s
 }
 // dW_l += stage^T u_l,  db_l += column sums of the value rows of stage
+template <int NCB>
 __device__ __forceinline__ void accum_w(const float* s_st, const float* s_ul, int lane, f32x4& acc,
                                         float& bsum) {
   const int m16 = lane & 15, kk = lane >> 4;
 #pragma unroll
-  for (int step = 0; step < 16; ++step) {
+  for (int step = 0; step < 4 * NCB; ++step) {
     const int row = 4 * step + kk;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_st[row * kLdS + m16], s_ul[row * kHd + m16], acc, 0, 0, 0);
+    acc = PV2_MFMA(s_st[row * kLdS + m16], s_ul[row * kHd + m16], acc);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bsum += s_st[(4 * (kk + 4 * i)) * kLdS + m16];
+  for (int i = 0; i < NCB; ++i) bsum += s_st[(4 * (kk + 4 * i)) * kLdS + m16];
 }
 
-__device__ __forceinline__ void stage_row(float* s_st, int lane, const float (&v)[kHd]) {
-#pragma unroll
-  for (int m = 0; m < kHd; m += 4)
-    *reinterpret_cast<float4*>(s_st + lane * kLdS + m) = make_float4(v[m], v[m + 1], v[m + 2], v[m + 3]);
-}
-
+template <int NCB>
 __global__ __launch_bounds__(64) void narrow_field_bwd_kernel(
-    Vol vol, const float* __restrict__ th, float pf, const float* __restrict__ origins,
+    Vol vol, const float* __restrict__ theta_g, float pf, const float* __restrict__ origins,
     const float* __restrict__ dirs, const float* __restrict__ starts, int64_t n_samples, int S,
     const float* __restrict__ ga, float* __restrict__ g_vol, float* __restrict__ slabs,
     int64_t n_groups) {
-  __shared__ __attribute__((aligned(16))) float s_u[kL * 64 * kHd];   // u_l rows, [l][k][16]
-  __shared__ __attribute__((aligned(16))) float s_fk[64 * kC];        // fk rows, swizzled
-  __shared__ __attribute__((aligned(16))) float s_st[64 * kLdS];      // bars of the current layer
-  __shared__ float s_coef[64], s_p[16 * 3];
-  const int lane = threadIdx.x, q = lane & 3, sidx = lane >> 2;
-  const int m16 = lane & 15, kk = lane >> 4;
+  constexpr int NS = 16 * NCB;   // slots per round
+  __shared__ __attribute__((aligned(16))) float s_u[kL * NS * kHd];   // u_l rows, [l][slot][16]
+  __shared__ __attribute__((aligned(16))) float s_fk[NS * kC];        // fk rows, swizzled
+  __shared__ __attribute__((aligned(16))) float s_st[NS * kLdS];      // bars of the current layer
+  __shared__ float s_coef[NS], s_p[4 * NCB * 3];
+  // the parameters, once per workgroup: with one wave per SIMD nothing hides a trip to L2 in front of
+  // every product, and the 18 KB do not survive in L1 next to the volume gathers
+  __shared__ __attribute__((aligned(16))) float s_th[(kTheta + 3) & ~3];
+  for (int i = threadIdx.x; i < kTheta; i += 64) s_th[i] = theta_g[i];
+  __syncthreads();
+  const float* th = s_th;
+  const int lane = threadIdx.x, n = lane & 15, g = lane >> 4, q = n & 3;
+  const int m16 = n, kk = g;
   const bool is_value = q == 0;
   const float a3 = is_value ? 1.f : 0.f;
 
@@ -372,123 +520,120 @@ __global__ __launch_bounds__(64) void narrow_field_bwd_kernel(
     bb[l] = 0.f;
   }
 
-  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t n = g * 16 + sidx;
-    const bool valid = n < n_samples;
-    const int64_t nn = valid ? n : n_samples - 1;
-    const int64_t ray = nn / S;
-    const int scene = (int)(ray / vol.rays_per_scene);
-    const float t = starts[nn];
-    const float px = origins[ray * 3 + 0] + dirs[ray * 3 + 0] * t;
-    const float py = origins[ray * 3 + 1] + dirs[ray * 3 + 1] * t;
-    const float pz = origins[ray * 3 + 2] + dirs[ray * 3 + 2] * t;
-    float fk[kC], coef[8];
-    int64_t offs[8];
-    gather_fk(vol, scene, px, py, pz, q, fk, offs, coef);
-    if (!valid) {
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    Pos<NCB> P;
+    Feat<NCB> F;
+    float avec[NCB], out[NCB], up[NCB];
+    load_slots<NCB>(vol, origins, dirs, starts, n_samples, S, grp, n, g, P, F, avec);
 #pragma unroll
-      for (int j = 0; j < kC; ++j) fk[j] = 0.f;
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int64_t smp = grp * (4 * NCB) + 4 * cb + (n >> 2);
+      // upstream: a = dL/dsdf on the value slot, gamma_j = dL/dgrad_j on tangent slot j
+      up[cb] = P.valid[cb] ? ga[smp * 4 + q] : 0.f;
+      if (!P.valid[cb]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) F.v[cb][j] = 0.f;
+      }
     }
-    // upstream: a = dL/dsdf on the value lane, gamma_j = dL/dgrad_j on tangent lane j
-    const float up = valid ? ga[nn * 4 + q] : 0.f;
     __syncthreads();   // the previous round's readers of the LDS tiles are done
 #pragma unroll
-    for (int j = 0; j < kC; j += 4)
-      *reinterpret_cast<float4*>(&s_fk[fk_phys(lane, j)]) = make_float4(fk[j], fk[j + 1], fk[j + 2], fk[j + 3]);
-    s_coef[lane] = up;
-    if (is_value) {
-      s_p[sidx * 3 + 0] = px;
-      s_p[sidx * 3 + 1] = py;
-      s_p[sidx * 3 + 2] = pz;
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int slot = 16 * cb + n;
+      *reinterpret_cast<float4*>(&s_fk[fk_phys(slot, 8 * g)]) =
+          make_float4(F.v[cb][0], F.v[cb][1], F.v[cb][2], F.v[cb][3]);
+      *reinterpret_cast<float4*>(&s_fk[fk_phys(slot, 8 * g + 4)]) =
+          make_float4(F.v[cb][4], F.v[cb][5], F.v[cb][6], F.v[cb][7]);
+      if (g == 0) s_coef[slot] = up[cb];
+      if (g == 0 && is_value) {
+        s_p[(slot >> 2) * 3 + 0] = P.x[cb];
+        s_p[(slot >> 2) * 3 + 1] = P.y[cb];
+        s_p[(slot >> 2) * 3 + 2] = P.z[cb];
+      }
     }
     // forward again, u_l rows into LDS
-    (void)narrow_forward<true>(th, pf, fk, is_value ? px : (q == 1 ? 1.f : 0.f),
-                               is_value ? py : (q == 2 ? 1.f : 0.f), is_value ? pz : (q == 3 ? 1.f : 0.f),
-                               a3, is_value, s_u + lane * kHd);
+    narrow_forward<true, NCB>(th, pf, n, g, F, avec, a3, is_value, s_u, out);
     __syncthreads();
 
     // last layer: sdf = w_last . u + b_last, grad_j = w_last . U_j
     {
-      float v = 0.f;   // dw_last[m16] partial over slots k = 16 kk + i
+      float v = 0.f;   // dw_last[m16] partial over slots k = 4 NCB kk + i
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = 16 * kk + i;
-        v = fmaf(s_coef[k], s_u[(kL - 1) * 64 * kHd + k * kHd + m16], v);
+      for (int i = 0; i < 4 * NCB; ++i) {
+        const int k = 4 * NCB * kk + i;
+        v = fmaf(s_coef[k], s_u[(kL - 1) * NS * kHd + k * kHd + m16], v);
       }
       wlb += v;
-      blb += is_value ? up : 0.f;
+      if (g == 0 && is_value) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) blb += up[cb];
+      }
     }
-    float ub[kHd], fkb[kC];
+    f32x4 UB[NCB], FB[2][NCB];
+    {
+      const float4 wl = ldg4(th + oWl + 4 * g);
 #pragma unroll
-    for (int m = 0; m < kHd; ++m) ub[m] = up * th[oWl + m];
-#pragma unroll
-    for (int j = 0; j < kC; ++j) fkb[j] = 0.f;
+      for (int cb = 0; cb < NCB; ++cb) {
+        UB[cb] = f32x4{wl.x, wl.y, wl.z, wl.w} * up[cb];
+        FB[0][cb] = FB[1][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
 
 #pragma unroll 1
     for (int l = kL - 1; l >= 0; --l) {
       const float* wc = th + oWc + l * sWc;
       __syncthreads();
-      stage_row(s_st, lane, ub);
+      store_rows16(s_st, kLdS, n, g, UB);
       __syncthreads();
       switch (l) {   // (uniform) - the accumulators are registers, so each layer has its own copy
-        case 0: accum_wc(s_st, s_fk, lane, accWc[0], bcb[0]); break;
-        case 1: accum_wc(s_st, s_fk, lane, accWc[1], bcb[1]); break;
-        case 2: accum_wc(s_st, s_fk, lane, accWc[2], bcb[2]); break;
-        case 3: accum_wc(s_st, s_fk, lane, accWc[3], bcb[3]); break;
-        case 4: accum_wc(s_st, s_fk, lane, accWc[4], bcb[4]); break;
-        default: accum_wc(s_st, s_fk, lane, accWc[5], bcb[5]); break;
+        case 0: accum_wc<NCB>(s_st, s_fk, lane, accWc[0], bcb[0]); break;
+        case 1: accum_wc<NCB>(s_st, s_fk, lane, accWc[1], bcb[1]); break;
+        case 2: accum_wc<NCB>(s_st, s_fk, lane, accWc[2], bcb[2]); break;
+        case 3: accum_wc<NCB>(s_st, s_fk, lane, accWc[3], bcb[3]); break;
+        case 4: accum_wc<NCB>(s_st, s_fk, lane, accWc[4], bcb[4]); break;
+        default: accum_wc<NCB>(s_st, s_fk, lane, accWc[5], bcb[5]); break;
       }
-      // fkb += Wc_l^T ub
-#pragma unroll
-      for (int m = 0; m < kHd; ++m) {
-#pragma unroll
-        for (int c = 0; c < kC; ++c) fkb[c] = fmaf(wc[m * kC + c], ub[m], fkb[c]);
-      }
+      mm_in_t(wc, n, g, UB, FB);   // fkb += Wc_l^T ub
       if (l == 0) break;
       // through x_l = softplus(z_{l-1}), X_l = softplus'(z_{l-1}) Z_{l-1}
       const float* w = th + oW + (l - 1) * sW;
-      float u[kHd], zs[kHd], zb[kHd];
+      f32x4 U[NCB], Z[NCB], ZB[NCB];
+      const f32x4 bl = bias4(w + kHd * kHd, g, a3);
 #pragma unroll
-      for (int m = 0; m < kHd; m += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(&s_u[(l - 1) * 64 * kHd + lane * kHd + m]);
-        u[m] = v.x;
-        u[m + 1] = v.y;
-        u[m + 2] = v.z;
-        u[m + 3] = v.w;
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float4 v = *reinterpret_cast<const float4*>(&s_u[(l - 1) * NS * kHd + (16 * cb + n) * kHd + 4 * g]);
+        U[cb] = f32x4{v.x, v.y, v.z, v.w};
+        Z[cb] = bl;
       }
-      layer_lin(w, u, a3, zs);   // z (value lane) / Z_j (tangent lanes)
+      mm_lin(w, n, g, U, Z);   // z (value slots) / Z_j (tangent slots)
 #pragma unroll
-      for (int m = 0; m < kHd; ++m) {
-        float sp, d1, d2;
-        softplus100(zs[m], &sp, &d1, &d2);
-        const float s1 = PV2_QUAD_BCAST0(d1), s2 = PV2_QUAD_BCAST0(d2);
-        float tz = is_value ? 0.f : ub[m] * zs[m];
-        PV2_QUAD_SUM(tz);
-        zb[m] = is_value ? ub[m] * s1 + tz * s2 : s1 * ub[m];
-      }
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sp, d1, d2;
+          softplus_fast(Z[cb][r], &sp, &d1, &d2);
+          const float s1 = PV2_QUAD_BCAST0(d1), s2 = PV2_QUAD_BCAST0(d2);
+          float tz = is_value ? 0.f : UB[cb][r] * Z[cb][r];
+          PV2_QUAD_SUM(tz);
+          ZB[cb][r] = is_value ? UB[cb][r] * s1 + tz * s2 : s1 * UB[cb][r];
+        }
       __syncthreads();
-      stage_row(s_st, lane, zb);
+      store_rows16(s_st, kLdS, n, g, ZB);
       __syncthreads();
       switch (l - 1) {
-        case 0: accum_w(s_st, s_u + 0 * 64 * kHd, lane, accW[0], bb[0]); break;
-        case 1: accum_w(s_st, s_u + 1 * 64 * kHd, lane, accW[1], bb[1]); break;
-        case 2: accum_w(s_st, s_u + 2 * 64 * kHd, lane, accW[2], bb[2]); break;
-        case 3: accum_w(s_st, s_u + 3 * 64 * kHd, lane, accW[3], bb[3]); break;
-        default: accum_w(s_st, s_u + 4 * 64 * kHd, lane, accW[4], bb[4]); break;
+        case 0: accum_w<NCB>(s_st, s_u + 0 * NS * kHd, lane, accW[0], bb[0]); break;
+        case 1: accum_w<NCB>(s_st, s_u + 1 * NS * kHd, lane, accW[1], bb[1]); break;
+        case 2: accum_w<NCB>(s_st, s_u + 2 * NS * kHd, lane, accW[2], bb[2]); break;
+        case 3: accum_w<NCB>(s_st, s_u + 3 * NS * kHd, lane, accW[3], bb[3]); break;
+        default: accum_w<NCB>(s_st, s_u + 4 * NS * kHd, lane, accW[4], bb[4]); break;
       }
-      // ub = W_{l-1}^T zb
 #pragma unroll
-      for (int h = 0; h < kHd; ++h) ub[h] = 0.f;
-#pragma unroll
-      for (int m = 0; m < kHd; ++m) {
-#pragma unroll
-        for (int h = 0; h < kHd; ++h) ub[h] = fmaf(w[m * kHd + h], zb[m], ub[h]);
-      }
+      for (int cb = 0; cb < NCB; ++cb) UB[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm_lin_t(w, n, g, ZB, UB);   // ub = W_{l-1}^T zb
     }
     // x_0 = pf (Wp p + bp), X_0 = pf Wp: the staging tile holds ub = bars of x_0 / X_0
     {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NCB; ++i) {
         const int s = kk + 4 * i;
         const float xb = s_st[(4 * s) * kLdS + m16];
         bpb += xb;
@@ -496,22 +641,30 @@ __global__ __launch_bounds__(64) void narrow_field_bwd_kernel(
         for (int a = 0; a < 3; ++a) wpb[a] += xb * s_p[s * 3 + a] + s_st[(4 * s + 1 + a) * kLdS + m16];
       }
     }
-    // volume: gV[corner] += sum over the quad of coef * fkb
+    // volume: gV[corner] += sum over the sample's four slots of coef * fkb; this lane holds channels
+    // 16 rb + 4 g + r of its slots and adds two of the eight after the quad sum
     if (g_vol) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int64_t off = offs[c];   // (the corner rows are the sample's: same on the four lanes)
-        float v[kC];
+      for (int cb = 0; cb < NCB; ++cb) {
+        const Axes ax = make_axes(P.x[cb], P.y[cb], P.z[cb], vol);
 #pragma unroll
-        for (int j = 0; j < kC; ++j) {
-          v[j] = coef[c] * fkb[j];
-          PV2_QUAD_SUM(v[j]);
-        }
-        if (valid && off >= 0) {   // lane q adds channels 8 q .. 8 q + 7
+        for (int c = 0; c < 8; ++c) {
+          int64_t off;
+          float w, dx, dy, dz;
+          const bool ok = corner(ax, vol, P.scene[cb], c, kC, &off, &w, &dx, &dy, &dz);
+          const float cf = q == 0 ? w : (q == 1 ? dx : (q == 2 ? dy : dz));
+          float v[8];
 #pragma unroll
-          for (int j = 0; j < kC / 4; ++j) {
-            const float x = q == 0 ? v[j] : (q == 1 ? v[8 + j] : (q == 2 ? v[16 + j] : v[24 + j]));
-            atomicAdd(g_vol + off + 8 * q + j, x);
+          for (int j = 0; j < 8; ++j) {
+            v[j] = cf * FB[j >> 2][cb][j & 3];
+            PV2_QUAD_SUM(v[j]);
+          }
+          if (ok && P.valid[cb]) {   // (same for the four lanes of the sample) lane q: v[2 q], v[2 q + 1]
+            const float x0 = q == 0 ? v[0] : (q == 1 ? v[2] : (q == 2 ? v[4] : v[6]));
+            const float x1 = q == 0 ? v[1] : (q == 1 ? v[3] : (q == 2 ? v[5] : v[7]));
+            float* dst = g_vol + off + 16 * (q >> 1) + 4 * g + 2 * (q & 1);
+            atomicAdd(dst, x0);
+            atomicAdd(dst + 1, x1);
           }
         }
       }
@@ -527,38 +680,28 @@ __global__ __launch_bounds__(64) void narrow_field_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         slab[oWc + l * sWc + (4 * kk + r) * kC + 16 * tcol + m16] = accWc[l][tcol][r];
-    float v = bcb[l];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    const float v = rows_sum(bcb[l]);
     if (lane < 16) slab[oWc + l * sWc + kHd * kC + lane] = v;
   }
 #pragma unroll
   for (int l = 0; l < kL - 1; ++l) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[oW + l * sW + (4 * kk + r) * kHd + m16] = accW[l][r];
-    float v = bb[l];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    const float v = rows_sum(bb[l]);
     if (lane < 16) slab[oW + l * sW + kHd * kHd + lane] = v;
   }
   {
-    float v = wlb;
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    const float v = rows_sum(wlb);
     if (lane < 16) slab[oWl + lane] = v;
     float b = blb;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) b += __shfl_xor(b, o);
     if (lane == 0) slab[oBl] = b;
-    float bp = bpb;
-    bp += __shfl_xor(bp, 16);
-    bp += __shfl_xor(bp, 32);
+    const float bp = rows_sum(bpb);
     if (lane < 16) slab[oBp + lane] = pf * bp;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      float w = wpb[a];
-      w += __shfl_xor(w, 16);
-      w += __shfl_xor(w, 32);
+      const float w = rows_sum(wpb[a]);
       if (lane < 16) slab[oWp + 3 * lane + a] = pf * w;
     }
   }
@@ -619,7 +762,7 @@ int pv2_narrow_field_forward(const float* volume, int vol_b, int vol_z, int vol_
   const int64_t n = n_rays * n_samples;
   PV2_REQUIRE(n < 0x7fffffffLL * 32, "pv2_narrow_field_forward: too many samples");
   Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
-  hipLaunchKernelGGL(narrow_field_fwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(narrow_field_fwd_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, v, theta, points_factor, origins, dirs, starts, n, n_samples, sdf,
                      grad);
   hipLaunchKernelGGL(narrow_composite_fwd_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0,
@@ -629,7 +772,7 @@ int pv2_narrow_field_forward(const float* volume, int vol_b, int vol_z, int vol_
 }
 
 int64_t pv2_narrow_backward_slabs(int64_t n_rays, int n_samples) {
-  const int64_t groups = (n_rays * n_samples + 15) / 16;
+  const int64_t groups = (n_rays * n_samples + 4 * kBwdNcb - 1) / (4 * kBwdNcb);
   return groups < kMaxSlabs ? (groups < 1 ? 1 : groups) : kMaxSlabs;
 }
 
@@ -649,11 +792,10 @@ int pv2_narrow_field_backward(const float* volume, int vol_b, int vol_z, int vol
   hipLaunchKernelGGL(narrow_composite_bwd_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0,
                      (hipStream_t)stream, sdf, grad, dirs, starts, deltas, inv_s, n_rays, n_samples,
                      weights, trans, g_comp, g_weights, g_sdf, g_grad, work, g_inv_s_part);
-  const int64_t groups = (n + 15) / 16;
   const int64_t slabs = pv2_narrow_backward_slabs(n_rays, n_samples);
-  hipLaunchKernelGGL(narrow_field_bwd_kernel, dim3((unsigned)slabs), dim3(64), 0, (hipStream_t)stream, v,
-                     theta, points_factor, origins, dirs, starts, n, n_samples, work, g_volume,
-                     g_theta_slabs, groups);
+  hipLaunchKernelGGL(narrow_field_bwd_kernel<kBwdNcb>, dim3((unsigned)slabs), dim3(64), 0,
+                     (hipStream_t)stream, v, theta, points_factor, origins, dirs, starts, n, n_samples, work,
+                     g_volume, g_theta_slabs, (n + 4 * kBwdNcb - 1) / (4 * kBwdNcb));
   return pv2::check_launch("narrow_field_backward");
 }
 

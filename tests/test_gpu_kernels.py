@@ -736,3 +736,45 @@ def test_small_inverse_matches_float64_inverse(device, n, batch):
     assert err.max() <= max(2 * lib_err.max(), 3e-7)            # at least as accurate as the library's fp32 LU
     # batch dimensions are kept: (B, V, n, n) as the pose stack arrives
     assert torch.equal(_inv(x[None]), got[None])
+
+
+@pytest.mark.parametrize("kind", ["SGD", "AdamW"])
+def test_lean_fused_optimizer_steps_equal_torch(device, kind):
+    """utils/optimizer.py replaces the per-step Python of torch's fused SGD / AdamW by direct calls of
+    the same multi-tensor kernels on cached lists: parameters and optimizer state after several steps
+    under a OneCycle schedule EQUAL torch's own fused step bit for bit - including a parameter that
+    never receives a gradient and one whose gradient disappears for a step."""
+    from ponderv2_amd.ponder.utils.optimizer import build_optimizer
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4)).to(device)
+        m.unused = torch.nn.Parameter(torch.ones(3, device=device))
+        return m
+
+    cfg = (dict(type="SGD", lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True) if kind == "SGD"
+           else dict(type="AdamW", lr=2e-3, weight_decay=0.01))
+    ours, ref = make(), make()
+    opt = build_optimizer(dict(cfg), ours)
+    cls = torch.optim.SGD if kind == "SGD" else torch.optim.AdamW
+    ref_opt = cls(ref.parameters(), fused=True, **{k: v for k, v in cfg.items() if k != "type"})
+    if kind == "SGD":
+        for p in ref.parameters():      # (build_optimizer creates the momentum buffers up front)
+            ref_opt.state[p]["momentum_buffer"] = torch.zeros_like(p)
+    scheds = [torch.optim.lr_scheduler.OneCycleLR(o, max_lr=cfg["lr"], total_steps=12) for o in (opt, ref_opt)]
+    assert type(opt.step.__func__).__name__ == "function" and opt.step.__func__.__name__ == "step"
+    x = torch.randn(5, 8, device=device)
+    for it in range(8):
+        for m, o, sc in ((ours, opt, scheds[0]), (ref, ref_opt, scheds[1])):
+            o.zero_grad(set_to_none=True)
+            loss = m(x).square().sum() if it != 4 else m[1](torch.randn(5, 16, device=device, generator=None) * 0 + 1).sum()
+            loss.backward()
+            o.step()
+            sc.step()
+    for (n, a), (_, b) in zip(ours.named_parameters(), ref.named_parameters()):
+        assert torch.equal(a, b), n
+    sa, sb = opt.state_dict()["state"], ref_opt.state_dict()["state"]
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        for name in sa[k]:
+            assert torch.equal(torch.as_tensor(sa[k][name]).float().cpu(), torch.as_tensor(sb[k][name]).float().cpu()), (k, name)

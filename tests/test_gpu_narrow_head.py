@@ -99,11 +99,11 @@ def _run(device, **kw):
     return flips, rows
 
 
-def _check(flips, rows):
+def _check(flips, rows, bins_tol=1e-4):
     assert flips <= 2, rows
     for name, err in rows:
         if name.startswith("coarse.bins") or name.startswith("coarse.starts"):
-            assert err <= 1e-4, (name, err)
+            assert err <= bins_tol, (name, err)
             continue
         tol = 5e-4 if name.endswith("inv_s") else REL_TOL
         assert err <= tol, (name, err)
@@ -122,7 +122,10 @@ def test_narrow_head_ragged_sizes_vs_oracle(device):
 
 def test_narrow_head_points_outside_the_volume(device):
     """Rays that leave the unit cube: zero padding on both passes, no gradient outside."""
-    _check(*_run(device, seed=2, scale=2.5))
+    # (far from any surface the section alphas are (e1 - e2 + 1e-5) / (e1 + 1e-5) with e1 - e2 ~ 1e-7:
+    # fp32 round-off of that difference is ~1 % of the weight, which the inverse cdf turns into a
+    # shift of up to 1e-3 of the unit interval - in any fp32 evaluation, the reference's included)
+    _check(*_run(device, seed=2, scale=2.5), bins_tol=1e-3)
 
 
 def test_narrow_head_is_the_default_outdoor_render_path(device):

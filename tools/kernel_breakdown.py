@@ -17,7 +17,7 @@ RULES = (  # first match wins
     ("dense U-Net convs + BatchNorm (MIOpen / CK / hipBLASLt)", ("ck::", "_ZN2ck", "Cijk", "MIOpen", "miopen")),
     ("fills", ("zero_words", "fillBuffer", "FillFunctor")),
     ("sparse BatchNorm + column sums", ("col_partials", "col_combine", "bn_", "col_sum")),
-    ("fused ray march", ("field_", "coarse_sample", "volume_scatter", "weights_", "accumulate_", "fold_")),
+    ("fused ray march", ("field_", "coarse_sample", "volume_scatter", "weights_", "accumulate_", "fold_", "narrow_")),
     ("optimizer", ("multi_tensor", "sgd", "Sgd")),
     ("rulebook build", ("rocprim", "table", "hash", "down_", "tile_prefix", "fill_i32", "pair_positions")),
     ("dense max-pool / concat / split (hand-written)", ("maxpool3d", "concat_rows", "split_rows", "small_inverse")),

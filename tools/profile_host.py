@@ -7,17 +7,18 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench
 from ponderv2_amd.ponder.models import build_model
 from ponderv2_amd.ponder.utils.config import ConfigDict
+from ponderv2_amd.ponder.utils.optimizer import build_optimizer
 
 dev = torch.device("cuda:0")
 OUTDOOR = "--outdoor" in sys.argv
 AMP = torch.bfloat16 if "--amp" in sys.argv else None  # the scoped reduced-precision mode (bench.py --amp bf16)
 if OUTDOOR:
     model = build_model(ConfigDict(bench.outdoor_model_cfg())).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01)
+    opt = build_optimizer(dict(type="AdamW", lr=2e-4, weight_decay=0.01), model)
     batch = bench.make_outdoor_batch(0, 4, 512, dev)
 else:
     model = build_model(ConfigDict(bench.model_cfg(256, "float32"))).to(dev).train()
-    opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    opt = build_optimizer(dict(type="SGD", lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4), model)
     batch = bench.make_batch(0, 2, 2, dev)
 PREFETCH = "--prefetch" in sys.argv
 staged = [model.prefetch(bench.clone_batch(batch)) if PREFETCH else bench.clone_batch(batch)]
