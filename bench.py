@@ -931,6 +931,9 @@ def main():
                        "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
             "backward_side_stream": side_state,
+            "optimizer": "%s%s, %d group updates on cached lists (utils/optimizer.py)" % (
+                type(opt).__name__, " (fused)" if opt.defaults.get("fused") else "",
+                getattr(opt, "_pv2_lean_steps", 0)),
             "render_head": (("fused ray-march kernels (csrc/raymarch_fused.hip)"
                              + (", UNet3D's final 1x1x1 convolution folded in per sample"
                                 if fused_head.FOLD_ENABLED else ""))

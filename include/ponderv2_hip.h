@@ -335,6 +335,8 @@ int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, co
  *                  gsum, dy (scratch, kept until the side stream has joined), dres (or NULL), dx (or
  *                  NULL; dx_accumulate != 0: ADD to what dx holds - an earlier record wrote this
  *                  activation's gradient first; for CONCAT the flag applies to dres), dweight.
+ *                  STEM with dx != NULL (the input features carry a gradient: a learnable mask token
+ *                  was written into them): weight_t = the weight transposed to [c_in, K, c_out].
  * Workspaces as for pv2_convbn_*: prod_ws >= max pairs x channels floats, stats_ws =
  * pv2_bn_workspace_floats(max channels), part_ws the weight gradient's partial sums (side stream).
  * ------------------------------------------------------------------------------------------ */
@@ -363,6 +365,7 @@ typedef struct pv2_unet_op {
   float* dres;
   float* dx;
   float* dweight;
+  const float* weight_t;   /* STEM only, with dx: the weight as [c_in, K, c_out] (grad-input pass) */
   float eps, momentum;
 } pv2_unet_op;
 int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,

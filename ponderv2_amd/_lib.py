@@ -37,7 +37,8 @@ class UnetOp(Structure):
                 + [("geom", POINTER(ConvGeom))]
                 + [(k, c_void_p) for k in ("nbr", "x", "residual", "weight", "bn_weight", "bn_bias",
                                            "running_mean", "running_var", "y_conv", "mean_invstd",
-                                           "out", "grad_out", "dy", "gsum", "dres", "dx", "dweight")]
+                                           "out", "grad_out", "dy", "gsum", "dres", "dx", "dweight",
+                                           "weight_t")]
                 + [("eps", c_float), ("momentum", c_float)])
 
 
@@ -51,7 +52,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),

@@ -123,6 +123,14 @@ int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* 
           e = pv2::spconv_wgrad(u.x, u.n_in, u.c_in, u.dy, u.n_out, u.c_out, u.K, u.geom->pair_in,
                                 u.geom->pair_out, u.geom->kstart, u.geom->tile_start_w,
                                 u.geom->tile_pairs_w, u.geom->n_tiles_w, u.dweight, prod_ws, s);
+        if (e == PV2_OK && u.dx) {
+          // the input features carry a gradient (a learnable mask token was written into them): the same
+          // gather table walked with mirrored offsets and the transposed weight (submanifold: in == out)
+          PV2_REQUIRE(u.weight_t != nullptr && u.n_in == u.n_out && !u.dx_accumulate,
+                      "pv2_unet_backward: stem grad-input needs weight_t");
+          e = pv2_spconv_os_forward(u.dy, u.n_out, u.c_out, u.weight_t, u.K, u.c_in, u.nbr, u.nbr_stride,
+                                    nullptr, !u.kflip, nullptr, u.dx, u.n_in, stream);
+        }
         break;
       }
       case PV2_UNET_CONCAT:

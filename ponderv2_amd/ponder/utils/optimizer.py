@@ -102,6 +102,7 @@ def _lean_fused_sgd_step(optimizer):
                 continue
             full = len(sel) == len(ps)
             params = ps if full else [ps[i] for i in sel]
+            optimizer._pv2_lean_steps += 1
             torch._fused_sgd_(params, [p.grad for p in params],
                               [] if group["momentum"] == 0 else (bufs if full else [bufs[i] for i in sel]),
                               weight_decay=group["weight_decay"], momentum=group["momentum"],
@@ -114,6 +115,7 @@ def _lean_fused_sgd_step(optimizer):
 
     optimizer.register_load_state_dict_post_hook(lambda opt: cache.clear())
     optimizer.step = types.MethodType(step, optimizer)
+    optimizer._pv2_lean_steps = 0   # group updates that took the short route (tests read it)
     return optimizer
 
 
@@ -162,6 +164,7 @@ def _lean_fused_adam_step(optimizer):
         for group, (ps, m1, m2, steps, _, _) in zip(optimizer.param_groups, plans):
             beta1, beta2 = group["betas"]
             decoupled = isinstance(optimizer, torch.optim.AdamW) or group.get("decoupled_weight_decay", False)
+            optimizer._pv2_lean_steps += 1
             torch._foreach_add_(steps, 1)
             (torch._fused_adamw_ if decoupled else torch._fused_adam_)(
                 ps, [p.grad for p in ps], m1, m2, [], steps, amsgrad=False, lr=group["lr"],
@@ -173,6 +176,7 @@ def _lean_fused_adam_step(optimizer):
 
     optimizer.register_load_state_dict_post_hook(lambda opt: cache.clear())
     optimizer.step = types.MethodType(step, optimizer)
+    optimizer._pv2_lean_steps = 0
     return optimizer
 
 

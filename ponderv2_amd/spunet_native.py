@@ -234,7 +234,7 @@ def build_plan(model, x, condition=None, context=None):
 def supported(model, x) -> bool:
     return (ENABLED and K.USE_PR == "all" and K.USE_CONVBN and x.features.is_cuda and model.training
             and not getattr(model, "cls_mode", False) and x.features.dtype == torch.float32
-            and not x.features.requires_grad and precision.sparse_dtype() is None
+            and precision.sparse_dtype() is None
             and x.indices.shape[0] > 1 and torch.is_grad_enabled())
 
 
@@ -341,8 +341,9 @@ class SpUNetFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         arena = _Arena()
         g_off = [None] * len(plan.acts)
+        want_dx = ctx.needs_input_grad[0]   # (a learnable mask token was written into the input features)
         for a, (rows, ch) in enumerate(plan.acts):
-            if a != 0 and a != plan.out_act:
+            if (a != 0 or want_dx) and a != plan.out_act:
                 g_off[a] = arena.reserve(rows * ch)
         for u in plan.units:
             if u.kind == UNET_CONCAT:
@@ -365,6 +366,9 @@ class SpUNetFunction(torch.autograd.Function):
             if u.kind == UNET_CONV_BN:
                 part_floats = max(part_floats, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
                     u.c_in, u.c_out, u.geom.n_tiles_w)))
+            elif want_dx:   # the stem's grad-input pass reads the weight as [c_in, K, c_out]
+                w_t = tensors[u.w_index].detach().permute(2, 1, 0).contiguous()
+                op.weight_t = w_t.data_ptr()
         # weight gradients on the backward side stream when every one of them is only stored
         weights = [tensors[u.w_index] for u in plan.units if u.kind == UNET_CONV_BN]
         side = None
@@ -388,4 +392,5 @@ class SpUNetFunction(torch.autograd.Function):
             grads[i + 1] = gsum[u.c_out:]
             grads[i + 2] = gsum[:u.c_out]
         ctx.plan = None
-        return (None, None) + tuple(grads)
+        g_feats = arena.view(g_off[0], *plan.acts[0]) if want_dx else None
+        return (g_feats, None) + tuple(grads)

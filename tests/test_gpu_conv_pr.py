@@ -335,3 +335,47 @@ def test_native_unet_equals_the_modular_walk(device, monkeypatch):
     worst = max(_rel(nat_g[n], mod_g[n]) for n in nat_g if float(mod_g[n].abs().max()) > 1e-6)
     print("native vs modular gradients: global", (num / den) ** 0.5, "worst tensor", worst)
     assert (num / den) ** 0.5 < 1e-3 and worst < 5e-2
+
+
+def test_native_unet_returns_the_gradient_of_its_input_features(device, monkeypatch):
+    """Block masking writes a LEARNABLE token into the input features (ponder_outdoor_base.py:93-137 /
+    masking.py), so the backbone's input carries a gradient: the native executor's stem computes it
+    (the gather table walked with mirrored offsets and the transposed weight) - equal to the modular
+    walk's, and the 4-channel lidar input (zero-padded to 8 for the kernels) gets exactly its own 4
+    columns back."""
+    from golden_cases import FULL_BACKBONE
+    from ponderv2_amd import spunet_native
+    from ponderv2_amd.ponder.models import build_model
+
+    torch.manual_seed(0)
+    model = build_model(dict(FULL_BACKBONE, in_channels=4)).to(device).train()
+    coords = random_voxels(12, batch=2, n_per_batch=5000)
+    counts = np.bincount(coords[:, 0], minlength=2)
+    feat0 = torch.randn(len(coords), 4, device=device)
+    token = torch.zeros(1, 4, device=device)
+    masked = torch.rand(len(coords), device=device) < 0.6
+    probe = None
+    res = {}
+    for native in (True, False):
+        monkeypatch.setattr(spunet_native, "ENABLED", native)
+        before = spunet_native.CALLS
+        model.zero_grad(set_to_none=True)
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.reset_running_stats()
+        tok = token.clone().requires_grad_(True)
+        feat = torch.where(masked[:, None], tok, feat0)
+        feat.retain_grad()
+        out = model(dict(grid_coord=torch.from_numpy(coords[:, 1:]).to(device), feat=feat,
+                         offset=torch.from_numpy(np.cumsum(counts)).to(device)))
+        assert (spunet_native.CALLS > before) == native
+        if probe is None:
+            probe = torch.randn_like(out)
+        (out * probe).sum().backward()
+        res[native] = (out.detach().clone(), feat.grad.clone(), tok.grad.clone(),
+                       model.conv_input[0].weight.grad.clone())
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    assert a[1].shape == feat0.shape
+    for i, name in ((1, "d features"), (2, "d token"), (3, "d stem weight")):
+        assert _rel(a[i], b[i]) < 2e-3, (name, _rel(a[i], b[i]))

@@ -40,8 +40,7 @@ def sect():
         ray = model.prepare_ray(d); t.append(time.perf_counter())
         vol = model.prepare_volume(d); t.append(time.perf_counter())
         B = vol[0].shape[0]
-        ray = {k: v.reshape(B, -1, v.shape[-1]) if k in ("ray_o", "ray_d") else v
-               for k, v in ray.items() if torch.is_tensor(v) and k != "ray_offset"}
+        ray = dict(ray)
     else:
         ray, d = model.prepare_ray(d); t.append(time.perf_counter())
         vol = model.prepare_volume(d); t.append(time.perf_counter())
