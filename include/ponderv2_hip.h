@@ -525,6 +525,29 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
                             pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-ray / per-sample loss terms of the surface-rendering models (csrc/surface_loss.hip):
+ * SurfaceModel.get_loss, ponder/models/ponder/render_utils/models/base_surface_model.py:102-211 -
+ * depth, colour (+ psnr), free-space, SDF and eikonal terms; the semantic term is not covered.
+ *   depth, depth_gt [R]; rgb, rgb_gt [R,3] or both NULL; sdf, z [R,S]; grad [R,S,3] or NULL.
+ *   weights [5] (device): depth, rgb, free_space, sdf, eikonal.  trunc = sensor_depth_truncation.
+ *   forward: out [6] = depth_loss, rgb_loss, psnr, free_space_loss, sdf_loss, eikonal_loss; sums [9] is
+ *     kept for the backward; workspace: pv2_surface_loss_workspace_floats() floats.
+ *   backward: upstream = 6 device pointers to the scalar gradients of `out` (NULL = none) ->
+ *     g_depth [R], g_rgb [R,3] (or NULL), g_sdf [R,S], g_grad [R,S,3] (or NULL), every element written.
+ * Reproducible: per-workgroup partial sums added in workgroup order.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_surface_loss_workspace_floats(void);
+int pv2_surface_loss_forward(const float* depth, const float* depth_gt, const float* rgb,
+                             const float* rgb_gt, const float* sdf, const float* z, const float* grad,
+                             int64_t n_rays, int n_samples, float trunc, const float* weights,
+                             float* workspace, float* out, float* sums, pv2_stream_t stream);
+int pv2_surface_loss_backward(const float* depth, const float* depth_gt, const float* rgb,
+                              const float* rgb_gt, const float* sdf, const float* z, const float* grad,
+                              int64_t n_rays, int n_samples, float trunc, const float* weights,
+                              const float* sums, const float* const* upstream, float* g_depth,
+                              float* g_rgb, float* g_sdf, float* g_grad, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * The NeuS head for NARROW SDF decoders (csrc/raymarch_narrow.hip): the head of the reference's
  * nuScenes configuration (configs/nuscenes/pretrain-ponder-spunet-v1m1-0-base.py: SDFField with
  * sdf_decoder = dict(in_dim=32, out_dim=16+1, hidden_size=16, n_blocks=5), no colour / semantic

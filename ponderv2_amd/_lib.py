@@ -132,6 +132,9 @@ SIGNATURES = {
     "pv2_neus_field_backward": (
         c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int] + [_P] * 7
         + [c_int, c_float] + [_P] * 9 + [_P] * 9 + [_P]),
+    "pv2_surface_loss_workspace_floats": (c_int, []),
+    "pv2_surface_loss_forward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P]),
+    "pv2_surface_loss_backward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pv2_narrow_head_dims": (c_int, [POINTER(c_int)] * 4),
     "pv2_narrow_coarse_sample": (
         c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P,

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ponderv2_amd import surface_loss
 from ..builder import build_collider, build_field, build_sampler
 from ..renderers import DepthRenderer, NormalRenderer, RGBRenderer, SemanticRenderer
 
@@ -58,11 +59,37 @@ class SurfaceModel(nn.Module):
     def forward(self, ray_bundle, volume_feature, **kwargs):
         return self.get_outputs(self.collider(ray_bundle), volume_feature, **kwargs)
 
+    def _semantic_loss(self, preds_dict, targets, valid):
+        if not self.training:
+            raise NotImplementedError("semantic loss is only defined for training (SURVEY Q2)")
+        sem_pred = F.normalize(preds_dict["semantic"], dim=-1)
+        sem_gt = targets["semantic"]
+        ok = (valid * sem_gt.any(dim=-1, keepdim=True)).squeeze(-1).bool()
+        logits = torch.mm(sem_pred, sem_gt.transpose(1, 0)) / self.loss.temperature
+        labels = torch.arange(sem_pred.shape[0], dtype=torch.long, device=sem_pred.device)
+        labels = torch.where(ok, labels, torch.full_like(labels, -100))
+        # all-ignored -> exactly 0 (cross_entropy would give nan); no host sync
+        ce = F.cross_entropy(logits, labels, reduction="sum") / ok.sum().clamp(min=1)
+        return ce * self.loss.weights.semantic_loss
+
     def get_loss(self, preds_dict, targets):
         lw = self.loss.weights
         out = {}
         depth_gt = targets["depth"]
         valid = depth_gt > 0.0
+        if surface_loss.usable(preds_dict, targets) and lw.get("sparse_points_sdf_loss", 0.0) <= 0:
+            # depth / colour / free-space / SDF / eikonal terms in three launches (csrc/surface_loss.hip);
+            # the semantic term below is the same code as on the modular route
+            fused = surface_loss.surface_losses(preds_dict, targets, self.loss)
+            for k in ("depth_loss", "rgb_loss", "psnr"):
+                if k in fused:
+                    out[k] = fused[k]
+            if lw.get("semantic_loss", 0.0) > 0:
+                out["semantic_loss"] = self._semantic_loss(preds_dict, targets, valid)
+            for k in ("free_space_loss", "sdf_loss", "eikonal_loss"):
+                if k in fused:
+                    out[k] = fused[k]
+            return out
         if lw.get("depth_loss", 0.0) > 0:
             l1 = torch.sum(valid * torch.abs(depth_gt - preds_dict["depth"]))
             out["depth_loss"] = l1 / torch.clamp(torch.sum(valid), min=1.0) * lw.depth_loss
@@ -71,17 +98,7 @@ class SurfaceModel(nn.Module):
             out["rgb_loss"] = torch.mean(torch.abs(rgb_pred - rgb_gt)) * lw.rgb_loss
             out["psnr"] = 20.0 * torch.log10(1.0 / torch.mean((rgb_pred - rgb_gt).pow(2)).sqrt())
         if lw.get("semantic_loss", 0.0) > 0:
-            if not self.training:
-                raise NotImplementedError("semantic loss is only defined for training (SURVEY Q2)")
-            sem_pred = F.normalize(preds_dict["semantic"], dim=-1)
-            sem_gt = targets["semantic"]
-            ok = (valid * sem_gt.any(dim=-1, keepdim=True)).squeeze(-1).bool()
-            logits = torch.mm(sem_pred, sem_gt.transpose(1, 0)) / self.loss.temperature
-            labels = torch.arange(sem_pred.shape[0], dtype=torch.long, device=sem_pred.device)
-            labels = torch.where(ok, labels, torch.full_like(labels, -100))
-            # all-ignored -> exactly 0 (cross_entropy would give nan); no host sync
-            ce = F.cross_entropy(logits, labels, reduction="sum") / ok.sum().clamp(min=1)
-            out["semantic_loss"] = ce * lw.semantic_loss
+            out["semantic_loss"] = self._semantic_loss(preds_dict, targets, valid)
         pred_sdf = preds_dict["sdf"][..., 0]
         z_vals = preds_dict["z_vals"][..., 0]
         trunc = self.loss.sensor_depth_truncation

@@ -778,3 +778,50 @@ def test_lean_fused_optimizer_steps_equal_torch(device, kind):
     for k in sa:
         for name in sa[k]:
             assert torch.equal(torch.as_tensor(sa[k][name]).float().cpu(), torch.as_tensor(sb[k][name]).float().cpu()), (k, name)
+
+
+@pytest.mark.parametrize("with_rgb,with_eik", [(True, True), (False, False)])
+def test_fused_surface_losses_equal_get_loss(device, with_rgb, with_eik):
+    """csrc/surface_loss.hip against SurfaceModel.get_loss's torch formulas (base_surface_model.py:
+    102-211 of the reference) evaluated in float64: every term, and the gradients of their sum with
+    respect to depth, colour, SDF and SDF gradient; rays without a depth target, samples in front of,
+    around and behind the surface, zero differences (sign(0) = 0)."""
+    from ponderv2_amd import surface_loss
+    from ponderv2_amd.ponder.models.ponder.render_utils.models.base_surface_model import SurfaceModel
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.manual_seed(0)
+    R, S = 301, 45
+    weights = dict(depth_loss=1.0, free_space_loss=1.0, sdf_loss=10.0)
+    if with_rgb:
+        weights.update(rgb_loss=10.0)
+    if with_eik:
+        weights.update(eikonal_loss=0.01)
+    loss_cfg = ConfigDict(dict(sensor_depth_truncation=0.05, weights=weights))
+    model = SurfaceModel.__new__(SurfaceModel)
+    torch.nn.Module.__init__(model)
+    model.loss = loss_cfg
+    z = torch.sort(torch.rand(R, S, 1, device=device) * 2.0, dim=1).values
+    depth_gt = torch.rand(R, 1, device=device) * 2.0
+    depth_gt[::7] = 0.0                                   # rays without a target
+    leaves32 = dict(depth=torch.rand(R, 1, device=device) * 2.0, rgb=torch.rand(R, 3, device=device),
+                    sdf=torch.randn(R, S, 1, device=device) * 0.1, gradients=torch.randn(R, S, 3, device=device))
+    leaves32["depth"][5] = depth_gt[5]                    # an exact zero difference
+    targets32 = dict(depth=depth_gt, rgb=torch.rand(R, 3, device=device))
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        leaves = {k: v.to(dt).clone().requires_grad_(True) for k, v in leaves32.items()}
+        preds = dict(leaves, z_vals=z.to(dt))
+        before = surface_loss.CALLS
+        out = model.get_loss(preds, {k: v.to(dt) for k, v in targets32.items()})
+        assert (surface_loss.CALLS > before) == (dt == torch.float32)
+        total = sum(v for k, v in out.items() if "loss" in k)
+        total.backward()
+        res[dt] = ({k: float(v) for k, v in out.items()}, {k: v.grad for k, v in leaves.items()})
+    a, b = res[torch.float32], res[torch.float64]
+    assert a[0].keys() == b[0].keys() and ("psnr" in a[0]) == with_rgb
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 2e-6 * (1 + abs(b[0][k])), (k, a[0][k], b[0][k])
+    for k in ("depth", "sdf") + (("rgb",) if with_rgb else ()) + (("gradients",) if with_eik else ()):
+        ga, gb = a[1][k], b[1][k]
+        assert ga is not None and float((ga.double() - gb).abs().max()) <= 1e-6 * (float(gb.abs().max()) + 1e-12), k
