@@ -525,6 +525,32 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
                             pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Ray set-up of the indoor model (csrc/ray_setup.hip): PonderIndoor.to_unit_cube + ray_sample +
+ * get_mask_at_box, ponder/models/ponder/ponder_indoor_base.py:344-497 of the reference - fp32 in the
+ * reference's operation order (no contraction), the slab test in double.
+ *   pv2_unit_cube: coords [N,3] of n_scenes scenes (offsets: int64 cumulative counts), extrinsic
+ *     [B,V,4,4] world -> camera (its [3,3] entry is taken as 1), kmat [B,V,3,3], depth_scale [B]
+ *     -> scene [B, scene_floats]: scale | t(3) | extent (pc_scale) | new depth scale | bbox lo(3), hi(3);
+ *        extrinsic_out [B,V,4,4] = extrinsic . S^-1;  view [B*V, view_floats]: camera pose rows 0..2
+ *        ([R | o]) | K^-1 (9) | image-plane normal (3);  coords_out [N,3] the normalised cloud in
+ *        metres of the scaled scene.  bounds_ws: 6 B floats of scratch.  Record sizes:
+ *        pv2_ray_setup_record_sizes.
+ *   pv2_ray_gen: pixels [B,V,n] int64 flat indices y * width + x into colors [B,V,H,W,3], depths
+ *     [B,V,H,W], semantic [B,V,H,W] int64 (or NULL) -> ray_o, ray_d [B, V*n, 3], rgb [B*V*n, 3], depth
+ *     [B*V*n] (distance along the ray; -0.001 and zero colour for rays that miss the padded cube
+ *     bounds_lo / bounds_hi, HOST doubles), semantic_row [B*V*n] = class + 1, 0 for class <= 0 / miss.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_ray_setup_record_sizes(int* scene_floats, int* view_floats);
+int pv2_unit_cube(const float* coords, const int64_t* offsets, int n_scenes, int64_t n_points,
+                  int n_views, float z_level, const float* depth_scale, const float* extrinsic,
+                  const float* kmat, float* bounds_ws, float* scene, float* extrinsic_out, float* view,
+                  float* coords_out, pv2_stream_t stream);
+int pv2_ray_gen(const int64_t* pixels, int n_scenes, int n_views, int n_rays, int height, int width,
+                const float* view, const float* scene, const float* colors, const float* depths,
+                const int64_t* semantic, const double* bounds_lo, const double* bounds_hi, float* ray_o,
+                float* ray_d, float* rgb, float* depth, int64_t* semantic_row, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-ray / per-sample loss terms of the surface-rendering models (csrc/surface_loss.hip):
  * SurfaceModel.get_loss, ponder/models/ponder/render_utils/models/base_surface_model.py:102-211 -
  * depth, colour (+ psnr), free-space, SDF and eikonal terms; the semantic term is not covered.

@@ -132,6 +132,9 @@ SIGNATURES = {
     "pv2_neus_field_backward": (
         c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int] + [_P] * 7
         + [c_int, c_float] + [_P] * 9 + [_P] * 9 + [_P]),
+    "pv2_ray_setup_record_sizes": (c_int, [POINTER(c_int)] * 2),
+    "pv2_unit_cube": (c_int, [_P, _P, c_int, c_int64, c_int, c_float] + [_P] * 9),
+    "pv2_ray_gen": (c_int, [_P, c_int, c_int, c_int, c_int, c_int] + [_P] * 13),
     "pv2_surface_loss_workspace_floats": (c_int, []),
     "pv2_surface_loss_forward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P]),
     "pv2_surface_loss_backward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),

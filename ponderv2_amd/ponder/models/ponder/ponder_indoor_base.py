@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ponderv2_amd import precision
+from ponderv2_amd import precision, ray_setup
 from ponderv2_amd.linear import linear
 
 from ponderv2_amd.torch_scatter import scatter
@@ -248,6 +248,18 @@ class PonderIndoor(nn.Module):
         key = torch.where(valid.reshape(B, V, -1), key, torch.full_like(key, 2.0))
         return torch.topk(key, n, dim=-1, largest=False).indices
 
+    def _semantic_table(self, data_dict, dev):
+        """[zero row; one text embedding per class]: row ``semantic + 1`` is a pixel's target."""
+        index2semantic = data_dict.get("index2semantic")
+        if "condition" in data_dict:
+            index2semantic = self._valid_embedding(self._condition_index(data_dict), dev)
+            data_dict["index2semantic"] = index2semantic
+        if index2semantic is None:
+            index2semantic = self.class_embedding
+        index2semantic = index2semantic.to(dev)
+        assert index2semantic.shape[0] > 0
+        return torch.cat([index2semantic.new_zeros((1, index2semantic.shape[1])), index2semantic], 0)
+
     @torch.no_grad()
     def ray_sample(self, data_dict):
         colors = data_dict["rgb"].float()        # (B,V,H,W,3)
@@ -263,13 +275,7 @@ class PonderIndoor(nn.Module):
         Kmat = intr[..., :3, :3]
 
         if self.render_semantic:
-            index2semantic = data_dict.get("index2semantic")
-            if "condition" in data_dict:
-                index2semantic = self._valid_embedding(self._condition_index(data_dict), dev)
-                data_dict["index2semantic"] = index2semantic
-            if index2semantic is None:
-                index2semantic = self.class_embedding
-            index2semantic = index2semantic.to(dev)
+            table = self._semantic_table(data_dict, dev)
 
         pix = data_dict.get("ray_pixels")  # optional (B,V,n,2) [y,x] from the caller
         if pix is None:
@@ -313,9 +319,6 @@ class PonderIndoor(nn.Module):
         if self.render_semantic:
             sem = pick(data_dict["semantic"])
             sem = torch.where(inside, sem, torch.full_like(sem, -1))
-            assert index2semantic.shape[0] > 0
-            table = torch.cat([index2semantic.new_zeros((1, index2semantic.shape[1])),
-                               index2semantic], 0)
             # class 0 and ignore (-1) -> zero row (reference uses `semantic > 0`)
             row = torch.where(sem > 0, sem + 1, torch.zeros_like(sem)).long()
             ray_dict["semantic"] = table[row.reshape(-1)].float()
@@ -323,6 +326,8 @@ class PonderIndoor(nn.Module):
 
     @torch.no_grad()
     def prepare_ray(self, data_dict):
+        if ray_setup.usable(self, data_dict):   # four launches (csrc/ray_setup.hip), same arithmetic
+            return ray_setup.prepare_ray(self, data_dict)
         data_dict = self.to_unit_cube(data_dict)
         return self.ray_sample(data_dict), data_dict
 
