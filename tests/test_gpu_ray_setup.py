@@ -27,6 +27,7 @@ def test_fused_ray_setup_equals_the_torch_route(device, semantic):
     cfg = bench.model_cfg(64, "float32")
     model = build_model(ConfigDict(cfg)).to(device).train()
     model.render_semantic = semantic
+    model.bounds = [[-0.3, -0.3, -0.3], [0.3, 0.3, 0.3]]   # a tight box: part of the rays miss it
     batch = bench.make_batch(0, 2, 2, device)
     B, V, H, W = batch["depth"].shape
     n = model.ray_nsample

@@ -20,7 +20,7 @@ RULES = (  # first match wins
     ("fused ray march", ("field_", "coarse_sample", "volume_scatter", "weights_", "accumulate_", "fold_", "narrow_")),
     ("optimizer", ("multi_tensor", "sgd", "Sgd")),
     ("rulebook build", ("rocprim", "table", "hash", "down_", "tile_prefix", "fill_i32", "pair_positions")),
-    ("dense max-pool / concat / split (hand-written)", ("maxpool3d", "concat_rows", "split_rows", "small_inverse")),
+    ("dense max-pool / concat / split, ray set-up, losses (hand-written)", ("maxpool3d", "concat_rows", "split_rows", "small_inverse", "scene_bounds", "unit_cube", "ray_gen", "surface_loss")),
     ("ATen elementwise / copies / reductions", ("at::native", "copyBuffer")),
 )
 

@@ -67,7 +67,7 @@ for ph in phases:
         name = c.name.replace("autograd::engine::evaluate_function: ", "bwd ")
         groups[name] += launches(c)
         hosts[name] += c.cpu_time_total
-    for name, k in groups.most_common(14 if "backward" in ph.name else 8):
+    for name, k in groups.most_common(24):
         if k:
             print("        %5d  %-60s host %.2f ms" % (k, name[:60], hosts[name] / 1e3))
 # the backward pass runs on the autograd engine's device thread: its nodes are no children of the
