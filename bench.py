@@ -85,6 +85,14 @@ def pmc_traffic(kernel_key):
         return None, f"{PMC_FILE} unavailable ({type(e).__name__})"
 
 
+def _backbone_route():
+    """Which route the sparse U-Net took over the run (counters of the product modules)."""
+    from ponderv2_amd import convbn, spunet_native
+
+    return ("native executor: %d calls (csrc/spunet_exec.hip); conv + BatchNorm units outside it: %d"
+            % (spunet_native.CALLS, getattr(convbn, "CALLS", 0)))
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks of one
     node under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), the way the
@@ -931,6 +939,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "first_loss": first_loss, "final_loss": loss, "loss_sane": loss_sane,
             "backward_side_stream": side_state,
+            "sparse_backbone": _backbone_route(),
             "optimizer": "%s%s, %d group updates on cached lists (utils/optimizer.py)" % (
                 type(opt).__name__, " (fused)" if opt.defaults.get("fused") else "",
                 getattr(opt, "_pv2_lean_steps", 0)),
