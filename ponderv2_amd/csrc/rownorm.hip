@@ -233,23 +233,27 @@ __global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
 }
 
 // Step 2: one block per panel of 32 channels adds the partial rows in a FIXED order (thread (q, ch)
-// adds rows q, q + 8, ...; the 8 sub-sums are then added in order of q), in double precision, and
+// adds rows q, q + 32, ...; the 32 sub-sums are then added in order of q), in double precision, and
 // turns the totals into the layer's statistics.
 //   MODE 0: out[0..C) = mean, out[C..2C) = invstd (biased variance); running statistics updated
 //   MODE 1: out[0..C) = sum g (= dbias), out[C..2C) = sum g*xhat (= dweight)
+// (kCombineThreads / 32 = 32 sub-sums per channel: with up to 2048 partial rows the loop is a chain of
+// dependent loads - 8 sub-sums took 10 us per layer, 118 launches per step)
+constexpr int kCombineThreads = 1024;
+constexpr int kCombineSubs = kCombineThreads / 32;
 template <int MODE, typename EX>
-__global__ __launch_bounds__(kThreads) void col_combine_kernel(
+__global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0, int64_t n,
     float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ out) {
-  __shared__ double r0[kThreads];
-  __shared__ double r1[kThreads];
+  __shared__ double r0[kCombineThreads];
+  __shared__ double r1[kCombineThreads];
   const int tid = threadIdx.x, q = tid >> 5, cc = tid & 31;
   const int ch = blockIdx.x * 32 + cc;
   double a0 = 0.0, a1 = 0.0;
   if (ch < c) {
 #pragma unroll 8
-    for (int b = q; b < nb; b += 8) {
+    for (int b = q; b < nb; b += kCombineSubs) {
       a0 += (double)partial[(int64_t)b * 2 * c + ch];
       a1 += (double)partial[(int64_t)b * 2 * c + c + ch];
     }
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void col_combine_kernel(
   __syncthreads();
   if (q != 0 || ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < kCombineSubs; ++k) {
     t0 += r0[k * 32 + cc];
     t1 += r1[k * 32 + cc];
   }
@@ -457,7 +461,7 @@ int bn_forward_from_partials(const float* x, int64_t n, int c, const float* part
                              const float* weight, const float* bias, const float* residual,
                              int relu, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean_invstd, float* y, hipStream_t s) {
-  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
                      partial, blocks, c, x, n, eps, momentum, running_mean, running_var,
                      mean_invstd);
   if ((c % 8) == 0)
@@ -493,7 +497,7 @@ int bn_forward_t(const void* x, int64_t n, int c, const float* weight, const flo
     hipLaunchKernelGGL((col_partials_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
                        (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
                        workspace);
-  hipLaunchKernelGGL((col_combine_kernel<0, EX>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+  hipLaunchKernelGGL((col_combine_kernel<0, EX>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
                      workspace, blocks, c, (const TX*)x, n, eps, momentum, running_mean, running_var,
                      mean_invstd);
   if (vec)
@@ -525,7 +529,7 @@ int bn_backward_t(const void* dy, const void* x, const void* y_or_null, const fl
     hipLaunchKernelGGL((col_partials_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
                        (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
                        workspace);
-  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kThreads), 0, s,
+  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
                      workspace, blocks, c, (const float*)nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
   if (vec)
     hipLaunchKernelGGL((bn_backward_apply_vec_kernel<EX, EY>),
