@@ -686,6 +686,10 @@ int pv2_neus_field_backward_rows(const float* jrows, const float* origins, const
  * ponder_outdoor_base.py:204.
  * ------------------------------------------------------------------------------------------ */
 /* out[index[i], :] += src[i, :];  count[index[i]] += 1.   index: int64 [m], values in [0, g). */
+/* out[i, :] = table[index[i], :], c % 4 == 0: the expansion of a small table of rows (the 27 border
+ * classes of the dense grid's first convolution, models/ponder/sparse_input.py) into a full matrix. */
+int pv2_gather_rows(const float* table, const int32_t* index, int64_t n, int c, float* out,
+                    pv2_stream_t stream);
 int pv2_scatter_add(const float* src, const int64_t* index, int64_t m, int c, float* out,
                     float* count, int64_t g, pv2_stream_t stream);
 /* out[r, :] /= max(count[r], 1) */

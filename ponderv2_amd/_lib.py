@@ -168,6 +168,7 @@ SIGNATURES = {
     "pv2_maxpool3d_cl_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pv2_maxpool3d_cl_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pv2_small_inverse": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "pv2_gather_rows": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "pv2_scatter_mean_finish": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pv2_scatter_backward": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_int64, _P]),

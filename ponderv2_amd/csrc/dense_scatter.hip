@@ -53,7 +53,32 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(const float* __restric
 
 }  // namespace
 
+namespace {
+// out[i, :] = table[index[i], :] for a SMALL table (it lives in L1): a pure 16-byte-vector write of the
+// output.  torch's index_select on an int64 index ran this 134 MB fill at 0.6 TB/s.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ table,
+                                                         const int32_t* __restrict__ index, int64_t n,
+                                                         int c4, float4* __restrict__ out) {
+  const int64_t total = n * c4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const int64_t i = q / c4;
+    const int j = (int)(q - i * c4);
+    out[q] = table[(int64_t)index[i] * c4 + j];
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int pv2_gather_rows(const float* table, const int32_t* index, int64_t n, int c, float* out,
+                    pv2_stream_t stream) {
+  PV2_REQUIRE(c >= 4 && (c % 4) == 0 && n >= 0, "pv2_gather_rows: c must be a multiple of 4");
+  if (n == 0) return PV2_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(pv2::grid_for(n * (c / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)table, index, n, c / 4, (float4*)out);
+  return pv2::check_launch("gather_rows");
+}
 
 int pv2_scatter_add(const float* src, const int64_t* index, int64_t m, int c, float* out,
                     float* count, int64_t g, pv2_stream_t stream) {

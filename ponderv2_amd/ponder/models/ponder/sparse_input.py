@@ -138,7 +138,19 @@ class _ExpandClasses(torch.autograd.Function):
     def forward(ctx, table, cls, batch, dims):
         ctx.cls, ctx.batch, ctx.dims = cls, batch, dims
         ctx.table_shape = table.shape
-        return table.reshape(-1, table.shape[-1]).index_select(0, cls["rows"])
+        flat = table.reshape(-1, table.shape[-1])
+        if flat.is_cuda and flat.dtype == torch.float32 and flat.shape[1] % 4 == 0:
+            from ponderv2_amd import _lib
+
+            if "rows32" not in cls:
+                cls["rows32"] = cls["rows"].to(torch.int32).contiguous()
+            flat = flat.contiguous()
+            out = torch.empty((cls["rows32"].numel(), flat.shape[1]), dtype=torch.float32, device=flat.device)
+            _lib.check(_lib.lib().pv2_gather_rows(K._ptr(flat), K._ptr(cls["rows32"]), out.shape[0],
+                                                  flat.shape[1], K._ptr(out), K._stream(flat)),
+                       "pv2_gather_rows")
+            return out
+        return flat.index_select(0, cls["rows"])
 
     @staticmethod
     def backward(ctx, g):
@@ -176,7 +188,7 @@ def _constant_part(weight, y0, bias, batch, dims):
     return _ExpandClasses.apply(table, cls, batch, (zs, ys, xs))
 
 
-def conv3d_on_cells(cells, delta, weight, y0=None, bias=None):
+def conv3d_on_cells(cells, delta, weight, y0=None, bias=None, relu=False):
     """3x3x3 / stride 1 / padding 1 convolution of the field ``y0 + occupied * delta``.
     weight (Cout, Cin, 3, 3, 3) as nn.Conv3d holds it -> (B, Cout, Z, Y, X), channels-last."""
     assert tuple(weight.shape[2:]) == (3, 3, 3)
@@ -184,6 +196,8 @@ def conv3d_on_cells(cells, delta, weight, y0=None, bias=None):
     init = _constant_part(weight, y0, bias, cells.batch, cells.dims)
     w_okc = weight.permute(0, 2, 3, 4, 1).reshape(c_out, 27, c_in).contiguous()
     out = K.SparseConvIntoFunction.apply(delta, w_okc, cells.rulebook(), init)
+    if relu:   # on the rows, BEFORE the volume view: an in-place op on a view makes autograd clone the
+        out = F.relu_(out)   # whole 134 MB gradient (CopySlices) and run the ReLU backward strided
     zs, ys, xs = cells.dims
     return out.view(cells.batch, zs, ys, xs, c_out).permute(0, 4, 1, 2, 3)
 
@@ -216,5 +230,4 @@ def bn_conv_relu_on_cells(bn, conv, cells):
     y0 = -mean * scale
     if bn.affine:
         y0 = y0 + bn.bias
-    out = conv3d_on_cells(cells, x * scale, conv.weight, y0=y0, bias=conv.bias)
-    return F.relu_(out)
+    return conv3d_on_cells(cells, x * scale, conv.weight, y0=y0, bias=conv.bias, relu=True)

@@ -45,7 +45,7 @@ def step(tag=False):
 for _ in range(4):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(tag=True)
     torch.cuda.synchronize()
 
@@ -86,3 +86,26 @@ print("%-46s %5d launches  host %.2f ms  (%d nodes)" % ("backward (autograd node
 for name, k in sorted(hosts.items(), key=lambda kv: -kv[1])[:40]:
     print("        %5d launches %4d nodes  %-52s host %.2f ms" % (groups[name], counts[name], name[:52], k / 1e3))
 print("total launches in the step:", total)
+
+
+# the copies: which op asked for them, on what shapes
+def chain(e):
+    names = []
+    while e is not None and len(names) < 6:
+        if not e.name.startswith(("phase:", "autograd::engine")):
+            names.append(e.name + (str(e.input_shapes)[:60] if e.input_shapes else ""))
+        e = e.cpu_parent
+    return " <- ".join(names)
+
+
+copies = collections.Counter()
+times = collections.Counter()
+for e in events:
+    for k in e.kernels:
+        if "direct_copy" in k.name or "copyBuffer" in k.name or "gather" in k.name or "BinaryFunctor" in k.name:
+            key = chain(e)
+            copies[key] += 1
+            times[key] += k.duration
+print("copy / gather / big elementwise kernels by caller (us, count):")
+for key, t in times.most_common(24):
+    print("  %8.1f %3d  %s" % (t, copies[key], key[:230]))
