@@ -855,10 +855,6 @@ def main():
             dt = float(t)
         return dt, t_cpu, out
 
-    if os.environ.get("PV2_BENCH_MAIN_PRIORITY"):   # experiment: the critical chain on a high-priority stream
-        prio = torch.cuda.Stream(device, priority=-1)
-        prio.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(prio)
     first_loss_t = None
     for _ in range(args.warmup):
         out = step()
