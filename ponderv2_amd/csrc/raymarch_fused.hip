@@ -121,6 +121,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 // SDF MLP up to a1 for a 32-row feature tile in sF (columns 0..F-1).  Leaves a1 in `a1` and
 // t = W1[0] * softplus'(h0) in `tt` (accumulator layout); h0 goes to `save_h0` when given.
+// FAST: the activation on the hardware exp / log / rcp units (softplus_fast) - the main pass, whose
+// results are compared with tolerances; the coarse pass keeps libm's (its SDF values decide the
+// importance sampler's bins, which the full-size fixtures pin bit for bit).
+template <bool FAST>
 __device__ __forceinline__ void mlp_hidden(const float* sF, int lda, const Head& P, int lane,
                                            f32x16 (&a1)[4], f32x16 (&tt)[4], float* save_h0,
                                            int64_t base, int64_t n_total) {
@@ -140,7 +144,8 @@ __device__ __forceinline__ void mlp_hidden(const float* sF, int lda, const Head&
         if (n < n_total) save_h0[n * kH + col] = h0;
       }
       float sp, d1, d2;
-      softplus100(h0, &sp, &d1, &d2);
+      if (FAST) softplus_fast(h0, &sp, &d1, &d2);
+      else softplus100(h0, &sp, &d1, &d2);
       a1[nb][r] = sp;
       tt[nb][r] = v1 * d1;
     }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
   __syncthreads();
 
   f32x16 a1[4], tt[4];
-  mlp_hidden(bufA, kLd, P, lane, a1, tt, save_h0, base, n_total);
+  mlp_hidden<true>(bufA, kLd, P, lane, a1, tt, save_h0, base, n_total);
   store_acc_lds<4>(bufB, kLd, a1, lane);
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
       const bool valid = n < n_total;
       const float a = ga1[nb][r] + s_gs[row] * v1;
       float sp, d1 = 0.f, d2 = 0.f;
-      if (valid) softplus100(save_h0[n * kH + col], &sp, &d1, &d2);
+      if (valid) softplus_fast(save_h0[n * kH + col], &sp, &d1, &d2);
       const float g0 = a * d1 + gt[nb][r] * v1 * d2;
       s_c0 += g0;
       s_bc1 += valid ? a : 0.f;
@@ -931,7 +936,7 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
   }
   if (wave * 32 < S0) {
     f32x16 a1[4], tt[4];
-    mlp_hidden(s_f[wave], kLdF, P, lane, a1, tt, nullptr, 0, 0);
+    mlp_hidden<false>(s_f[wave], kLdF, P, lane, a1, tt, nullptr, 0, 0);
     // (L.sdf rows beyond S0 land in the padding of the kMaxS0 array)
     sdf_rows(a1, P, lane, L.sdf + wave * 32);
   }

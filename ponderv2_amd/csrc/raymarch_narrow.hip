@@ -89,21 +89,6 @@ struct Feat {
   float v[NCB][8];   // [cb][s] = channel 8 g + s of slot 16 cb + n
 };
 
-// Softplus(beta = 100, threshold = 20) with its first two derivatives on the hardware exp / log / rcp
-// units (1 ulp each): ~8 instructions per element where the libm forms take ~50 - the activation, not
-// the matrix products, was the longest part of a layer.  log(1 + e) instead of log1p(e) costs at most
-// 6e-8 / 100 ABSOLUTE on a value that is >= 0 and enters sums of O(1) terms.
-__device__ __forceinline__ void softplus_fast(float h, float* sp, float* d1, float* d2) {
-  const float bx = 100.f * h;
-  const float e = __expf(fminf(bx, 20.f));
-  const float r = __frcp_rn(1.f + e);
-  const bool lin = bx > 20.f;
-  const float s = e * r;
-  *sp = lin ? h : __logf(1.f + e) * 0.01f;
-  *d1 = lin ? 1.f : s;
-  *d2 = lin ? 0.f : 100.f * s * r;    // s (1 - s) = e / (1 + e)^2
-}
-
 // trilinear feature (q = 0) or its derivative along p_q of one slot, this lane's 8 channels
 __device__ __forceinline__ void gather8(const Vol& vol, int scene, float px, float py, float pz, int q,
                                         int g, float (&f)[8]) {

@@ -13,3 +13,5 @@ d=json.loads(open('gpurun_out/val/bench_default.json').read().strip().splitlines
 print({k:d["roofline"].get(k) for k in ("kernel","achieved","frac","avg_launch_us","launches","traffic","alg_bytes_per_launch")})
 print(d.get("cpu_baseline",{}).get("value"), d.get("optimizer"), d.get("sparse_backbone"))
 PY
+PV2_WGRAD_STREAM=0 bash tools/gpu_pmc.sh val_outdoor_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload outdoor --steps 6 --warmup 2
+cp gpurun_out/pmc_val_outdoor_mfma_by_kernel.csv $O/pmc_outdoor_mfma_by_kernel.csv 2>/dev/null; head -8 $O/pmc_outdoor_mfma_by_kernel.csv | cut -c1-200
