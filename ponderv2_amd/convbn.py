@@ -80,7 +80,7 @@ class ConvBNFunction(torch.autograd.Function):
             dw = torch.empty((c_out, k, c_in), dtype=torch.float32, device=dev)
             floats = int(_lib.lib().pv2_spconv_wgrad_partial_floats(c_in, c_out, g.n_tiles_w))
             if sidestream.active(grad_out) and sidestream.safe_leaf(weight_okc):
-                side = sidestream.native_fork(dev, (feats, dy, dw))
+                side = sidestream.native_fork(dev, (feats, dy, dw, rb))   # (rb: the pair lists the kernels read)
                 part = K.workspace("wgrad", dev, floats, stream=side)
             else:
                 part = K.workspace("wgrad", dev, floats)

@@ -859,7 +859,9 @@ def spconv16_backward_weight(feats, grad_out, rb: Rulebook, c_out: int) -> torch
 
 def _weight_grad(fn, weight_view, *reads):
     """``fn()`` (a weight-gradient launch reading ``reads``) on the backward side stream when that
-    is on and safe for this leaf (sidestream.py), on the current stream otherwise."""
+    is on and safe for this leaf (sidestream.py), on the current stream otherwise.  ``reads`` holds
+    EVERYTHING the launch touches until the streams join - the rulebook (its pair lists) included:
+    autograd drops a node's context as soon as the node has run, long before the side stream has."""
     from . import sidestream
 
     if sidestream.active(reads[0]) and sidestream.safe_leaf(weight_view):
@@ -891,7 +893,7 @@ class SparseConv16Function(torch.autograd.Function):
         g_feats = g_w = g_b = None
         if ctx.needs_input_grad[1]:   # first: it leaves for the side stream (sidestream.py)
             g_w = _weight_grad(lambda: spconv16_backward_weight(feats, grad_out, rb, c_out),
-                               weight_okc, grad_out, feats)
+                               weight_okc, grad_out, feats, rb)
         if ctx.needs_input_grad[0]:
             nbr, stride, perm, kflip = rb._transposed_os
             g_feats = spconv16_forward(grad_out, ctx.packed_bwd, K, c_in, nbr, stride, perm, kflip,
@@ -918,7 +920,7 @@ class SparseConvFunction(torch.autograd.Function):
         g_feats = g_w = None
         if ctx.needs_input_grad[1]:   # first: it leaves for the side stream (sidestream.py)
             g_w = _weight_grad(lambda: spconv_backward_weight(feats, grad_out, rb, weight_okc.shape[0]),
-                               weight_okc, grad_out, feats)
+                               weight_okc, grad_out, feats, rb)
         if ctx.needs_input_grad[0]:
             g_feats = spconv_grad_input(grad_out, weight_okc, rb)
         return g_feats, g_w, None

@@ -79,6 +79,7 @@ def prepare_ray(model, data_dict):
     d["pc_scale"] = scene[:, 4]
     d["bbox"] = scene[:, 6:12].reshape(B, 2, 3)
     d["coord"] = coords_out
+    d["ray_setup_records"] = (scene, view)   # (scene / view records of csrc/ray_setup.hip, kept with the batch)
 
     pix = d.get("ray_pixels")   # optional (B,V,n,2) [y,x] from the caller
     if pix is None:

@@ -388,7 +388,11 @@ class SpUNetFunction(torch.autograd.Function):
         weights = [tensors[u.w_index] for u in plan.units if u.kind == UNET_CONV_BN]
         side = None
         if sidestream.active(grad_out) and all(sidestream.safe_leaf(w) for w in weights):
-            side = sidestream.native_fork(dev, (plan.fwd.tensor, arena.tensor, ctx.feats, grad_out))
+            # (the plan too: its rulebooks own the pair lists / tile prefixes the side stream's kernels
+            # read - released with ``ctx.plan = None`` below while those kernels were still queued,
+            # the arrays could be handed to the next allocation on this stream BEFORE the join:
+            # a memory fault once in a few runs of the full-size fixtures)
+            side = sidestream.native_fork(dev, (plan.fwd.tensor, arena.tensor, ctx.feats, grad_out, plan))
             part = K.workspace("wgrad", dev, part_floats, stream=side)
         else:
             part = K.workspace("wgrad", dev, part_floats)

@@ -1,10 +1,13 @@
 #!/bin/bash
-# The whole -m gpu suite N times with the HIP runtime's error log on (AMD_LOG_LEVEL=1 prints only errors):
-# a check for rare failures.  usage: tools/gpu_repeat_suite.sh [N]
+# The -m gpu suite (or the files given after N) N times WITHOUT pytest's output capture, so that messages
+# of the HIP runtime / C++ libraries survive an abort: a check for rare failures.
+# usage: tools/gpu_repeat_suite.sh [N] [pytest targets...]
 set -u
-N=${1:-2}
+N=${1:-2}; shift || true
+T=${@:-tests}
 O=gpurun_out/repeat; mkdir -p $O
 for i in $(seq 1 $N); do
-  AMD_LOG_LEVEL=1 timeout 900 python -m pytest tests -m gpu -q --timeout 400 > $O/run_$i.txt 2> $O/run_$i.err
-  echo "run $i rc=$?"; tail -1 $O/run_$i.txt | cut -c1-200; grep -v "^$" $O/run_$i.err | grep -iv "amdgpu.ids" | head -12 | cut -c1-300
+  timeout 900 python -m pytest $T -m gpu -q --timeout 400 -s -p no:faulthandler > $O/run_$i.txt 2> $O/run_$i.err
+  rc=$?; echo "run $i rc=$rc"; grep -E "passed|failed" $O/run_$i.txt | tail -1 | cut -c1-200
+  if [ $rc -ne 0 ]; then grep -v "amdgpu.ids" $O/run_$i.err | tail -15 | cut -c1-400; tail -5 $O/run_$i.txt | cut -c1-300; fi
 done
