@@ -632,3 +632,19 @@ def test_pending_batchnorm_counts_do_not_survive_a_checkpoint_load():
     model = torch.nn.Sequential(bn)
     rownorm.flush_bn_counters(model)        # for direct readers of the buffers (EMA copy, broadcast)
     assert int(bn.num_batches_tracked) == 11 and bn._pv2_pending_batches == 0
+
+
+def test_arena_views_split_matches_per_piece_views():
+    """spunet_native._Arena.views: the gradient views of the native backward from ONE split call equal
+    the piece-by-piece views (offsets are 64-float aligned, gaps are skipped, the tail is ignored)."""
+    from ponderv2_amd.spunet_native import _Arena
+
+    a = _Arena()
+    offs = [a.reserve(n) for n in (10, 100, 7, 64, 1)]
+    a.allocate("cpu")
+    a.tensor.copy_(torch.arange(a.size, dtype=torch.float32))
+    specs = [(offs[0], 4), (offs[0] + 4, 6), (offs[1], 100), (offs[3], 64), (offs[4], 1)]
+    got = a.views(specs)
+    assert len(got) == len(specs)
+    for (off, n), v in zip(specs, got):
+        assert torch.equal(v, a.view(off, n)) and v.data_ptr() == a.view(off, n).data_ptr()
