@@ -242,7 +242,8 @@ def _render_outputs(model, ray_bundle, volume_feature):
     out = dict(depth=torch.maximum(torch.minimum(depth, hi), lo))
     out.update(weights=weights.unsqueeze(-1), sdf=sdf.unsqueeze(-1), gradients=grad,
                z_vals=starts.unsqueeze(-1))
+    # (the composited normal feeds no loss of this head; kept for the callers that read it)
+    out["normal"] = (weights.unsqueeze(-1) * torch.nn.functional.normalize(grad, dim=-1)).sum(1)
     if not model.training:
-        out["normal"] = (weights.unsqueeze(-1) * torch.nn.functional.normalize(grad, dim=-1)).sum(1)
         out["sampled_points"] = o[:, None, :] + d[:, None, :] * starts[..., None]
     return out
