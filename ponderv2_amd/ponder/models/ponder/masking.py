@@ -25,7 +25,7 @@ def mask_blocks(grid_coord, feat, offset, size, ratio, mtoken, rand=None):
     n = grid_coord.shape[0]
     dev = grid_coord.device
     batch = offset2batch(offset, n).long()
-    b = torch.div(grid_coord, size, rounding_mode="floor").long()
+    b = torch.div(grid_coord, size).int().long()   # (true division, then truncation: the reference's :115)
     # one integer per block, ordered like the rows (scene, bx, by, bz): 16 bits per coordinate
     key = (batch << 48) | ((b[:, 0] + 32768) << 32) | ((b[:, 1] + 32768) << 16) | (b[:, 2] + 32768)
     skey, perm = torch.sort(key)

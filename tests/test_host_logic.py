@@ -240,6 +240,38 @@ def test_block_masking_keeps_the_reference_set():
     assert torch.allclose(token.grad, torch.full((1, 4), float(masked.sum())))
 
 
+def test_block_masking_with_its_own_draws():
+    """mask_blocks drawing its own random keys (no compaction, no host read): a block is kept or
+    masked as a whole, exactly round(n_blocks*(1-ratio)) blocks per scene are kept, scenes do not
+    mix, different seeds give different sets; negative block coordinates and an empty-looking last
+    scene (one voxel) are handled."""
+    from ponderv2_amd.ponder.models.ponder.masking import mask_blocks
+
+    g = torch.Generator().manual_seed(1)
+    grid = torch.randint(-20, 90, (3001, 3), generator=g)
+    offset = torch.tensor([1200, 3000, 3001])
+    feat = torch.randn(3001, 5, generator=g)
+    token = torch.full((1, 5), -9.0)
+    batch = torch.repeat_interleave(torch.arange(3), torch.tensor([1200, 1800, 1]))
+    block = torch.cat([batch[:, None], torch.div(grid, 8).int()], 1)   # (the reference's expression)
+    ublock, inv = block.unique(dim=0, return_inverse=True)
+    sets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        out = mask_blocks(grid, feat, offset, 8, 0.75, token)
+        masked = (out == -9.0).all(1)
+        per_block = torch.zeros(len(ublock)).index_add_(0, inv, masked.float())
+        size = torch.bincount(inv, minlength=len(ublock)).float()
+        assert bool(((per_block == 0) | (per_block == size)).all())      # whole blocks
+        for s in range(3):
+            ids = ublock[:, 0] == s
+            kept = int(((per_block == 0) & ids).sum())
+            assert kept == round(int(ids.sum()) * (1 - 0.75)), (s, kept)
+        assert torch.equal(out[~masked], feat[~masked])
+        sets.append(masked)
+    assert not torch.equal(sets[0], sets[1])
+
+
 @pytest.mark.parametrize("hash_type", ["fnv", "ravel"])
 def test_device_grid_sample_same_voxels_as_host_transform(hash_type):
     """grid_sample_torch (runs on any device) against the host GridSample: identical hash bit
