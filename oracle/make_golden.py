@@ -627,6 +627,34 @@ def ponder_ppt_case(ConfigDict):
     print("ponder_ppt_small:", {k: round(float(v), 6) for k, v in out.items()})
 
 
+def narrow_decoder_case():
+    """The nuScenes head's SDF decoder in isolation (tests/golden/narrow_decoder.npz): the REFERENCE's
+    own ``SDFDecoder(in_dim=32, out_dim=17, hidden_size=16, n_blocks=5)``
+    (ponder/models/ponder/render_utils/decoders.py:6-36) in float64 on random points / features, with
+    the gradient of its SDF output with respect to the points through a LINEAR feature field
+    feat = A p + a (so that d feat / d p = A is known exactly) - what sdf_field.py:211-250 takes by
+    autograd.  Pins oracle/narrow_head.py's value / tangent recursion and the parameter layout of
+    ponderv2_amd/narrow_head.py::pack_theta."""
+    D = ref_shims.load_reference_file("ponder/models/ponder/render_utils/decoders.py")
+    torch.manual_seed(7)
+    dec = D.SDFDecoder(in_dim=32, out_dim=17, hidden_size=16, n_blocks=5).double()
+    with torch.no_grad():
+        for q in dec.parameters():          # well away from the softplus threshold on both sides
+            q.mul_(1.5)
+    n = 64
+    pts = torch.rand(n, 3, dtype=torch.float64, requires_grad=True)
+    A = torch.randn(32, 3, dtype=torch.float64) * 0.4
+    a = torch.randn(32, dtype=torch.float64) * 0.2
+    feat = pts @ A.t() + a
+    out = dec(pts, feat)
+    (g,) = torch.autograd.grad(out[:, 0].sum(), pts)
+    names = [k for k, _ in dec.named_parameters()]
+    np.savez(os.path.join(GOLDEN, "narrow_decoder.npz"), points=pts.detach().numpy(), A=A.numpy(),
+             a=a.numpy(), out=out.detach().numpy(), grad_sdf=g.numpy(), param_names=np.array(names),
+             **{f"param_{i}": q.detach().numpy() for i, (_, q) in enumerate(dec.named_parameters())})
+    print("narrow_decoder:", out.shape, float(out[:, 0].abs().max()), float(g.abs().max()))
+
+
 def main():
     ref_shims.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -639,7 +667,8 @@ def main():
                  cfg0=lambda: ponder_indoor_cfg0_case(ConfigDict),
                  cfg1=lambda: ponder_indoor_cfg1_case(ConfigDict),
                  ppt_full=lambda: ponder_ppt_full_case(ConfigDict),
-                 outdoor_full=lambda: ponder_outdoor_full_case(ConfigDict))
+                 outdoor_full=lambda: ponder_outdoor_full_case(ConfigDict),
+                 narrow_decoder=narrow_decoder_case)
     for name, fn in cases.items():
         if not only or name in only:
             fn()
