@@ -763,6 +763,29 @@ int pv2_trilinear_backward_backward_f64(const double* g_ginput, const double* g_
                                         int padding_mode, int align_corners, int apply_smoothstep,
                                         pv2_stream_t stream);
 
+/* The sampler on 16-bit tensors (dtype: 1 = bfloat16, 2 = float16).  Replaces the half branch of the
+ * reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (libs/smooth-sampler/smooth_sampler/csrc/
+ * smooth_sampler_kernel.cu:630,670,726), which its shipped enable_amp=True configs reach.  input,
+ * grid, grad_output, g_ginput, g_ggrid, output, grad_grid, grad_grid2, grad_grad_output are
+ * 16-bit with the strides of the descriptors; arithmetic is fp32; the atomically accumulated
+ * volume gradients grad_input_f32 / grad_input2_f32 (NULL to skip; ZERO-initialised, strides of
+ * `vol`) are FP32 buffers the caller narrows once - the reference accumulates them in half. */
+int pv2_trilinear_forward_16(const void* input, int dtype, const pv2_volume_desc* vol,
+                             const void* grid, const pv2_points_desc* pts, void* output,
+                             int padding_mode, int align_corners, int apply_smoothstep,
+                             pv2_stream_t stream);
+int pv2_trilinear_backward_16(const void* grad_output, const void* input, int dtype,
+                              const pv2_volume_desc* vol, const void* grid,
+                              const pv2_points_desc* pts, float* grad_input_f32, void* grad_grid,
+                              int padding_mode, int align_corners, int apply_smoothstep,
+                              pv2_stream_t stream);
+int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid, const void* input,
+                                       int dtype, const pv2_volume_desc* vol, const void* grid,
+                                       const void* grad_output, const pv2_points_desc* pts,
+                                       float* grad_input2_f32, void* grad_grid2,
+                                       void* grad_grad_output, int padding_mode, int align_corners,
+                                       int apply_smoothstep, pv2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

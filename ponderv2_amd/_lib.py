@@ -182,6 +182,14 @@ for _sfx in ("f32", "f64"):
     SIGNATURES["pv2_trilinear_backward_backward_" + _sfx] = (
         c_int, [_P, _P, _P, POINTER(VolumeDesc), _P, _P, POINTER(PointsDesc), _P, _P, _P,
                 c_int, c_int, c_int, _P])
+SIGNATURES["pv2_trilinear_forward_16"] = (
+    c_int, [_P, c_int, POINTER(VolumeDesc), _P, POINTER(PointsDesc), _P, c_int, c_int, c_int, _P])
+SIGNATURES["pv2_trilinear_backward_16"] = (
+    c_int, [_P, _P, c_int, POINTER(VolumeDesc), _P, POINTER(PointsDesc), _P, _P,
+            c_int, c_int, c_int, _P])
+SIGNATURES["pv2_trilinear_backward_backward_16"] = (
+    c_int, [_P, _P, _P, c_int, POINTER(VolumeDesc), _P, _P, POINTER(PointsDesc), _P, _P, _P,
+            c_int, c_int, c_int, _P])
 
 _lib = None
 

@@ -31,6 +31,35 @@
 
 namespace {
 
+// Storage types of the 16-bit instantiations (the reference dispatches its kernels over half too:
+// smooth_sampler_kernel.cu:630,670,726 AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Arithmetic is fp32
+// (T), operands are widened on load and results rounded to nearest-even on store (S); the
+// atomically accumulated volume gradient stays an fp32 buffer - the caller narrows it once.
+struct H16 { unsigned short v; };   // IEEE binary16
+struct B16 { unsigned short v; };   // bfloat16
+template <typename T, typename S>
+__device__ __forceinline__ T ldv(const S* __restrict__ p, int64_t i) { return (T)p[i]; }
+template <>
+__device__ __forceinline__ float ldv<float, H16>(const H16* __restrict__ p, int64_t i) {
+  return (float)__builtin_bit_cast(_Float16, p[i].v);
+}
+template <>
+__device__ __forceinline__ float ldv<float, B16>(const B16* __restrict__ p, int64_t i) {
+  return __builtin_bit_cast(float, (unsigned)p[i].v << 16);
+}
+template <typename T, typename S>
+__device__ __forceinline__ void stv(S* __restrict__ p, int64_t i, T v) { p[i] = (S)v; }
+template <>
+__device__ __forceinline__ void stv<float, H16>(H16* __restrict__ p, int64_t i, float v) {
+  p[i].v = __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+template <>
+__device__ __forceinline__ void stv<float, B16>(B16* __restrict__ p, int64_t i, float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  // round to nearest even; NaN keeps a quiet payload
+  p[i].v = (v != v) ? (unsigned short)((u >> 16) | 0x40) : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 template <typename T>
 struct Axis {
   T w0, w1;   // om(0), om(1)
@@ -128,14 +157,14 @@ struct Point {
   Geom g;
 };
 
-template <typename T>
-__device__ __forceinline__ Point<T> make_point(const T* __restrict__ grid, int64_t pt,
+template <typename T, typename S = T>
+__device__ __forceinline__ Point<T> make_point(const S* __restrict__ grid, int64_t pt,
                                                const pv2_volume_desc& v, int padding, bool align,
                                                bool smooth) {
   Point<T> p;
-  p.ax = make_axis<T>(grid[pt * 3 + 0], v.w, padding, align, smooth);
-  p.ay = make_axis<T>(grid[pt * 3 + 1], v.h, padding, align, smooth);
-  p.az = make_axis<T>(grid[pt * 3 + 2], v.d, padding, align, smooth);
+  p.ax = make_axis<T>(ldv<T, S>(grid, pt * 3 + 0), v.w, padding, align, smooth);
+  p.ay = make_axis<T>(ldv<T, S>(grid, pt * 3 + 1), v.h, padding, align, smooth);
+  p.az = make_axis<T>(ldv<T, S>(grid, pt * 3 + 2), v.d, padding, align, smooth);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int64_t ix = p.ax.i0 + (c & 1), iy = p.ay.i0 + ((c >> 1) & 1), iz = p.az.i0 + (c >> 2);
@@ -160,43 +189,43 @@ __device__ __forceinline__ T wave_sum(T v) {
     w[c] = wx * wy * wz;                                                \
   }
 
-template <typename T>
-__global__ __launch_bounds__(256) void tri_fwd_kernel(const T* __restrict__ in, pv2_volume_desc v,
-                                                      const T* __restrict__ grid,
-                                                      pv2_points_desc pd, T* __restrict__ out,
+template <typename T, typename S = T>
+__global__ __launch_bounds__(256) void tri_fwd_kernel(const S* __restrict__ in, pv2_volume_desc v,
+                                                      const S* __restrict__ grid,
+                                                      pv2_points_desc pd, S* __restrict__ out,
                                                       int padding, int align, int smooth) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
     const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
-    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
+    const Point<T> p = make_point<T, S>(grid, pt, v, padding, align != 0, smooth != 0);
     T w[8];
     PV2_CORNER_WEIGHTS(p, w)
-    const T* base = in + n * v.sn;
-    T* obase = out + n * pd.o_sn + q * pd.o_sp;
+    const S* base = in + n * v.sn;
+    S* obase = out + n * pd.o_sn + q * pd.o_sp;
     for (int64_t ch = lane; ch < v.c; ch += 64) {
-      const T* src = base + ch * v.sc;
+      const S* src = base + ch * v.sc;
       T acc = T(0);
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        if (p.g.inb[c]) acc += src[p.g.off[c]] * w[c];
-      obase[ch * pd.o_sc] = acc;
+        if (p.g.inb[c]) acc += ldv<T, S>(src, p.g.off[c]) * w[c];
+      stv<T, S>(obase, ch * pd.o_sc, acc);
     }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void tri_bwd_kernel(const T* __restrict__ gout,
-                                                      const T* __restrict__ in, pv2_volume_desc v,
-                                                      const T* __restrict__ grid,
+template <typename T, typename S = T>
+__global__ __launch_bounds__(256) void tri_bwd_kernel(const S* __restrict__ gout,
+                                                      const S* __restrict__ in, pv2_volume_desc v,
+                                                      const S* __restrict__ grid,
                                                       pv2_points_desc pd, T* __restrict__ gin,
-                                                      T* __restrict__ ggrid, int padding,
+                                                      S* __restrict__ ggrid, int padding,
                                                       int align, int smooth) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
     const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
-    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
+    const Point<T> p = make_point<T, S>(grid, pt, v, padding, align != 0, smooth != 0);
     T w[8], dx[8], dy[8], dz[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -208,17 +237,17 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(const T* __restrict__ gout
       dy[c] = wx * sy * wz;
       dz[c] = wx * wy * sz;
     }
-    const T* base = in + n * v.sn;
+    const S* base = in + n * v.sn;
     T* gbase = gin ? gin + n * v.sn : nullptr;
-    const T* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    const S* gobase = gout + n * pd.o_sn + q * pd.o_sp;
     T gx = T(0), gy = T(0), gz = T(0);
     for (int64_t ch = lane; ch < v.c; ch += 64) {
-      const T go = gobase[ch * pd.o_sc];
-      const T* src = base + ch * v.sc;
+      const T go = ldv<T, S>(gobase, ch * pd.o_sc);
+      const S* src = base + ch * v.sc;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (p.g.inb[c]) {
-          const T val = src[p.g.off[c]];
+          const T val = ldv<T, S>(src, p.g.off[c]);
           gx += go * val * dx[c];
           gy += go * val * dy[c];
           gz += go * val * dz[c];
@@ -230,25 +259,26 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(const T* __restrict__ gout
     gy = wave_sum(gy);
     gz = wave_sum(gz);
     if (lane == 0) {
-      ggrid[pt * 3 + 0] = gx;
-      ggrid[pt * 3 + 1] = gy;
-      ggrid[pt * 3 + 2] = gz;
+      stv<T, S>(ggrid, pt * 3 + 0, gx);
+      stv<T, S>(ggrid, pt * 3 + 1, gy);
+      stv<T, S>(ggrid, pt * 3 + 2, gz);
     }
   }
 }
 
-template <typename T>
+template <typename T, typename S = T>
 __global__ __launch_bounds__(256) void tri_bwdbwd_kernel(
-    const T* __restrict__ hV, const T* __restrict__ hG, const T* __restrict__ in,
-    pv2_volume_desc v, const T* __restrict__ grid, const T* __restrict__ gout, pv2_points_desc pd,
-    T* __restrict__ gin2, T* __restrict__ ggrid2, T* __restrict__ ggout, int padding, int align,
+    const S* __restrict__ hV, const S* __restrict__ hG, const S* __restrict__ in,
+    pv2_volume_desc v, const S* __restrict__ grid, const S* __restrict__ gout, pv2_points_desc pd,
+    T* __restrict__ gin2, S* __restrict__ ggrid2, S* __restrict__ ggout, int padding, int align,
     int smooth) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pt < pd.n_points; pt += nwaves) {
     const int64_t n = pt / pd.points_per_n, q = pt % pd.points_per_n;
-    const Point<T> p = make_point<T>(grid, pt, v, padding, align != 0, smooth != 0);
-    const T hx = hG[pt * 3 + 0], hy = hG[pt * 3 + 1], hz = hG[pt * 3 + 2];
+    const Point<T> p = make_point<T, S>(grid, pt, v, padding, align != 0, smooth != 0);
+    const T hx = ldv<T, S>(hG, pt * 3 + 0), hy = ldv<T, S>(hG, pt * 3 + 1),
+            hz = ldv<T, S>(hG, pt * 3 + 2);
     T w[8], dx[8], dy[8], dz[8], D[8], ex[8], ey[8], ez[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -267,21 +297,21 @@ __global__ __launch_bounds__(256) void tri_bwdbwd_kernel(
       ey[c] = hx * (sx * sy * wz) + hy * (wx * cy * wz) + hz * (wx * sy * sz);
       ez[c] = hx * (sx * wy * sz) + hy * (wx * sy * sz) + hz * (wx * wy * cz);
     }
-    const T* base = in + n * v.sn;
-    const T* hbase = hV ? hV + n * v.sn : nullptr;
+    const S* base = in + n * v.sn;
+    const S* hbase = hV ? hV + n * v.sn : nullptr;
     T* gbase = gin2 ? gin2 + n * v.sn : nullptr;
-    const T* gobase = gout + n * pd.o_sn + q * pd.o_sp;
-    T* ggobase = ggout + n * pd.o_sn + q * pd.o_sp;
+    const S* gobase = gout + n * pd.o_sn + q * pd.o_sp;
+    S* ggobase = ggout + n * pd.o_sn + q * pd.o_sp;
     T gx = T(0), gy = T(0), gz = T(0);
     for (int64_t ch = lane; ch < v.c; ch += 64) {
-      const T go = gobase[ch * pd.o_sc];
+      const T go = ldv<T, S>(gobase, ch * pd.o_sc);
       const int64_t choff = ch * v.sc;
       T ggo = T(0);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (p.g.inb[c]) {
-          const T val = base[choff + p.g.off[c]];
-          const T hv = hbase ? hbase[choff + p.g.off[c]] : T(0);
+          const T val = ldv<T, S>(base, choff + p.g.off[c]);
+          const T hv = hbase ? ldv<T, S>(hbase, choff + p.g.off[c]) : T(0);
           ggo += val * D[c] + hv * w[c];
           gx += go * (hv * dx[c] + val * ex[c]);
           gy += go * (hv * dy[c] + val * ey[c]);
@@ -289,15 +319,15 @@ __global__ __launch_bounds__(256) void tri_bwdbwd_kernel(
           if (gbase) unsafeAtomicAdd(gbase + choff + p.g.off[c], go * D[c]);
         }
       }
-      ggobase[ch * pd.o_sc] = ggo;
+      stv<T, S>(ggobase, ch * pd.o_sc, ggo);
     }
     gx = wave_sum(gx);
     gy = wave_sum(gy);
     gz = wave_sum(gz);
     if (lane == 0) {
-      ggrid2[pt * 3 + 0] = gx;
-      ggrid2[pt * 3 + 1] = gy;
-      ggrid2[pt * 3 + 2] = gz;
+      stv<T, S>(ggrid2, pt * 3 + 0, gx);
+      stv<T, S>(ggrid2, pt * 3 + 1, gy);
+      stv<T, S>(ggrid2, pt * 3 + 2, gz);
     }
   }
 }
@@ -777,9 +807,88 @@ int run_bwdbwd(const T* hV, const T* hG, const T* input, const pv2_volume_desc* 
   return pv2::check_launch("trilinear_backward_backward");
 }
 
+// 16-bit storage (dtype: 1 = bfloat16, 2 = float16, the codes of the other mixed-precision entry
+// points), fp32 arithmetic; grad_input / grad_input2 are FP32 accumulation buffers.
+template <typename S>
+int run_fwd16(const void* input, const pv2_volume_desc* vol, const void* grid,
+              const pv2_points_desc* pts, void* output, int padding, int align, int smooth,
+              pv2_stream_t stream) {
+  hipLaunchKernelGGL((tri_fwd_kernel<float, S>), dim3(pv2::grid_for(pts->n_points * 64, 256)),
+                     dim3(256), 0, (hipStream_t)stream, (const S*)input, *vol, (const S*)grid, *pts,
+                     (S*)output, padding, align, smooth);
+  return pv2::check_launch("trilinear_forward_16");
+}
+template <typename S>
+int run_bwd16(const void* gout, const void* input, const pv2_volume_desc* vol, const void* grid,
+              const pv2_points_desc* pts, float* gin, void* ggrid, int padding, int align,
+              int smooth, pv2_stream_t stream) {
+  hipLaunchKernelGGL((tri_bwd_kernel<float, S>), dim3(pv2::grid_for(pts->n_points * 64, 256)),
+                     dim3(256), 0, (hipStream_t)stream, (const S*)gout, (const S*)input, *vol,
+                     (const S*)grid, *pts, gin, (S*)ggrid, padding, align, smooth);
+  return pv2::check_launch("trilinear_backward_16");
+}
+template <typename S>
+int run_bwdbwd16(const void* hV, const void* hG, const void* input, const pv2_volume_desc* vol,
+                 const void* grid, const void* gout, const pv2_points_desc* pts, float* gin2,
+                 void* ggrid2, void* ggout, int padding, int align, int smooth,
+                 pv2_stream_t stream) {
+  hipLaunchKernelGGL((tri_bwdbwd_kernel<float, S>), dim3(pv2::grid_for(pts->n_points * 64, 256)),
+                     dim3(256), 0, (hipStream_t)stream, (const S*)hV, (const S*)hG,
+                     (const S*)input, *vol, (const S*)grid, (const S*)gout, *pts, gin2,
+                     (S*)ggrid2, (S*)ggout, padding, align, smooth);
+  return pv2::check_launch("trilinear_backward_backward_16");
+}
+
+int check16(const pv2_volume_desc* vol, const pv2_points_desc* pts, int dtype, int padding) {
+  if (int e = check_desc(vol, pts)) return e;
+  PV2_REQUIRE(dtype == 1 || dtype == 2, "trilinear: 16-bit dtype must be 1 (bf16) or 2 (f16)");
+  PV2_REQUIRE(padding >= 0 && padding <= 2, "trilinear: padding_mode must be 0, 1 or 2");
+  return PV2_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int pv2_trilinear_forward_16(const void* input, int dtype, const pv2_volume_desc* vol,
+                             const void* grid, const pv2_points_desc* pts, void* output,
+                             int padding_mode, int align_corners, int apply_smoothstep,
+                             pv2_stream_t stream) {
+  if (int e = check16(vol, pts, dtype, padding_mode)) return e;
+  if (pts->n_points == 0) return PV2_OK;
+  return dtype == 1 ? run_fwd16<B16>(input, vol, grid, pts, output, padding_mode, align_corners,
+                                     apply_smoothstep, stream)
+                    : run_fwd16<H16>(input, vol, grid, pts, output, padding_mode, align_corners,
+                                     apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_16(const void* grad_output, const void* input, int dtype,
+                              const pv2_volume_desc* vol, const void* grid,
+                              const pv2_points_desc* pts, float* grad_input_f32, void* grad_grid,
+                              int padding_mode, int align_corners, int apply_smoothstep,
+                              pv2_stream_t stream) {
+  if (int e = check16(vol, pts, dtype, padding_mode)) return e;
+  if (pts->n_points == 0) return PV2_OK;
+  return dtype == 1 ? run_bwd16<B16>(grad_output, input, vol, grid, pts, grad_input_f32, grad_grid,
+                                     padding_mode, align_corners, apply_smoothstep, stream)
+                    : run_bwd16<H16>(grad_output, input, vol, grid, pts, grad_input_f32, grad_grid,
+                                     padding_mode, align_corners, apply_smoothstep, stream);
+}
+int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid, const void* input,
+                                       int dtype, const pv2_volume_desc* vol, const void* grid,
+                                       const void* grad_output, const pv2_points_desc* pts,
+                                       float* grad_input2_f32, void* grad_grid2,
+                                       void* grad_grad_output, int padding_mode, int align_corners,
+                                       int apply_smoothstep, pv2_stream_t stream) {
+  if (int e = check16(vol, pts, dtype, padding_mode)) return e;
+  if (pts->n_points == 0) return PV2_OK;
+  return dtype == 1
+             ? run_bwdbwd16<B16>(g_ginput, g_ggrid, input, vol, grid, grad_output, pts,
+                                 grad_input2_f32, grad_grid2, grad_grad_output, padding_mode,
+                                 align_corners, apply_smoothstep, stream)
+             : run_bwdbwd16<H16>(g_ginput, g_ggrid, input, vol, grid, grad_output, pts,
+                                 grad_input2_f32, grad_grid2, grad_grad_output, padding_mode,
+                                 align_corners, apply_smoothstep, stream);
+}
 
 int pv2_trilinear_forward_f32(const float* input, const pv2_volume_desc* vol, const float* grid,
                               const pv2_points_desc* pts, float* output, int padding_mode,

@@ -1044,7 +1044,14 @@ def _fn(name: str, dtype: torch.dtype):
         return getattr(_lib.lib(), name + "_f32")
     if dtype == torch.float64:
         return getattr(_lib.lib(), name + "_f64")
-    raise TypeError(f"trilinear sampler supports float32/float64, got {dtype}")
+    raise TypeError(f"trilinear sampler supports float64/float32/float16/bfloat16, got {dtype}")
+
+
+def _same_dtype(what, ref, *tensors):
+    for t in tensors:
+        if t is not None and t.dtype != ref.dtype:
+            raise TypeError(f"{what}: expected every tensor in {ref.dtype}, got {t.dtype} "
+                            "(the reference's extension checks scalar types the same way)")
 
 
 def trilinear_forward(inp, grid, padding_mode="zeros", align_corners=True, smooth=False):
@@ -1057,6 +1064,13 @@ def trilinear_forward(inp, grid, padding_mode="zeros", align_corners=True, smoot
     _, do, ho, wo, _ = grid.shape
     out = _out_layout(n, c, do, ho, wo, inp, channels_last=True)
     vd, pd = _vol_desc(inp), _pts_desc(out)
+    _same_dtype("trilinear_forward", inp, grid)
+    if inp.dtype in HALF_DTYPES:   # 16-bit storage, fp32 arithmetic (smooth_sampler_kernel.cu:630)
+        _lib.check(_lib.lib().pv2_trilinear_forward_16(
+            _ptr(inp), DTYPE_CODE[inp.dtype], ctypes.byref(vd), _ptr(grid), ctypes.byref(pd),
+            _ptr(out), _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
+            "pv2_trilinear_forward_16")
+        return out
     _lib.check(_fn("pv2_trilinear_forward", inp.dtype)(
         _ptr(inp), ctypes.byref(vd), _ptr(grid), ctypes.byref(pd), _ptr(out),
         _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
@@ -1072,10 +1086,19 @@ def trilinear_backward(grad_out, inp, grid, padding_mode, align_corners, smooth,
     if not _single_point_stride(grad_out):
         grad_out = grad_out.contiguous()
     grad_grid = torch.empty_like(grid)
-    grad_in = torch.zeros_like(inp) if need_input_grad else None  # preserves inp's strides
+    _same_dtype("trilinear_backward", inp, grid, grad_out)
+    half = inp.dtype in HALF_DTYPES
+    # preserves inp's strides; the 16-bit path accumulates the volume gradient in fp32
+    grad_in = torch.zeros_like(inp, dtype=torch.float32 if half else None) if need_input_grad else None
     if grad_in is not None:
         assert grad_in.stride() == inp.stride()
     vd, pd = _vol_desc(inp), _pts_desc(grad_out)
+    if half:
+        _lib.check(_lib.lib().pv2_trilinear_backward_16(
+            _ptr(grad_out), _ptr(inp), DTYPE_CODE[inp.dtype], ctypes.byref(vd), _ptr(grid),
+            ctypes.byref(pd), _ptr(grad_in), _ptr(grad_grid), _PADDING[padding_mode],
+            int(align_corners), int(smooth), _stream(inp)), "pv2_trilinear_backward_16")
+        return (None if grad_in is None else grad_in.to(inp.dtype)), grad_grid
     _lib.check(_fn("pv2_trilinear_backward", inp.dtype)(
         _ptr(grad_out), _ptr(inp), ctypes.byref(vd), _ptr(grid), ctypes.byref(pd), _ptr(grad_in),
         _ptr(grad_grid), _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
@@ -1096,11 +1119,20 @@ def trilinear_backward_backward(g_ginput, g_ggrid, inp, grid, grad_out, padding_
         tmp = torch.empty_like(inp)
         tmp.copy_(g_ginput)
         g_ginput = tmp
-    grad_in2 = torch.zeros_like(inp) if need_input_grad else None
+    _same_dtype("trilinear_backward_backward", inp, grid, grad_out, g_ggrid, g_ginput)
+    half = inp.dtype in HALF_DTYPES
+    grad_in2 = torch.zeros_like(inp, dtype=torch.float32 if half else None) if need_input_grad else None
     grad_grid2 = torch.empty_like(grid)
     gg_out = torch.empty_like(grad_out)  # same strides as grad_out (dense permutation)
     assert gg_out.stride() == grad_out.stride()
     vd, pd = _vol_desc(inp), _pts_desc(grad_out)
+    if half:
+        _lib.check(_lib.lib().pv2_trilinear_backward_backward_16(
+            _ptr(g_ginput), _ptr(g_ggrid), _ptr(inp), DTYPE_CODE[inp.dtype], ctypes.byref(vd),
+            _ptr(grid), _ptr(grad_out), ctypes.byref(pd), _ptr(grad_in2), _ptr(grad_grid2),
+            _ptr(gg_out), _PADDING[padding_mode], int(align_corners), int(smooth), _stream(inp)),
+            "pv2_trilinear_backward_backward_16")
+        return (None if grad_in2 is None else grad_in2.to(inp.dtype)), grad_grid2, gg_out
     _lib.check(_fn("pv2_trilinear_backward_backward", inp.dtype)(
         _ptr(g_ginput), _ptr(g_ggrid), _ptr(inp), ctypes.byref(vd), _ptr(grid), _ptr(grad_out),
         ctypes.byref(pd), _ptr(grad_in2), _ptr(grad_grid2), _ptr(gg_out),

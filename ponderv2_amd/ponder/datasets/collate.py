@@ -82,10 +82,12 @@ def _own_collate(samples, inner, mix_prob, max_point):
         samples = _within_budget(samples, max_point)
     batch = inner(samples)
     if mix_prob > 0:
-        # Mix3D halves ``offset``; batches that carry per-scene stacks next to the points (views,
-        # poses, ray offsets, conditions: every pre-training batch) would be left with B scenes of
-        # poses against B/2 scenes of points.  The reference only mixes plain point batches.
-        per_scene = [k for k in ("rgb", "depth", "extrinsic", "intrinsic", "ray_offset", "condition")
+        # Mix3D halves ``offset``; batches that carry per-scene TENSOR stacks next to the points
+        # (views, poses, ray offsets: every pre-training batch) would be left with B scenes of poses
+        # against B/2 scenes of points.  ``condition`` is not such a stack: the reference's PPT
+        # fine-tuning configs collect it with mix_prob = 0.8 and the model reads condition[0] only
+        # (configs/scannet/semseg-ppt-v1m1-0-sc-s3-st-spunet-lovasz-ft.py) - it passes through.
+        per_scene = [k for k in ("rgb", "depth", "extrinsic", "intrinsic", "ray_offset")
                      if k in batch]
         if per_scene:
             raise ValueError(

@@ -21,6 +21,7 @@ from ..datasets.collate import loader_collate
 from ..datasets.voxelize import device_grid_sample
 from .defaults import create_ddp_model, worker_init_fn
 from .hooks import HOOKS, HookBase
+from ponderv2_amd.rownorm import flush_bn_counters
 
 TRAINERS = Registry("trainers")
 DATASETS = Registry("datasets")
@@ -86,6 +87,10 @@ class TrainerBase:
                 self._call("before_step")
                 self.run_step()
                 self._call("after_step")
+            # the fused BatchNorm paths count ``num_batches_tracked`` on the host (rownorm.py); the
+            # epoch-end hooks (evaluators, checkpoints, anything that copies the model or reads
+            # ``model.buffers()`` directly) must see the buffers current
+            flush_bn_counters(self.model)
             self._call("after_epoch")
         self._call("after_train")
         comm.synchronize()

@@ -6,9 +6,13 @@ features of the voxels inside with the learnable ``mtoken`` row.  The reference 
 draws ``torch.rand(1, n_blocks)`` on the host for each and syncs on ``.item()``; here all scenes are
 ranked in one device pass.
 """
+import os
+
 import torch
 
 from ..utils import offset2batch
+
+_CHECK_RANGE = os.environ.get("PV2_CHECK_MASK_RANGE", "0") == "1"
 
 
 def mask_blocks(grid_coord, feat, offset, size, ratio, mtoken, rand=None):
@@ -26,7 +30,17 @@ def mask_blocks(grid_coord, feat, offset, size, ratio, mtoken, rand=None):
     dev = grid_coord.device
     batch = offset2batch(offset, n).long()
     b = torch.div(grid_coord, size).int().long()   # (true division, then truncation: the reference's :115)
-    # one integer per block, ordered like the rows (scene, bx, by, bz): 16 bits per coordinate
+    # one integer per block, ordered like the rows (scene, bx, by, bz): 16 bits per coordinate,
+    # i.e. block coordinates in [-32768, 32767] and < 32768 scenes.  Out-of-range coordinates are
+    # CLAMPED (no device -> host read, so no exception can be raised from here without a sync):
+    # voxels beyond the limit share the outermost block of their axis instead of spilling into the
+    # neighbouring field of the key.  With the reference's own shapes (nuScenes 1080 x 1080 x 80
+    # voxels, ScanNet < 4096 per axis) block coordinates stay below 2^11.  PV2_CHECK_MASK_RANGE=1
+    # turns the clamp into an assertion (one blocking read; for debugging a new dataset).
+    if _CHECK_RANGE:
+        assert int(b.abs().max()) < 32768 and offset.numel() < 32768, \
+            "block masking packs 16 bits per block coordinate"
+    b = b.clamp(-32768, 32767)
     key = (batch << 48) | ((b[:, 0] + 32768) << 32) | ((b[:, 1] + 32768) << 16) | (b[:, 2] + 32768)
     skey, perm = torch.sort(key)
     pos = torch.arange(n, device=dev)

@@ -112,6 +112,15 @@ class _FusedBNFunction(torch.autograd.Function):
         return dx, dweight, dbias, dres, None, None, None, None, None, None
 
 
+def _momentum(bn):
+    """The running-average factor of this call (``momentum=None``: the cumulative average)."""
+    if bn.momentum is not None:
+        return bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        return 1.0 / float(bn.num_batches_tracked)
+    return 0.0
+
+
 def can_fuse(bn, x):
     """True when the rownorm.hip kernels cover this call: a training-mode device matrix.  Autocast
     does not change the answer - the kernels are fp32 launches it never touches; reduced-precision
@@ -128,10 +137,21 @@ def fused_bn(bn, x, residual=None, relu=False, weight=None, bias=None):
     ``weight`` / ``bias`` (C,) replace the module's affine pair in the kernel epilogue: prompt-driven
     normalisation folds its per-condition modulation ``y * (1 + scale) + shift`` into them
     (spconv_unet_v1m3_pdnorm.py), gradients flow back to whatever produced them.  Callers that
-    pass them must check ``can_fuse`` first - the module fallback only knows its own parameters."""
+    may pass them whatever ``can_fuse`` says: the fallback is ``F.batch_norm`` with the same pair."""
     if not can_fuse(bn, x):
-        assert weight is None and bias is None, "affine overrides need the kernel path (can_fuse)"
-        y = bn(x)
+        if weight is None and bias is None:
+            y = bn(x)
+        else:
+            # the same normalisation with the caller's affine pair (a one-row output of a strided
+            # conv, eval mode, a host tensor: whatever kept the kernels away)
+            if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            use_batch = bn.training or bn.running_mean is None
+            y = F.batch_norm(x, None if use_batch and not bn.track_running_stats else bn.running_mean,
+                             None if use_batch and not bn.track_running_stats else bn.running_var,
+                             bn.weight if weight is None else weight.to(x.dtype),
+                             bn.bias if bias is None else bias.to(x.dtype),
+                             use_batch, _momentum(bn), bn.eps)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y

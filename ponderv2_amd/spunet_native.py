@@ -360,13 +360,18 @@ class SpUNetFunction(torch.autograd.Function):
         for a, (rows, ch) in enumerate(plan.acts):
             if (a != 0 or want_dx) and a != plan.out_act:
                 g_off[a] = arena.reserve(rows * ch)
+        # parameter gradients live in their OWN (small) arena: ``AccumulateGrad`` keeps the returned
+        # views as ``param.grad`` until the next ``zero_grad`` - carved from the activation-gradient
+        # arena they would pin its ~GB through the following forward
+        parena = _Arena()
         for u in plan.units:
             if u.kind == UNET_CONCAT:
                 continue
             u.dy_off = arena.reserve(u.n_out * u.c_out)
-            u.gsum_off = arena.reserve(2 * u.c_out)
-            u.dw_off = arena.reserve(u.c_out * u.rb.K * u.c_in)
+            u.gsum_off = parena.reserve(2 * u.c_out)
+            u.dw_off = parena.reserve(u.c_out * u.rb.K * u.c_in)
         arena.allocate(dev)
+        parena.allocate(dev)
         g_ptr = [None if off is None else arena.ptr(off) for off in g_off]
         g_ptr[plan.out_act] = grad_out.data_ptr()
         ops = plan.ops
@@ -377,7 +382,7 @@ class SpUNetFunction(torch.autograd.Function):
             op.dres = g_ptr[u.res] if u.res is not None else None
             if u.kind == UNET_CONCAT:
                 continue
-            op.dy, op.gsum, op.dweight = arena.ptr(u.dy_off), arena.ptr(u.gsum_off), arena.ptr(u.dw_off)
+            op.dy, op.gsum, op.dweight = arena.ptr(u.dy_off), parena.ptr(u.gsum_off), parena.ptr(u.dw_off)
             if u.kind == UNET_CONV_BN:
                 part_floats = max(part_floats, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
                     u.c_in, u.c_out, u.geom.n_tiles_w)))
@@ -392,7 +397,8 @@ class SpUNetFunction(torch.autograd.Function):
             # read - released with ``ctx.plan = None`` below while those kernels were still queued,
             # the arrays could be handed to the next allocation on this stream BEFORE the join:
             # a memory fault once in a few runs of the full-size fixtures)
-            side = sidestream.native_fork(dev, (plan.fwd.tensor, arena.tensor, ctx.feats, grad_out, plan))
+            side = sidestream.native_fork(dev, (plan.fwd.tensor, arena.tensor, parena.tensor, ctx.feats,
+                                                grad_out, plan))
             part = K.workspace("wgrad", dev, part_floats, stream=side)
         else:
             part = K.workspace("wgrad", dev, part_floats)
@@ -404,10 +410,10 @@ class SpUNetFunction(torch.autograd.Function):
         grads = [None] * len(tensors)
         convs = [u for u in plan.units if u.kind != UNET_CONCAT]
         specs = []
-        for u in convs:   # (reserved in this order per unit: dy, gsum, dweight)
+        for u in convs:   # (reserved in this order per unit: gsum, dweight)
             specs += [(u.gsum_off, u.c_out), (u.gsum_off + u.c_out, u.c_out),
                       (u.dw_off, tensors[u.w_index].numel())]
-        pieces = arena.views(specs)
+        pieces = parena.views(specs)
         for j, u in enumerate(convs):
             i = u.w_index
             grads[i] = pieces[3 * j + 2].view(tensors[i].shape)

@@ -423,6 +423,59 @@ def test_sampler_second_order_vs_oracle_f32(device, C, B, channels_last, padding
         assert err < 2e-4, (name, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_sampler_half_dispatch_vs_oracle(device, dtype, channels_last):
+    """The sampler on 16-bit tensors - the half branch of the reference's dispatch
+    (smooth_sampler_kernel.cu:630,670,726 AT_DISPATCH_FLOATING_TYPES_AND_HALF), which its shipped
+    ``enable_amp=True`` configs reach.  Each of the three entry points is compared with the float64
+    oracle evaluated on the SAME 16-bit-rounded operands; what is left is the rounding of the 16-bit
+    results (fp32 arithmetic, fp32 volume-gradient accumulation): a few units of the type's epsilon
+    relative to the largest entry."""
+    from oracle.sampler import SmoothSampler as OSampler
+    from ponderv2_amd.smooth_sampler import SmoothSampler
+
+    torch.manual_seed(23)
+    B, C, D, H, W, R, S = 2, 24, 5, 7, 9, 29, 7
+    vol = torch.randn(B, C, D, H, W).to(dtype)
+    grid = away_from_kinks(torch.rand(B, 1, R, S, 3) * 2.3 - 1.15, (W, H, D), True).to(dtype)
+    go = torch.randn(B, C, 1, R, S).to(dtype)
+    hV = torch.randn(B, C, D, H, W).to(dtype)
+    hG = torch.randn(B, 1, R, S, 3).to(dtype)
+
+    def run(sampler, cast):
+        v, g, o = (cast(t).requires_grad_(True) for t in (vol, grid, go))
+        out = sampler.apply(v, g, "zeros", True, False)
+        g_in, g_grid = torch.autograd.grad(out, [v, g], o, create_graph=True)
+        second = torch.autograd.grad([g_in, g_grid], [v, g, o], [cast(hV), cast(hG)])
+        return (out.detach(), g_in.detach(), g_grid.detach()) + tuple(second)
+
+    def to_dev(t):
+        t = t.to(device)
+        if channels_last and t.dim() == 5 and t.shape[1] == C and t.shape[2] == D:
+            t = t.contiguous(memory_format=torch.channels_last_3d)
+        return t
+
+    ref = run(OSampler, lambda t: t.double())
+    got = run(SmoothSampler, to_dev)
+    eps = torch.finfo(dtype).eps
+    names = ("out", "grad_input", "grad_grid", "grad_input2", "grad_grid2", "grad_grad_out")
+    for name, a, b in zip(names, got, ref):
+        assert a.dtype == dtype, (name, a.dtype)
+        err = (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        assert err < 4 * eps, (name, err, eps)
+
+
+def test_sampler_rejects_mixed_dtypes(device):
+    """Like the reference's extension (one scalar type per call), no silent widening."""
+    from ponderv2_amd.smooth_sampler import SmoothSampler
+
+    vol = torch.randn(1, 4, 3, 3, 3, device=device, dtype=torch.float16)
+    grid = torch.zeros(1, 1, 1, 2, 3, device=device)
+    with pytest.raises(TypeError, match="expected every tensor"):
+        SmoothSampler.apply(vol, grid, "zeros", True, False)
+
+
 # ------------------------------------------------------------------ sparse first dense layer
 @pytest.mark.parametrize("with_bn", [True, False])
 def test_sparse_first_layer_equals_dense_layer_gpu(device, with_bn):

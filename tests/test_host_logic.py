@@ -375,6 +375,17 @@ def test_loaders_apply_the_point_budget_of_the_config():
 
     mixed = loader_collate(OwnCollate(), mix_prob=1.0)([Scenes()[0], Scenes()[1]])
     assert mixed["offset"].tolist() == [30]
+
+    class Conditioned(Scenes):   # the reference's PPT fine-tuning batches: points + "condition"
+        @staticmethod             # with mix_prob = 0.8 (semseg-ppt-v1m1-0-sc-s3-st-spunet-lovasz-ft.py)
+        def collate_fn(batch):
+            out = point_collate_fn([{k: v for k, v in b.items() if k != "condition"} for b in batch])
+            out["condition"] = [b["condition"] for b in batch]
+            return out
+
+    tagged = [dict(Scenes()[i], condition="ScanNet") for i in range(2)]
+    mixed = loader_collate(Conditioned(), mix_prob=1.0)(tagged)
+    assert mixed["offset"].tolist() == [30] and mixed["condition"][0] == "ScanNet"
     # the multi-dataset loader no longer refuses the reference's settings
     loader = MultiDatasetDataloader(ConcatDataset([Scenes(), Scenes()], loop=1), 2, 0, mix_prob=0,
                                     seed=3, max_point=2000000)
@@ -664,6 +675,26 @@ def test_pending_batchnorm_counts_do_not_survive_a_checkpoint_load():
     model = torch.nn.Sequential(bn)
     rownorm.flush_bn_counters(model)        # for direct readers of the buffers (EMA copy, broadcast)
     assert int(bn.num_batches_tracked) == 11 and bn._pv2_pending_batches == 0
+
+
+def test_fused_bn_affine_overrides_fall_back_to_the_same_normalisation():
+    """rownorm.fused_bn with an affine override where the kernels do not apply (host tensor, one
+    row, eval mode): F.batch_norm with the caller's pair - not an assertion."""
+    from ponderv2_amd.rownorm import fused_bn
+
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm1d(5)
+    x, w, b = torch.randn(9, 5), torch.randn(5), torch.randn(5)
+    res = torch.randn(9, 5)
+    got = fused_bn(bn, x, residual=res, relu=True, weight=w, bias=b)
+    xh = (x - x.mean(0)) / torch.sqrt(x.var(0, unbiased=False) + bn.eps)
+    assert torch.allclose(got, torch.relu(xh * w + b + res), atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    assert torch.allclose(bn.running_mean, 0.1 * x.mean(0), atol=1e-6)
+    bn.eval()
+    got = fused_bn(bn, x, weight=w, bias=b)
+    want = (x - bn.running_mean) / torch.sqrt(bn.running_var + bn.eps) * w + b
+    assert torch.allclose(got, want, atol=1e-6)
 
 
 def test_arena_views_split_matches_per_piece_views():
