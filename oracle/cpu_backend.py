@@ -79,7 +79,7 @@ class _ConvApply:
 
 class _ScatterApply:
     @staticmethod
-    def apply(src, index, out, mean):
+    def apply(out, src, index, mean):
         with _no_autocast():
             return oracle_scatter(src, index, dim=0, out=out, reduce="mean" if mean else "sum")
 

@@ -62,7 +62,9 @@ def install(num_classes=20, dim=512, seed=0):
     table = table / table.norm(dim=-1, keepdim=True)
 
     def clip_load(name, device="cpu", download_root=None):
-        return _FakeClipModel(table), None
+        # the reference asks for "cuda" whenever a GPU is visible (ponder_indoor_base.py:87-90) and
+        # moves the tokens there: the stand-in's table has to live on the same device
+        return _FakeClipModel(table.to(device)), None
 
     def clip_tokenize(prompts):
         # prompts are class-major with T templates per class; the reference then views the

@@ -960,10 +960,16 @@ class SparseConvIntoFunction(torch.autograd.Function):
 # Dense scatter (to_dense)
 # --------------------------------------------------------------------------------------------
 class ScatterRowsFunction(torch.autograd.Function):
-    """out[index[i]] (+)= src[i], optionally averaged over the rows landing in each bin."""
+    """out[index[i]] (+)= src[i], optionally averaged over the rows landing in each bin; IN PLACE on
+    ``out`` like ``torch_scatter.scatter(..., out=out)`` (whose sum / mean are ``out.scatter_add_``
+    underneath).  ``out`` is the FIRST input on purpose: the reference passes a VIEW
+    (``fea_grid[i] = scatter(feat, idx, out=fea_grid[i])``, ponder_indoor_base.py:214) and autograd
+    rebases an in-place op on a view through ``CopySlices``, which routes the gradient of input 0 -
+    and only input 0 - back into the base.  With ``src`` first, the row gradients would have been
+    copied over the grid gradient's slice (a size-mismatch error, or silently wrong numbers)."""
 
     @staticmethod
-    def forward(ctx, src, index, out, mean: bool):
+    def forward(ctx, out, src, index, mean: bool):
         _require_device(src, index, out)
         src = src.contiguous()
         index = index.reshape(-1).contiguous()
@@ -989,11 +995,16 @@ class ScatterRowsFunction(torch.autograd.Function):
         index, count = ctx.saved_tensors
         m, c, g = ctx.shape
         grad_out = grad_out.contiguous()
-        dsrc = torch.empty((m, c), dtype=torch.float32, device=grad_out.device)
-        _lib.check(_lib.lib().pv2_scatter_backward(
-            _ptr(grad_out), _ptr(index), _ptr(count) if ctx.mean else None, m, c, _ptr(dsrc), g,
-            _stream(grad_out)), "pv2_scatter_backward")
-        return dsrc, None, None, None
+        dsrc = None
+        if ctx.needs_input_grad[1]:
+            dsrc = torch.empty((m, c), dtype=torch.float32, device=grad_out.device)
+            _lib.check(_lib.lib().pv2_scatter_backward(
+                _ptr(grad_out), _ptr(index), _ptr(count) if ctx.mean else None, m, c, _ptr(dsrc), g,
+                _stream(grad_out)), "pv2_scatter_backward")
+        dout = None
+        if ctx.needs_input_grad[0]:   # what was in ``out`` before: summed as is / divided like the rows
+            dout = grad_out / count.clamp(min=1.0)[:, None] if ctx.mean else grad_out
+        return dout, dsrc, None, None
 
 
 # --------------------------------------------------------------------------------------------

@@ -18,4 +18,4 @@ def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
         if dim_size is None:
             dim_size = int(index.max().item()) + 1 if index.numel() else 0
         out = torch.zeros((dim_size, src.shape[1]), dtype=src.dtype, device=src.device)
-    return ScatterRowsFunction.apply(src, index.long(), out, reduce == "mean")
+    return ScatterRowsFunction.apply(out, src, index.long(), reduce == "mean")

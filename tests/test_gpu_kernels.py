@@ -340,6 +340,34 @@ def test_scatter_mean_vs_oracle(device):
     assert (s_dev.grad.double().cpu() - s_ref.grad).abs().max() < 1e-5
 
 
+def test_scatter_into_a_view_like_the_reference_to_dense(device):
+    """The reference's call pattern (ponder_indoor_base.py:214): ``fea_grid[i] = scatter(feat, idx,
+    dim=0, reduce="mean", out=fea_grid[i])`` - ``out`` is a VIEW of the batch grid, modified in
+    place; the gradient of every scene's rows must come back through the base tensor."""
+    from oracle.scatter import scatter as oscatter
+    from ponderv2_amd.torch_scatter import scatter
+
+    torch.manual_seed(1)
+    m, c, g, scenes = 900, 24, 64, 3
+    srcs = [torch.randn(m + 7 * i, c) for i in range(scenes)]
+    idxs = [torch.randint(0, g, (m + 7 * i, 1)) for i in range(scenes)]
+    probe = torch.randn(scenes, g, c)
+
+    def run(fn, dev, dtype):
+        leaves = [s.to(dev, dtype).requires_grad_(True) for s in srcs]
+        grid = torch.zeros(scenes, g, c, device=dev, dtype=dtype)
+        for i in range(scenes):
+            grid[i] = fn(leaves[i] * (i + 1.0), idxs[i].to(dev), dim=0, reduce="mean", out=grid[i])
+        (grid * probe.to(dev, dtype)).sum().backward()
+        return grid.detach(), [l.grad for l in leaves]
+
+    ref_grid, ref_grads = run(oscatter, "cpu", torch.float64)
+    got_grid, got_grads = run(scatter, device, torch.float32)
+    assert (got_grid.double().cpu() - ref_grid).abs().max() < 1e-5
+    for a, b in zip(got_grads, ref_grads):
+        assert a is not None and (a.double().cpu() - b).abs().max() < 1e-5
+
+
 # ------------------------------------------------------------------ trilinear sampler
 @pytest.mark.parametrize("padding_mode", ["zeros", "border", "reflection"])
 @pytest.mark.parametrize("align_corners", [True, False])
