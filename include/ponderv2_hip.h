@@ -432,6 +432,14 @@ int pv2_bn_backward_mixed(const void* dy, const void* x, int x_dtype, const void
                           int c, float* workspace, float* gsum, void* dx,
                           void* dresidual_or_null, pv2_stream_t stream);
 /* out[c] = sum_r x[r, c] */
+/* Training-mode statistics of the rows of x [n, c] without applying them: mean_invstd [2c], the
+ * running statistics (as pv2_bn_forward), and affine [2c] = (weight * invstd, bias - mean * weight *
+ * invstd) - BatchNorm as one multiply-add, folded into the load path of the convolution that follows
+ * it (nn.BatchNorm3d in SingleConv order "bcr", unet3d.py:125-156 -> pv2_dconv3_forward's in_scale /
+ * in_shift).  workspace: pv2_bn_workspace_floats(c). */
+int pv2_bn_statistics(const float* x, int64_t n, int c, const float* weight, const float* bias,
+                      float eps, float momentum, float* running_mean, float* running_var,
+                      float* workspace, float* mean_invstd, float* affine, pv2_stream_t stream);
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -785,6 +793,46 @@ int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid
                                        float* grad_input2_f32, void* grad_grid2,
                                        void* grad_grad_output, int padding_mode, int align_corners,
                                        int apply_smoothstep, pv2_stream_t stream);
+
+/* ---- Dense 3x3x3 convolutions of the projection network (csrc/dense_conv.hip) -------------------
+ * Replace the cuDNN / MIOpen convolutions behind nn.Conv3d(k3, p1) and nn.ConvTranspose3d(k3, s2, p1)
+ * of the reference's UNet3D-v1m2 (ponder/models/ponder/unet3d.py:45-156 SingleConv "bcr", :292-356
+ * Encoder, :359-493 Decoder / Upsampling) - forward, grad-input, grad-weight.  Grids are fp32
+ * (b, z, y, x, c): the channels_last_3d storage of a (b, c, z, y, x) tensor.
+ *
+ * pv2_dconv3_pack_weights: the weight in MFMA fragment order, once per optimiser step.
+ *   packed[t][ck][nb][s][lane][q] = w[out*s_out + red*s_red + kz*s_z + ky*s_y + kx*s_x] with out = nb*32
+ *   + (lane & 31), red = ck*16 + 8s + 4(lane >> 5) + q, (kz,ky,kx) = tap (flip ? 26 - t : t).
+ *   n_out % 32 == 0 (the output channels of the launch that will use it), n_red % 16 == 0.
+ *     conv forward:        out = dim 0 of the Conv3d weight [C_out, C_in, 3,3,3], red = dim 1, flip 0
+ *     conv grad-input:     out = dim 1, red = dim 0, flip 1
+ *     transposed forward:  ConvTranspose3d weight [C_in, C_out, 3,3,3]: out = dim 1, red = dim 0, flip 0
+ *     transposed grad-in:  out = dim 0, red = dim 1, flip 0   (mode 2 below)
+ * pv2_dconv3_forward: out = [relu]( conv(mask(x * in_scale + in_shift)) + bias + addend )
+ *   mode 0: conv k3 s1 p1, out grid = in grid;  mode 1: transposed conv k3 s2 p1, out = 2 x in per axis
+ *   (bias / addend only);  mode 2: strided conv k3 s2 p1, out = in / 2 (even sizes): mode 1's grad-input.
+ *   in_scale / in_shift [c_in] or NULL: the BatchNorm3d in front of the conv (zero padding AFTER it);
+ *   in_mask_src [as x] or NULL: x is zeroed where in_mask_src <= 0 (ReLU backward); bias [c_out] or
+ *   NULL; addend [as out] or NULL (the decoder's skip features, unet3d.py:401-411).
+ * pv2_dconv3_backward_weight: dw[n*s_n + c*s_c + kz*s_z + ky*s_y + kx*s_x] = sum over cells of
+ *   mask(gy)[cell_g][n] * (x * in_scale + in_shift)[cell_x][c]; mode 0 (conv k3 s1 p1: x the conv
+ *   input [b,z,y,xx,c_x], gy [b,z,y,xx,c_g]) or mode 1 (transposed: x the coarse input, gy
+ *   [b,2z,2y,2xx,c_g]).  Partial slabs in partial_ws (pv2_dconv3_wgrad_partial_floats), summed in a fixed
+ *   order: bitwise repeatable.  c_x % 32 == 0, c_g % 32 == 0. */
+int64_t pv2_dconv3_packed_floats(int c_out, int c_in);
+int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
+                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, float* packed,
+                            pv2_stream_t stream);
+int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
+                       int c_out, int mode, const float* in_scale, const float* in_shift,
+                       const float* in_mask_src, const float* bias, const float* addend, int relu,
+                       float* out, pv2_stream_t stream);
+int64_t pv2_dconv3_wgrad_partial_floats(int b, int z, int y, int xx, int c_x, int c_g, int mode);
+int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int c_x,
+                               const float* in_scale, const float* in_shift, const float* gy,
+                               int c_g, const float* gy_mask_src, int mode, float* partial_ws,
+                               float* dw, int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y,
+                               int64_t s_x, pv2_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,919 @@
+// Dense 3x3x3 convolutions of the projection network (UNet3D-v1m2) on gfx950: fp32 MFMA implicit
+// GEMM over channels-last grids, the input tile and its halo staged ONCE in LDS and re-used by all
+// 27 taps.
+//
+// Stands in for the MIOpen / composable-kernel convolutions behind nn.Conv3d(k3, p1) and
+// nn.ConvTranspose3d(k3, s2, p1) of the reference's ponder/models/ponder/unet3d.py (SingleConv
+// :45-156 order "bcr", Encoder :292-356, Decoder :359-444, Upsampling :447-493) - forward,
+// grad-input and grad-weight - with what surrounds them folded into the load / store paths:
+// the preceding BatchNorm3d's affine map (x * scale + shift, zero padding applied AFTER it, as the
+// module order batchnorm -> conv demands), the following ReLU, the ReLU mask of the backward pass,
+// the decoder's "skip + upsampled" sum and the transposed conv's bias.
+//
+// Layout: grids are (B, Z, Y, X, C) fp32 (a channels_last_3d view of (B, C, Z, Y, X)); a cell's C
+// channels are contiguous.  MFMA v_mfma_f32_32x32x2_f32 (exact fp32): M = 32 cells of a tile, N =
+// 32 output channels, K = input channels (x 27 taps).
+//   A operand (cells x channels): ds_read_b128 from the LDS halo tile, rows padded by 4 floats
+//     (16 staged channels + 4 = 20, or 8 + 4 = 12): conflict-free for every 16-lane group;
+//   B operand (weights): packed once per optimiser step into MFMA fragment order
+//     (dconv_pack_kernel), so a wave's load is one contiguous 1 KB read that hits L1 / L2 for all
+//     but the first workgroup; prefetched one tap ahead straight into registers - the main loop
+//     has no barrier except around the staging of the next 16-channel chunk.
+// Three shapes of the same loop:
+//   dconv_kernel<NB, MT>   one output cell per iteration cell: conv k3 s1 p1 (forward, and the
+//                          grad-input = the same conv on flipped, transposed weights) and the
+//                          strided conv k3 s2 p1 (grad-input of the transposed conv);
+//   dconvT_kernel          transposed conv k3 s2 p1 (out = 2 x in): 8 output parity classes per
+//                          coarse cell, each with its own accumulator; a tap feeds exactly one class;
+//   dconv_wgrad_kernel     weight gradient of both: K = cells, per-workgroup partial slabs then an
+//                          ordered sum (dconv_wgrad_reduce_kernel): no atomics, bitwise repeatable.
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DGeom {
+  int B, Zi, Yi, Xi;  // input grid (what is staged)
+  int Zo, Yo, Xo;     // output grid
+  int Zt, Yt, Xt;     // iteration grid: M runs over its cells
+  int TZ, TY, TX;     // cell decode of a workgroup tile (powers of two, TZ*TY*TX = 128*MT); cells
+  int eTZ;            // with z >= eTZ do not exist (tiles of grids smaller than a full tile)
+  int lTX, lTY;       // log2(TX), log2(TY)
+  int nTZ, nTY, nTX;  // tiles per axis (z in steps of eTZ)
+  int HZ, HY, HX;     // staged halo box (input cells)
+  int in_mul, in_off; // halo origin = tile origin * in_mul + in_off
+  int cell_mul;       // LDS row of iteration cell (z, y, x) = ((z*cm)*HY + y*cm)*HXr + xrow(x*cm)
+  int xsplit, HXh;    // strided conv: the box's x axis is stored odd / even de-interleaved (HXh each)
+  int HXr;            // row count of the x axis in LDS (HX, or 2*HXh)
+};
+
+__device__ __forceinline__ float4 ld4g(const float* __restrict__ p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+
+__device__ __forceinline__ void keep_positive(float4& v, const float4& m) {
+  if (!(m.x > 0.f)) v.x = 0.f;
+  if (!(m.y > 0.f)) v.y = 0.f;
+  if (!(m.z > 0.f)) v.z = 0.f;
+  if (!(m.w > 0.f)) v.w = 0.f;
+}
+
+__device__ __forceinline__ void affine4(float4& v, const float4& sc, const float4& sh) {
+  v.x = v.x * sc.x + sh.x;
+  v.y = v.y * sc.y + sh.y;
+  v.z = v.z * sc.z + sh.z;
+  v.w = v.w * sc.w + sh.w;
+}
+
+// Stage the CK-channel chunk `ck` of the halo box into LDS: row = halo cell, CK/4 float4 per row,
+// rows padded to CK + 4 floats.  Outside the grid: zeros (the padding of the convolution, applied
+// after the affine map).  Four loads (eight with a mask) are in flight per thread before the first
+// LDS store: the loop is latency-bound otherwise (one L2 / MALL round trip per iteration).
+template <int CK>
+__device__ __forceinline__ void stage_chunk(float* __restrict__ sX, const float* __restrict__ X,
+                                            const DGeom& g, int b, int hz0, int hy0, int hx0,
+                                            int c_in, int ck, const float* __restrict__ in_scale,
+                                            const float* __restrict__ in_shift,
+                                            const float* __restrict__ mask_src, int tid,
+                                            int nthreads) {
+  constexpr int QPR = CK / 4, LDR = CK + 4;
+  const int quad = tid & (QPR - 1);
+  const int c0 = ck * CK + quad * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in_scale != nullptr) {
+    sc = ld4g(in_scale + c0);
+    sh = ld4g(in_shift + c0);
+  }
+  const int total = g.HZ * g.HY * g.HX * QPR;
+  constexpr int U = 4;
+  for (int base = tid; base < total; base += nthreads * U) {
+    float4 v[U], m[U];
+    int dst[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthreads;
+      const int row = idx / QPR;
+      const int hx = row % g.HX;
+      const int t2 = row / g.HX;
+      const int hy = t2 % g.HY, hz = t2 / g.HY;
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      const int xr = g.xsplit ? (hx & 1) * g.HXh + (hx >> 1) : hx;
+      dst[u] = idx < total ? ((hz * g.HY + hy) * g.HXr + xr) * LDR + quad * 4 : -1;
+      ok[u] = idx < total && iz >= 0 && iz < g.Zi && iy >= 0 && iy < g.Yi && ix >= 0 && ix < g.Xi;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      m[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (ok[u]) {
+        const int64_t off = ((((int64_t)b * g.Zi + iz) * g.Yi + iy) * g.Xi + ix) * c_in + c0;
+        v[u] = ld4g(X + off);
+        if (mask_src != nullptr) m[u] = ld4g(mask_src + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (dst[u] < 0) continue;
+      if (ok[u]) {
+        if (in_scale != nullptr) affine4(v[u], sc, sh);
+        if (mask_src != nullptr) keep_positive(v[u], m[u]);  // ReLU backward
+      }
+      *reinterpret_cast<float4*>(&sX[dst[u]]) = v[u];
+    }
+  }
+}
+
+constexpr int kStagePad = 36;  // row stride of the epilogue's 32 x 32 staging tiles
+
+// acc (MFMA layout: column n = lane & 31, rows m = (r & 3) + 8 (r >> 2) + 4 h) -> the wave's LDS
+// staging tile, so the block can leave as 16-byte rows
+__device__ __forceinline__ void acc_to_stage(float* __restrict__ stage, const f32x16& acc, int i, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * kStagePad + i] = acc[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// One output cell per iteration cell.  Workgroup = 4 waves; wave w owns MT M-tiles of 32 cells
+// (cells (w*MT + mt)*32 .. +32 of the tile in x-fastest order) and NB 32-wide output channel
+// blocks: MT*NB independent accumulators.  Packed weights (dconv_pack_kernel):
+//   Wp[t][r8][nb][lane][4]: lane (i, h) holds W[out = nb*32 + i][red = r8*8 + 4h + q][tap t], q = 0..3
+//   - the B fragments of the four MFMAs of one 8-channel reduction step.
+// CK: channels staged per chunk (16; 8 for the strided conv, whose halo box is 8x the tile).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int MT, int CK>
+__global__ __launch_bounds__(256) void dconv_kernel(
+    const float* __restrict__ X, DGeom g, int c_in, const float* __restrict__ Wp, int c_out,
+    int n_groups, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ mask_src, const float* __restrict__ bias,
+    const float* __restrict__ addend, int relu, float* __restrict__ Y) {
+  constexpr int S = CK / 8, LDR = CK + 4;
+  extern __shared__ __attribute__((aligned(16))) float sX[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int grp = blockIdx.x % n_groups;
+  int tile = blockIdx.x / n_groups;
+  const int tx = tile % g.nTX;
+  tile /= g.nTX;
+  const int ty = tile % g.nTY;
+  tile /= g.nTY;
+  const int tz = tile % g.nTZ;
+  const int b = tile / g.nTZ;
+  const int z0 = tz * g.eTZ, y0 = ty * g.TY, x0 = tx * g.TX;
+  const int hz0 = z0 * g.in_mul + g.in_off, hy0 = y0 * g.in_mul + g.in_off,
+            hx0 = x0 * g.in_mul + g.in_off;
+
+  int rowbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = (wave * MT + mt) * 32 + i;
+    const int cx = q & (g.TX - 1), cy = (q >> g.lTX) & (g.TY - 1), cz = q >> (g.lTX + g.lTY);
+    const int xr = cx * g.cell_mul;  // (strided conv: even box column 2 cx -> row cx of the even half)
+    rowbase[mt] = ((cz * g.cell_mul) * g.HY + cy * g.cell_mul) * g.HXr + (g.xsplit ? cx : xr);
+    if (cz >= g.eTZ) rowbase[mt] = 0;  // no such cell: any staged row, the result is dropped
+  }
+
+  f32x16 acc[MT][NB];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
+
+  const int nchunks = c_in / CK;
+  const int nbtot = c_out >> 5;
+  const float4* __restrict__ Wp4 = reinterpret_cast<const float4*>(Wp) + (grp * NB) * 64 + lane;
+  const int64_t wr8 = (int64_t)nbtot * 64;             // float4 per 8-channel step
+  const int64_t wtap = (int64_t)(c_in >> 3) * wr8;     // float4 per tap
+
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck) __syncthreads();  // every wave is done with the previous chunk
+    stage_chunk<CK>(sX, X, g, b, hz0, hy0, hx0, c_in, ck, in_scale, in_shift, mask_src, tid, 256);
+    __syncthreads();
+
+    const float4* __restrict__ wck = Wp4 + (int64_t)ck * S * wr8;
+    float4 bq[NB][S], aq[MT][S];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int s = 0; s < S; ++s) bq[nb][s] = wck[s * wr8 + nb * 64];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        aq[mt][s] = *reinterpret_cast<const float4*>(&sX[rowbase[mt] * LDR + 8 * s + 4 * h]);
+
+    // (the first tap's operands have landed before the loop is entered: otherwise the wait-count
+    // pass, merging loop entry and back edge, waits at the first MFMA of EVERY iteration for
+    // "older" loads - which then are the prefetches just issued)
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll 1
+    for (int t = 0; t < 27; ++t) {
+      float4 bn[NB][S], an[MT][S];
+      if (t + 1 < 27) {  // tap t+1: weights from L1 / L2, cells from LDS - in flight during the MFMAs
+        const int t1 = t + 1;
+        const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+        const int delta = (kz * g.HY + ky) * g.HXr + (g.xsplit ? (kx & 1) * g.HXh + (kx >> 1) : kx);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int s = 0; s < S; ++s) bn[nb][s] = wck[t1 * wtap + s * wr8 + nb * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+            an[mt][s] = *reinterpret_cast<const float4*>(
+                &sX[(rowbase[mt] + delta) * LDR + 8 * s + 4 * h]);
+      }
+      // the scheduler would sink those loads down to their first use (the copies below become the
+      // MFMA operands of the next iteration) and expose a full L2 round trip per tap: pin them
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].x, bq[nb][s].x, acc[mt][nb], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].y, bq[nb][s].y, acc[mt][nb], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].z, bq[nb][s].z, acc[mt][nb], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].w, bq[nb][s].w, acc[mt][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < 27) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int s = 0; s < S; ++s) bq[nb][s] = bn[nb][s];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int s = 0; s < S; ++s) aq[mt][s] = an[mt][s];
+      }
+    }
+  }
+
+  // Epilogue: every 32 x 32 block goes through a wave-private LDS tile and leaves as 16-byte pieces
+  // of output rows (4 store instructions per block instead of 16; the addend arrives the same way).
+  __syncthreads();  // the halo tile is free
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      acc_to_stage(stage, acc[mt][nb], i, h);
+      __builtin_amdgcn_wave_barrier();
+      const int n = (grp * NB + nb) * 32 + 4 * c4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias != nullptr) bv = ld4g(bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = r8 + 8 * j;
+        const int q = (wave * MT + mt) * 32 + m;
+        const int cz = q >> (g.lTX + g.lTY);
+        const int oz = z0 + cz, oy = y0 + ((q >> g.lTX) & (g.TY - 1)), ox = x0 + (q & (g.TX - 1));
+        float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+        if (cz >= g.eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
+        const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+        if (addend != nullptr) {
+          const float4 a = ld4g(addend + off);
+          v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(Y + off) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed conv k3 s2 p1, out = 2 x in per axis: out[o] = sum_t W[t] x[(o + 1 - t) / 2] over the
+// taps with o + 1 - t even.  Per axis: o = 2j -> t = 1 (x[j]);  o = 2j + 1 -> t = 0 (x[j + 1]) and
+// t = 2 (x[j]).  A wave owns 32 coarse cells j and ONE 32-wide output channel block; the 8 output
+// parity classes have one accumulator each; tap (kz, ky, kx) belongs to class p = (k != 1) per
+// axis and reads the coarse cell j + (k == 0).  Weights packed as for dconv_kernel (out = C_out of
+// the transposed conv, red = its C_in).  Epilogue: + bias + addend (the decoder's skip features).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void dconvT_kernel(
+    const float* __restrict__ X, DGeom g, int c_in, const float* __restrict__ Wp, int c_out,
+    int n_groups, const float* __restrict__ bias, const float* __restrict__ addend,
+    float* __restrict__ Y) {
+  constexpr int CK = 16, LDR = CK + 4;
+  extern __shared__ __attribute__((aligned(16))) float sX[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int grp = blockIdx.x % n_groups;
+  int tile = blockIdx.x / n_groups;
+  const int tx = tile % g.nTX;
+  tile /= g.nTX;
+  const int ty = tile % g.nTY;
+  tile /= g.nTY;
+  const int tz = tile % g.nTZ;
+  const int b = tile / g.nTZ;
+  const int z0 = tz * g.eTZ, y0 = ty * g.TY, x0 = tx * g.TX;
+
+  int rowbase;
+  {
+    const int q = wave * 32 + i;
+    const int cx = q & (g.TX - 1), cy = (q >> g.lTX) & (g.TY - 1), cz = q >> (g.lTX + g.lTY);
+    rowbase = cz < g.eTZ ? (cz * g.HY + cy) * g.HX + cx : 0;
+  }
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int nchunks = c_in / CK;
+  const int nbtot = c_out >> 5;
+  const float4* __restrict__ Wp4 = reinterpret_cast<const float4*>(Wp) + grp * 64 + lane;
+  const int64_t wr8 = (int64_t)nbtot * 64;
+  const int64_t wtap = (int64_t)(c_in >> 3) * wr8;
+
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck) __syncthreads();
+    stage_chunk<CK>(sX, X, g, b, z0, y0, x0, c_in, ck, nullptr, nullptr, nullptr, tid, 256);
+    __syncthreads();
+    const float4* __restrict__ wck = Wp4 + (int64_t)ck * 2 * wr8;
+    float4 a[8][2];  // the 8 coarse neighbours j + (dz, dy, dx)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int delta = (((d >> 2) & 1) * g.HY + ((d >> 1) & 1)) * g.HX + (d & 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        a[d][s] = *reinterpret_cast<const float4*>(&sX[(rowbase + delta) * LDR + 8 * s + 4 * h]);
+    }
+    float4 b0 = wck[0], b1 = wck[wr8];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int cls = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
+      const int d = ((kz == 0) << 2) | ((ky == 0) << 1) | (kx == 0);
+      float4 n0 = b0, n1 = b1;
+      if (t + 1 < 27) {  // the next tap's fragments, in flight during this tap's MFMAs (pinned: the
+        n0 = wck[(t + 1) * wtap];        // scheduler would sink the loads to their first use)
+        n1 = wck[(t + 1) * wtap + wr8];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][0].x, b0.x, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][0].y, b0.y, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][0].z, b0.z, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][0].w, b0.w, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][1].x, b1.x, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][1].y, b1.y, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][1].z, b1.z, acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][1].w, b1.w, acc[cls], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      b0 = n0, b1 = n1;
+    }
+  }
+
+  __syncthreads();
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+  const int n = grp * 32 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias != nullptr) bv = ld4g(bias + n);
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    acc_to_stage(stage, acc[cls], i, h);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = r8 + 8 * j;
+      const int q = wave * 32 + m;
+      const int cz = q >> (g.lTX + g.lTY);
+      const int jz = z0 + cz, jy = y0 + ((q >> g.lTX) & (g.TY - 1)), jx = x0 + (q & (g.TX - 1));
+      float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+      if (cz >= g.eTZ || jz >= g.Zt || jy >= g.Yt || jx >= g.Xt) continue;
+      const int64_t off =
+          ((((int64_t)b * g.Zo + 2 * jz + pz) * g.Yo + 2 * jy + py) * g.Xo + 2 * jx + px) * c_out + n;
+      v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+      if (addend != nullptr) {
+        const float4 a = ld4g(addend + off);
+        v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+      }
+      *reinterpret_cast<float4*>(Y + off) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][c][t] = sum over iteration cells q of G[cellG(q, t)][n] * X[cellX(q, t)][c]
+//   conv k3 s1 p1:        G = dy at q,            X = input at q + t - 1
+//   transposed k3 s2 p1:  G = dy at 2q + (t != 1), X = input at q + (t == 0)       (per axis)
+// MFMA: M = n (32 output channels of G), N = c (32 input channels of X), K = cells, two per
+// instruction (lanes h = 0 / 1 take consecutive cells).  A workgroup (8 waves) owns one (n block,
+// c block) pair and a strided list of tiles; every wave walks all cells of a tile for its own 2 - 4
+// taps (one accumulator each).  Both operands come from LDS with plain ds_read_b32: a lane group reads 32
+// consecutive floats of one row.  The boxes of the NEXT tile are fetched into registers while the
+// MFMAs of the current one run (XI / GI: float4 per thread of the X / G box).  The result leaves as
+// partial slabs part[wg][28][32][32].
+// ---------------------------------------------------------------------------------------------
+struct WGeom {
+  int B, Zx, Yx, Xx;  // X grid
+  int Zg, Yg, Xg;     // G grid
+  int Zt, Yt, Xt;     // iteration grid
+  int TZ, TY, TX, eTZ, lTX, lTY, nTZ, nTY, nTX;
+  int HZ, HY, HX;     // staged X box; origin = tile origin * x_mul + x_off
+  int x_mul, x_off;
+  int GZ, GY, GX;     // staged G box; origin = tile origin * g_mul; LDS row of cell = cell * g_mul
+  int g_mul;
+  int transposed;     // which of the two tap -> row-delta rules applies (no tables in here: a
+};                    // dynamically indexed array would move the whole argument to scratch memory)
+
+constexpr int kWgThreads = 512;
+
+// SHARED_A: every tap reads the same G row (conv k3 s1 p1: dG == 0) - one A fragment per cell pair.
+template <int XI, int GI, bool SHARED_A>
+__global__ __launch_bounds__(kWgThreads) void dconv_wgrad_kernel(
+    const float* __restrict__ X, int c_x, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ G, int c_g,
+    const float* __restrict__ mask_src, WGeom geom, int n_tiles, int n_nblk, int n_cblk,
+    float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // (the lambdas below are always_inline: a closure that is CALLED keeps what it captured by
+  // reference in scratch memory, and every use becomes a scratch load inside the MFMA loop)
+  const int Zx = geom.Zx, Yx = geom.Yx, Xx = geom.Xx, Zg = geom.Zg, Yg = geom.Yg, Xg = geom.Xg;
+  const int TXm = geom.TX - 1, TYm = geom.TY - 1, lTX = geom.lTX, lTXY = geom.lTX + geom.lTY;
+  const int TYs = geom.TY, TXs = geom.TX, eTZ = geom.eTZ;
+  const int nTX = geom.nTX, nTY = geom.nTY, nTZ = geom.nTZ;
+  const int HY = geom.HY, HX = geom.HX, GY = geom.GY, GX = geom.GX;
+  const int x_mul = geom.x_mul, x_off = geom.x_off, g_mul = geom.g_mul;
+  const int xrows = geom.HZ * HY * HX, grows = geom.GZ * GY * GX;
+  const int ncell = geom.TZ * geom.TY * geom.TX;
+  const bool transposed = geom.transposed != 0;
+  float* sXw = smem;               // [xrows][32]
+  float* sG = smem + xrows * 32;   // [grows][32]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  // taps of this wave: waves 0-3 take four each (taps 0..15), waves 4-7 three, three, three, two
+  // (16..26) - waves w and w + 4 share a SIMD, whose matrix pipe then serves 7, 7, 7, 6 taps
+  const int t0 = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 * wave : 16 + 3 * (wave - 4));
+  const int cnt = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 : (wave < 7 ? 3 : 2));
+  const int per_slot = n_nblk * n_cblk;
+  const int slot = blockIdx.x / per_slot, sub = blockIdx.x % per_slot;
+  const int n_slots = gridDim.x / per_slot;
+  const int nblk = sub / n_cblk, cblk = sub % n_cblk;
+  const int n0 = nblk * 32, c0 = cblk * 32;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+  int dXu[4], dGu[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {   // LDS row deltas of this wave's taps (tap 27 = padding, unused)
+    const int t = t0 + u < 27 ? t0 + u : 26;
+    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+    if (transposed) {
+      dXu[u] = (((kz == 0) * HY + (ky == 0)) * HX + (kx == 0)) * 32;
+      dGu[u] = (((kz != 1) * GY + (ky != 1)) * GX + (kx != 1)) * 32;
+    } else {
+      dXu[u] = ((kz * HY + ky) * HX + kx) * 32;
+      dGu[u] = 0;
+    }
+  }
+
+  const int oct = tid & 7;  // float4 column of a 32-channel row
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in_scale != nullptr) {
+    sc = ld4g(in_scale + c0 + oct * 4);
+    sh = ld4g(in_shift + c0 + oct * 4);
+  }
+
+  float4 px[XI], pg[GI], pm[GI];
+  // global -> registers: the boxes of `tile` (zeros outside the grids; the X box with the preceding
+  // BatchNorm's affine map, the G box with the ReLU mask applied when they are stored)
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int tt = tile;
+    const int tx = tt % nTX;
+    tt /= nTX;
+    const int ty = tt % nTY;
+    tt /= nTY;
+    const int tz = tt % nTZ;
+    const int b = tt / nTZ;
+    const int z0 = tz * eTZ, y0 = ty * TYs, x0 = tx * TXs;
+    const int hz0 = z0 * x_mul + x_off, hy0 = y0 * x_mul + x_off, hx0 = x0 * x_mul + x_off;
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      const int row = idx >> 3;
+      const int hx = row % HX;
+      const int t2 = row / HX;
+      const int hy = t2 % HY, hz = t2 / HY;
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < xrows && iz >= 0 && iz < Zx && iy >= 0 && iy < Yx && ix >= 0 && ix < Xx) {
+        v = ld4g(X + ((((int64_t)b * Zx + iz) * Yx + iy) * Xx + ix) * c_x + c0 + oct * 4);
+        if (in_scale != nullptr) affine4(v, sc, sh);
+      }
+      px[u] = v;
+    }
+    const int gz0 = z0 * g_mul, gy0 = y0 * g_mul, gx0 = x0 * g_mul;
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      const int row = idx >> 3;
+      const int hx = row % GX;
+      const int t2 = row / GX;
+      const int hy = t2 % GY, hz = t2 / GY;
+      const int iz = gz0 + hz, iy = gy0 + hy, ix = gx0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (row < grows && iz < Zg && iy < Yg && ix < Xg) {
+        const int64_t off = ((((int64_t)b * Zg + iz) * Yg + iy) * Xg + ix) * c_g + n0 + oct * 4;
+        v = ld4g(G + off);
+        if (mask_src != nullptr) m = ld4g(mask_src + off);
+      }
+      pg[u] = v;
+      pm[u] = m;
+    }
+  };
+  auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      if ((idx >> 3) < xrows) *reinterpret_cast<float4*>(&sXw[idx * 4]) = px[u];
+    }
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      if ((idx >> 3) < grows) {
+        float4 v = pg[u];
+        keep_positive(v, pm[u]);
+        *reinterpret_cast<float4*>(&sG[idx * 4]) = v;
+      }
+    }
+  };
+
+  // The loop over this workgroup's tiles, compiled once per tap count (2, 3 or 4: a wave-uniform
+  // choice made outside the loops, so the MFMA stream has no branches in it).
+  auto run = [&](auto cnt_tag) __attribute__((always_inline)) {
+    constexpr int CNT = decltype(cnt_tag)::value;
+    if (slot < n_tiles) fetch(slot);
+    const int npair = ncell >> 1;
+    for (int tile = slot; tile < n_tiles; tile += n_slots) {
+      __syncthreads();  // the previous tile's reads are done
+      deposit();
+      __syncthreads();
+      if (tile + n_slots < n_tiles) fetch(tile + n_slots);  // in flight during the MFMAs below
+      __builtin_amdgcn_sched_barrier(0);                    // (not to be sunk to the deposit)
+      // operands of cell pair jj + 1 are read from LDS while the MFMAs of pair jj run
+      float a_c[CNT], b_c[CNT], a_n[CNT], b_n[CNT];
+      // the pair's first cell is wave-uniform (scalar unit); lanes add their own h / channel part
+      const int lane_x = h * 32 + i, lane_g = h * g_mul * 32 + i;
+      auto read_pair = [&](int jj, float (&a)[CNT], float (&bb)[CNT]) __attribute__((always_inline)) {
+        const int q0 = 2 * jj;
+        const int cx = q0 & TXm, cy = (q0 >> lTX) & TYm, cz = q0 >> lTXY;
+        const bool real = cz < eTZ;  // (tiles of grids smaller than a full tile)
+        const int rx = (real ? ((cz * HY + cy) * HX + cx) * 32 : 0) + lane_x;
+        const int rg = (real ? (((cz * g_mul) * GY + cy * g_mul) * GX + cx * g_mul) * 32 : 0) + lane_g;
+        if (SHARED_A) a[0] = sG[rg];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+          if (!SHARED_A) a[u] = sG[rg + dGu[u]];
+          bb[u] = sXw[rx + dXu[u]];
+        }
+        if (!real) {  // wave-uniform
+#pragma unroll
+          for (int u = 0; u < CNT; ++u) a[u] = 0.f;
+        }
+      };
+      auto mfmas = [&](const float (&a)[CNT], const float (&bb)[CNT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < CNT; ++u)
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(SHARED_A ? a[0] : a[u], bb[u], acc[u], 0, 0, 0);
+      };
+      // two pairs per iteration, ping-pong operand sets (no register copies); npair is even
+      read_pair(0, a_c, b_c);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only (see dconv_kernel): the tile prefetch stays in flight
+#pragma unroll 1
+      for (int jj = 0; jj < npair; jj += 2) {
+        read_pair(jj + 1, a_n, b_n);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a_c, b_c);
+        __builtin_amdgcn_sched_barrier(0);
+        read_pair(jj + 2 < npair ? jj + 2 : 0, a_c, b_c);   // (the last one is read and not used)
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a_n, b_n);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // part[wg][t][n_local][c_local]; D[m][j]: j = lane & 31 (c), m -> n
+    float* dst = part + ((int64_t)blockIdx.x * 28 + t0) * 1024;
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dst[u * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[u][r];
+  };
+  if (cnt == 4) run(std::integral_constant<int, 4>());
+  else if (cnt == 3) run(std::integral_constant<int, 3>());
+  else run(std::integral_constant<int, 2>());
+}
+
+// dW[n, c, t] = sum over the slots' partial slabs, in ascending order; written with the
+// strides of the caller's weight tensor (Conv3d [n, c, kz, ky, kx] or ConvTranspose3d [c, n, ...],
+// either memory format).
+__global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(
+    const float* __restrict__ part, int n_slots, int n_nblk, int n_cblk, int c_g, int c_x,
+    int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y, int64_t s_x, float* __restrict__ dW) {
+  const int64_t total = (int64_t)27 * c_g * c_x;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % c_x);
+  const int n = (int)((e / c_x) % c_g);
+  const int t = (int)(e / ((int64_t)c_x * c_g));
+  const int per_slot = n_nblk * n_cblk;
+  const int sub = (n >> 5) * n_cblk + (c >> 5);
+  const int local = (n & 31) * 32 + (c & 31);
+  float s = 0.f;
+  for (int slot = 0; slot < n_slots; ++slot) {
+    const int64_t wg = (int64_t)slot * per_slot + sub;
+    s += part[(wg * 28 + t) * 1024 + local];
+  }
+  dW[n * s_n + c * s_c + (t / 9) * s_z + ((t / 3) % 3) * s_y + (t % 3) * s_x] = s;
+}
+
+// packed[t][r8][nb][lane][q] = W[out = nb*32 + (lane & 31)][red = r8*8 + 4(lane >> 5) + q][tap]
+// with tap = flip ? 26 - t : t.
+__global__ __launch_bounds__(256) void dconv_pack_kernel(
+    const float* __restrict__ W, int n_out, int n_red, int64_t s_out, int64_t s_red, int64_t s_z,
+    int64_t s_y, int64_t s_x, int flip, float* __restrict__ packed) {
+  const int64_t total = (int64_t)27 * n_out * n_red;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int q = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  int64_t rest = e >> 8;
+  const int nbtot = n_out >> 5, nred8 = n_red >> 3;
+  const int nb = (int)(rest % nbtot);
+  rest /= nbtot;
+  const int r8 = (int)(rest % nred8);
+  const int t = (int)(rest / nred8);
+  const int tap = flip ? 26 - t : t;
+  const int out = nb * 32 + (lane & 31);
+  const int red = r8 * 8 + 4 * (lane >> 5) + q;
+  packed[e] = W[out * s_out + red * s_red + (tap / 9) * s_z + ((tap / 3) % 3) * s_y + (tap % 3) * s_x];
+}
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+int pow2ceil(int v) { return 1 << ilog2(v); }
+
+// Tile of `cells` iteration cells: x first (up to 32), then y and z alternately, none beyond the
+// (power-of-two cover of the) grid; what is left over becomes cells that do not exist (*TZ > *eTZ).
+void pick_tile(int cells, int Zt, int Yt, int Xt, int* TZ, int* eTZ, int* TY, int* TX) {
+  const int cz = pow2ceil(Zt), cy = pow2ceil(Yt), cx = pow2ceil(Xt);
+  int tx = cx < 32 ? cx : 32;
+  int rest = cells / tx, ty = 1, tz = 1;
+  while (rest > 1) {
+    if (ty <= tz && ty < cy) ty <<= 1;
+    else if (tz < cz) tz <<= 1;
+    else if (ty < cy) ty <<= 1;
+    else break;
+    rest >>= 1;
+  }
+  *eTZ = tz;
+  *TZ = tz * rest;
+  *TY = ty;
+  *TX = tx;
+}
+
+// dynamic LDS above 64 KB has to be allowed per kernel; once per kernel and size is enough
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes <= 65536) return PV2_OK;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> allowed;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = allowed.find(key);
+  if (it != allowed.end() && it->second >= bytes) return PV2_OK;
+  if (int e = pv2::hip_status(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)bytes)))
+    return e;
+  allowed[key] = bytes;
+  return PV2_OK;
+}
+
+int env_int(const char* name, int fallback) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : fallback;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pv2_dconv3_packed_floats(int c_out, int c_in) { return (int64_t)27 * c_out * c_in; }
+
+int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
+                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, float* packed,
+                            pv2_stream_t stream) {
+  PV2_REQUIRE(w != nullptr && packed != nullptr, "dconv3_pack_weights: null pointer");
+  PV2_REQUIRE(n_out > 0 && n_out % 32 == 0 && n_red > 0 && n_red % 16 == 0,
+              "dconv3_pack_weights: output channels must be a multiple of 32, reduction channels of 16");
+  const int64_t total = (int64_t)27 * n_out * n_red;
+  hipLaunchKernelGGL(dconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, n_out, n_red, s_out, s_red, s_z, s_y, s_x, flip, packed);
+  return pv2::check_launch("dconv3_pack_weights");
+}
+
+// mode 0: conv k3 s1 p1 (out grid = in grid); mode 1: transposed conv k3 s2 p1 (out = 2 x in);
+// mode 2: strided conv k3 s2 p1 (out = in / 2, in even): the grad-input of mode 1.
+int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
+                       int c_out, int mode, const float* in_scale, const float* in_shift,
+                       const float* in_mask_src, const float* bias, const float* addend, int relu,
+                       float* out, pv2_stream_t stream) {
+  PV2_REQUIRE(x != nullptr && packed_w != nullptr && out != nullptr, "dconv3_forward: null pointer");
+  PV2_REQUIRE(mode >= 0 && mode <= 2, "dconv3_forward: mode must be 0, 1 or 2");
+  PV2_REQUIRE(c_in % 16 == 0 && c_out % 32 == 0 && c_in > 0 && c_out > 0,
+              "dconv3_forward: c_in must be a multiple of 16, c_out of 32");
+  PV2_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dconv3_forward: scale and shift come together");
+  PV2_REQUIRE(b > 0 && z > 0 && y > 0 && xx > 0, "dconv3_forward: empty grid");
+  if (mode == 2) PV2_REQUIRE(z % 2 == 0 && y % 2 == 0 && xx % 2 == 0, "dconv3_forward: mode 2 needs even input sizes");
+  if (mode == 1)
+    PV2_REQUIRE(in_scale == nullptr && in_mask_src == nullptr && relu == 0,
+                "dconv3_forward: mode 1 takes bias / addend only");
+  hipStream_t s = (hipStream_t)stream;
+  DGeom g;
+  g.B = b;
+  g.Zi = z, g.Yi = y, g.Xi = xx;
+  const int64_t cells_t = (int64_t)b * z * y * xx / (mode == 2 ? 8 : 1);
+  if (mode == 0) {
+    g.Zo = z, g.Yo = y, g.Xo = xx;
+    g.Zt = z, g.Yt = y, g.Xt = xx;
+  } else if (mode == 1) {
+    g.Zo = 2 * z, g.Yo = 2 * y, g.Xo = 2 * xx;
+    g.Zt = z, g.Yt = y, g.Xt = xx;
+  } else {
+    g.Zo = z / 2, g.Yo = y / 2, g.Xo = xx / 2;
+    g.Zt = g.Zo, g.Yt = g.Yo, g.Xt = g.Xo;
+  }
+  const int nbtot = c_out / 32;
+  int mt = 1, nb = 1;
+  if (mode == 0 && cells_t >= 262144) mt = 2;
+  static const int force_mt = env_int("PV2_DCONV_MT", 0), force_nb = env_int("PV2_DCONV_NB", 0);
+  if (mode == 0 && force_mt) mt = force_mt;
+  pick_tile(128 * mt, g.Zt, g.Yt, g.Xt, &g.TZ, &g.eTZ, &g.TY, &g.TX);
+  g.lTX = ilog2(g.TX), g.lTY = ilog2(g.TY);
+  g.nTZ = (g.Zt + g.eTZ - 1) / g.eTZ, g.nTY = (g.Yt + g.TY - 1) / g.TY, g.nTX = (g.Xt + g.TX - 1) / g.TX;
+  const int64_t n_tiles = (int64_t)b * g.nTZ * g.nTY * g.nTX;
+  if (mode != 1 && nbtot % 2 == 0 && n_tiles * (nbtot / 2) >= 512) nb = 2;
+  if (mode != 1 && force_nb && nbtot % force_nb == 0) nb = force_nb;
+  g.xsplit = 0, g.HXh = 0;
+  int ck = 16;
+  if (mode == 0) {
+    g.HZ = g.eTZ + 2, g.HY = g.TY + 2, g.HX = g.TX + 2;
+    g.in_mul = 1, g.in_off = -1, g.cell_mul = 1;
+  } else if (mode == 1) {
+    g.HZ = g.eTZ + 1, g.HY = g.TY + 1, g.HX = g.TX + 1;
+    g.in_mul = 1, g.in_off = 0, g.cell_mul = 1;
+  } else {
+    g.HZ = 2 * g.eTZ + 1, g.HY = 2 * g.TY + 1, g.HX = 2 * g.TX + 1;
+    g.in_mul = 2, g.in_off = -1, g.cell_mul = 2;
+    g.xsplit = 1, g.HXh = g.TX + 1;  // box column hx -> row (hx & 1) * HXh + (hx >> 1): the 32 cells of
+    ck = 8;                          // an M-tile read CONSECUTIVE rows (stride-2 rows conflict 2-way)
+  }
+  g.HXr = g.xsplit ? 2 * g.HXh : g.HX;
+  size_t lds = (size_t)g.HZ * g.HY * g.HXr * (ck + 4) * sizeof(float);
+  const size_t epilogue = (size_t)4 * 32 * kStagePad * sizeof(float);
+  if (lds < epilogue) lds = epilogue;
+  PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
+  const int n_groups = nbtot / nb;
+  const dim3 grid((unsigned)(n_tiles * n_groups));
+  if (mode == 1) {
+    if (int e = set_lds(dconvT_kernel, lds)) return e;
+    hipLaunchKernelGGL(dconvT_kernel, grid, dim3(256), lds, s, x, g, c_in, packed_w, c_out, n_groups,
+                       bias, addend, out);
+    return pv2::check_launch("dconv3_forward(transposed)");
+  }
+#define PV2_DCONV_LAUNCH(NB_, MT_, CK_)                                                                 \
+  do {                                                                                                  \
+    if (int e = set_lds(dconv_kernel<NB_, MT_, CK_>, lds)) return e;                                    \
+    hipLaunchKernelGGL((dconv_kernel<NB_, MT_, CK_>), grid, dim3(256), lds, s, x, g, c_in, packed_w,    \
+                       c_out, n_groups, in_scale, in_shift, in_mask_src, bias, addend, relu, out);      \
+  } while (0)
+  if (mode == 2) {
+    if (nb == 2) PV2_DCONV_LAUNCH(2, 1, 8);
+    else PV2_DCONV_LAUNCH(1, 1, 8);
+  } else if (nb == 2 && mt == 2) PV2_DCONV_LAUNCH(2, 2, 16);
+  else if (nb == 2) PV2_DCONV_LAUNCH(2, 1, 16);
+  else if (mt == 2) PV2_DCONV_LAUNCH(1, 2, 16);
+  else PV2_DCONV_LAUNCH(1, 1, 16);
+#undef PV2_DCONV_LAUNCH
+  return pv2::check_launch("dconv3_forward");
+}
+
+// Geometry shared by the partial-size query and the launch.
+static int wgrad_geometry(int b, int z, int y, int xx, int c_x, int c_g, int mode, WGeom* g,
+                          int* n_tiles, int* n_slots) {
+  g->B = b;
+  g->Zx = z, g->Yx = y, g->Xx = xx;
+  g->Zt = z, g->Yt = y, g->Xt = xx;
+  if (mode == 0) {
+    g->Zg = z, g->Yg = y, g->Xg = xx;
+    pick_tile(256, z, y, xx, &g->TZ, &g->eTZ, &g->TY, &g->TX);
+    g->HZ = g->eTZ + 2, g->HY = g->TY + 2, g->HX = g->TX + 2;
+    g->x_mul = 1, g->x_off = -1;
+    g->GZ = g->eTZ, g->GY = g->TY, g->GX = g->TX;
+    g->g_mul = 1;
+  } else {
+    g->Zg = 2 * z, g->Yg = 2 * y, g->Xg = 2 * xx;
+    pick_tile(64, z, y, xx, &g->TZ, &g->eTZ, &g->TY, &g->TX);
+    g->HZ = g->eTZ + 1, g->HY = g->TY + 1, g->HX = g->TX + 1;
+    g->x_mul = 1, g->x_off = 0;
+    g->GZ = 2 * g->eTZ, g->GY = 2 * g->TY, g->GX = 2 * g->TX;
+    g->g_mul = 2;
+  }
+  g->lTX = ilog2(g->TX), g->lTY = ilog2(g->TY);
+  g->nTZ = (z + g->eTZ - 1) / g->eTZ, g->nTY = (y + g->TY - 1) / g->TY, g->nTX = (xx + g->TX - 1) / g->TX;
+  g->transposed = mode == 1;
+  *n_tiles = b * g->nTZ * g->nTY * g->nTX;
+  const int blocks = (c_g / 32) * (c_x / 32);
+  int slots = 256 / blocks;   // one workgroup per CU (the LDS tile is > 80 KB)
+  if (slots < 1) slots = 1;
+  if (slots > *n_tiles) slots = *n_tiles;
+  *n_slots = slots;
+  return PV2_OK;
+}
+
+int64_t pv2_dconv3_wgrad_partial_floats(int b, int z, int y, int xx, int c_x, int c_g, int mode) {
+  WGeom g;
+  int n_tiles, n_slots;
+  wgrad_geometry(b, z, y, xx, c_x, c_g, mode, &g, &n_tiles, &n_slots);
+  return (int64_t)n_slots * (c_g / 32) * (c_x / 32) * 28 * 1024;
+}
+
+// mode 0: conv k3 s1 p1 - x [b,z,y,xx,c_x] the conv input (in_scale / in_shift: the BatchNorm in
+//         front of it), gy [b,z,y,xx,c_g] the output gradient (gy_mask_src: the output, for the ReLU mask);
+// mode 1: transposed conv k3 s2 p1 - x the coarse input, gy [b,2z,2y,2xx,c_g].
+// dw[n*s_n + c*s_c + kz*s_z + ky*s_y + kx*s_x], n over c_g, c over c_x.
+int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int c_x,
+                               const float* in_scale, const float* in_shift, const float* gy,
+                               int c_g, const float* gy_mask_src, int mode, float* partial_ws,
+                               float* dw, int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y,
+                               int64_t s_x, pv2_stream_t stream) {
+  PV2_REQUIRE(x != nullptr && gy != nullptr && partial_ws != nullptr && dw != nullptr,
+              "dconv3_backward_weight: null pointer");
+  PV2_REQUIRE(mode == 0 || mode == 1, "dconv3_backward_weight: mode must be 0 or 1");
+  PV2_REQUIRE(c_x % 32 == 0 && c_g % 32 == 0 && c_x > 0 && c_g > 0,
+              "dconv3_backward_weight: channel counts must be multiples of 32");
+  PV2_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dconv3_backward_weight: scale and shift come together");
+  hipStream_t s = (hipStream_t)stream;
+  WGeom g;
+  int n_tiles, n_slots;
+  wgrad_geometry(b, z, y, xx, c_x, c_g, mode, &g, &n_tiles, &n_slots);
+  const int n_nblk = c_g / 32, n_cblk = c_x / 32;
+  const int xrows = g.HZ * g.HY * g.HX, grows = g.GZ * g.GY * g.GX;
+  const size_t lds = ((size_t)xrows + grows) * 32 * sizeof(float);
+  PV2_REQUIRE(lds <= 160 * 1024, "dconv3_backward_weight: tiles do not fit the LDS");
+  const int xi = (xrows * 8 + kWgThreads - 1) / kWgThreads, gi = (grows * 8 + kWgThreads - 1) / kWgThreads;
+  const dim3 grid((unsigned)(n_slots * n_nblk * n_cblk));
+#define PV2_WGRAD_LAUNCH(XI_, GI_, SA_)                                                              \
+  do {                                                                                               \
+    if (int e = set_lds(dconv_wgrad_kernel<XI_, GI_, SA_>, lds)) return e;                           \
+    hipLaunchKernelGGL((dconv_wgrad_kernel<XI_, GI_, SA_>), grid, dim3(kWgThreads), lds, s, x, c_x,  \
+                       in_scale, in_shift, gy, c_g, gy_mask_src, g, n_tiles, n_nblk, n_cblk,         \
+                       partial_ws);                                                                  \
+  } while (0)
+  if (mode == 1 && xi <= 4 && gi <= 8) PV2_WGRAD_LAUNCH(4, 8, false);       // the transposed conv's boxes
+  else if (mode == 0 && xi <= 13 && gi <= 4) PV2_WGRAD_LAUNCH(13, 4, true); // (2, 4, 32)-cell tiles + halo
+  else if (xi <= 13 && gi <= 8) PV2_WGRAD_LAUNCH(13, 8, false);             // anything else that fits
+  else {
+    pv2::set_error("dconv3_backward_weight: no kernel variant for this tile geometry");
+    return PV2_E_UNSUPPORTED;
+  }
+#undef PV2_WGRAD_LAUNCH
+  const int64_t total = (int64_t)27 * c_g * c_x;
+  hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     partial_ws, n_slots, n_nblk, n_cblk, c_g, c_x, s_n, s_c, s_z, s_y, s_x, dw);
+  return pv2::check_launch("dconv3_backward_weight");
+}
+
+}  // extern "C"

@@ -245,7 +245,8 @@ template <int MODE, typename EX>
 __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0, int64_t n,
     float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-    float* __restrict__ out) {
+    float* __restrict__ out, const float* __restrict__ aff_w = nullptr,
+    const float* __restrict__ aff_b = nullptr, float* __restrict__ affine = nullptr) {
   __shared__ double r0[kCombineThreads];
   __shared__ double r1[kCombineThreads];
   const int tid = threadIdx.x, q = tid >> 5, cc = tid & 31;
@@ -274,7 +275,13 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     double var = t1 * inv_n - d * d;
     if (var < 0.0) var = 0.0;
     out[ch] = (float)mean;
-    out[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    out[c + ch] = invstd;
+    if (affine != nullptr) {  // the normalisation as one multiply-add per element: x * scale + shift
+      const float scale = (aff_w ? aff_w[ch] : 1.f) * invstd;
+      affine[ch] = scale;
+      affine[c + ch] = (aff_b ? aff_b[ch] : 0.f) - (float)mean * scale;
+    }
     if (running_mean != nullptr) {
       const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
       running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
@@ -597,6 +604,31 @@ int pv2_bn_backward(const float* dy, const float* x, const float* y_or_null,
                     pv2_stream_t stream) {
   return pv2_bn_backward_mixed(dy, x, PV2_F32, y_or_null, PV2_F32, mean_invstd, weight, n, c,
                                workspace, gsum, dx, dresidual_or_null, stream);
+}
+
+// Training-mode BatchNorm statistics of the rows of x WITHOUT applying them: mean / invstd, the
+// running statistics, and the affine pair (scale = weight * invstd, shift = bias - mean * scale) a
+// consumer folds into its own load path (the dense convolutions of csrc/dense_conv.hip).
+int pv2_bn_statistics(const float* x, int64_t n, int c, const float* weight, const float* bias,
+                      float eps, float momentum, float* running_mean, float* running_var,
+                      float* workspace, float* mean_invstd, float* affine, pv2_stream_t stream) {
+  PV2_REQUIRE(x != nullptr && workspace != nullptr && mean_invstd != nullptr && affine != nullptr,
+              "bn_statistics: null pointer");
+  PV2_REQUIRE(n > 0 && c > 0 && c <= kMaxChannels, "bn_statistics: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks;
+  int64_t rpb;
+  partial_geometry(n, c, &blocks, &rpb);
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((col_partials_vec_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       x, (const float*)nullptr, (const float*)nullptr, nullptr, n, c, rpb, workspace);
+  else
+    hipLaunchKernelGGL((col_partials_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       x, (const float*)nullptr, (const float*)nullptr, nullptr, n, c, rpb, workspace);
+  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
+                     workspace, blocks, c, x, n, eps, momentum, running_mean, running_var, mean_invstd,
+                     weight, bias, affine);
+  return pv2::check_launch("bn_statistics");
 }
 
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream) {

@@ -6,15 +6,18 @@ Mirror of ponder/models/ponder/unet3d.py (SimpleConv3D :16-34, create_conv :45-1
 UNet3Dv1m2 :710-743) restricted to what the v1m2 variant instantiates: SingleConv levels in
 "bcr" order (BatchNorm3d -> Conv3d(no bias) -> ReLU), MaxPool3d(2) between encoder levels,
 ConvTranspose3d(k3, s2, p1, output_size=skip size) + summation joining in the decoder, and a
-final 1x1 conv.  These are stock dense convolutions: they go to MIOpen through PyTorch-ROCm
-(north_star names no custom kernel for them); parameter names match the reference.
+final 1x1 conv.  On the device in fp32 the 3x3x3 levels and the transposed convolutions run on the
+hand-written MFMA kernels of csrc/dense_conv.hip (ponderv2_amd/dense_conv.py: BatchNorm affine, ReLU,
+ReLU mask, bias and the skip sum fused into them); anything else (autocast, eval mode, other orders,
+host tensors) goes to the convolution library through PyTorch-ROCm; parameter names match the
+reference.
 """
 import os
 
 import torch
 import torch.nn as nn
 
-from ponderv2_amd import sidestream
+from ponderv2_amd import dense_conv, sidestream
 from ..builder import MODELS
 
 
@@ -201,6 +204,7 @@ class SingleConv(nn.Sequential):
                  padding=1):
         super().__init__()
         assert "c" in order and order[0] not in "rle"
+        self._order = order
         has_norm = "b" in order or "g" in order
         for pos, op in enumerate(order):
             before_conv = pos < order.index("c")
@@ -224,6 +228,11 @@ class SingleConv(nn.Sequential):
                 raise ValueError(f"unsupported layer type {op!r} in order {order!r}")
 
     def forward(self, x):
+        # "bcr" on a device volume: BatchNorm statistics on the row kernels, the affine map, the ReLU
+        # and (backward) the ReLU mask inside the hand-written 3x3x3 convolution (dense_conv.py)
+        if (self._order == "bcr" and dense_conv.bn_conv_supported(self.batchnorm, self.conv, x)
+                and torch.is_grad_enabled()):
+            return dense_conv.bn_conv_relu(self.batchnorm, self.conv, x)
         for module in self:
             x = library_conv(module, x) if isinstance(module, nn.Conv3d) else module(x)
         return x
@@ -325,6 +334,11 @@ class Decoder(nn.Module):
                                        num_groups=num_groups)
 
     def forward(self, encoder_features, x):
+        up = self.upsampling.upsample
+        if (dense_conv.upsample_supported(up, x, encoder_features.shape[2:])
+                and encoder_features.dtype == torch.float32 and torch.is_grad_enabled()):
+            # skip + ConvTranspose3d(x) (+ bias) in one launch: the sum is the conv's epilogue
+            return self.basic_module(dense_conv.upsample_add(up, encoder_features, x))
         return self.basic_module(encoder_features + self.upsampling(encoder_features, x))
 
 
