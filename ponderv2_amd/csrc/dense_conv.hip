@@ -50,6 +50,7 @@ struct DGeom {
   int cell_mul;       // LDS row of iteration cell (z, y, x) = ((z*cm)*HY + y*cm)*HXr + xrow(x*cm)
   int xsplit, HXh;    // strided conv: the box's x axis is stored odd / even de-interleaved (HXh each)
   int HXr;            // row count of the x axis in LDS (HX, or 2*HXh)
+  float rHX, rHY;     // 1 / HX, 1 / HY: box row -> (hz, hy, hx) without integer division
 };
 
 __device__ __forceinline__ float4 ld4g(const float* __restrict__ p) {
@@ -68,6 +69,18 @@ __device__ __forceinline__ void affine4(float4& v, const float4& sc, const float
   v.y = v.y * sc.y + sh.y;
   v.z = v.z * sc.z + sh.z;
   v.w = v.w * sc.w + sh.w;
+}
+
+// row -> (hz, hy, hx) of a box of HY x HX rows per z-slice.  floor((row + 0.5) * (1 / HX)) == row / HX
+// for the few thousand rows of a box: the product is off by < 3e-4, (row + 0.5) / HX is >= 0.5 / HX
+// away from an integer.  (Runtime divisors: an integer division is ~40 VALU instructions, and the
+// staging loops did three per float4.)
+__device__ __forceinline__ void decode_row(int row, int HX, int HY, float rHX, float rHY, int& hz,
+                                           int& hy, int& hx) {
+  const int t2 = (int)(((float)row + 0.5f) * rHX);
+  hx = row - t2 * HX;
+  hz = (int)(((float)t2 + 0.5f) * rHY);
+  hy = t2 - hz * HY;
 }
 
 // Stage the CK-channel chunk `ck` of the halo box into LDS: row = halo cell, CK/4 float4 per row,
@@ -99,9 +112,8 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ sX, const float*
     for (int u = 0; u < U; ++u) {
       const int idx = base + u * nthreads;
       const int row = idx / QPR;
-      const int hx = row % g.HX;
-      const int t2 = row / g.HX;
-      const int hy = t2 % g.HY, hz = t2 / g.HY;
+      int hx, hy, hz;
+      decode_row(row, g.HX, g.HY, g.rHX, g.rHY, hz, hy, hx);
       const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
       const int xr = g.xsplit ? (hx & 1) * g.HXh + (hx >> 1) : hx;
       dst[u] = idx < total ? ((hz * g.HY + hy) * g.HXr + xr) * LDR + quad * 4 : -1;
@@ -142,36 +154,46 @@ __device__ __forceinline__ void acc_to_stage(float* __restrict__ stage, const f3
 //   Wp[t][r8][nb][lane][4]: lane (i, h) holds W[out = nb*32 + i][red = r8*8 + 4h + q][tap t], q = 0..3
 //   - the B fragments of the four MFMAs of one 8-channel reduction step.
 // CK: channels staged per chunk (16; 8 for the strided conv, whose halo box is 8x the tile).
+// A workgroup walks `tiles_per_wg` consecutive tiles x c_in / CK chunks as ONE pipeline of items:
+// while the 27 taps of an item run on the matrix pipe, the next item's box is on its way from L2 /
+// HBM into registers (PFN float4 per thread, twice that with the ReLU mask); it is written to LDS
+// when the taps are done.  Without that, two co-resident workgroups that start together stay in
+// phase - both staging, then both computing - and the matrix pipe idles a third of the time
+// (profiles/r04_pmc_dense_conv_v3.txt: 61 % busy).
 // ---------------------------------------------------------------------------------------------
-template <int NB, int MT, int CK>
-__global__ __launch_bounds__(256) void dconv_kernel(
+template <int NB, int MT, int CK, int PFN, bool MASKED>
+__global__ __launch_bounds__(256, 2) void dconv_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const float* __restrict__ Wp, int c_out,
-    int n_groups, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* __restrict__ mask_src, const float* __restrict__ bias,
-    const float* __restrict__ addend, int relu, float* __restrict__ Y) {
-  constexpr int S = CK / 8, LDR = CK + 4;
+    int n_groups, int tiles_per_wg, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ mask_src,
+    const float* __restrict__ bias, const float* __restrict__ addend, int relu,
+    float* __restrict__ Y) {
+  constexpr int S = CK / 8, LDR = CK + 4, QPR = CK / 4;
   extern __shared__ __attribute__((aligned(16))) float sX[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int grp = blockIdx.x % n_groups;
-  int tile = blockIdx.x / n_groups;
-  const int tx = tile % g.nTX;
-  tile /= g.nTX;
-  const int ty = tile % g.nTY;
-  tile /= g.nTY;
-  const int tz = tile % g.nTZ;
-  const int b = tile / g.nTZ;
-  const int z0 = tz * g.eTZ, y0 = ty * g.TY, x0 = tx * g.TX;
-  const int hz0 = z0 * g.in_mul + g.in_off, hy0 = y0 * g.in_mul + g.in_off,
-            hx0 = x0 * g.in_mul + g.in_off;
+  const int n_tiles = g.B * g.nTZ * g.nTY * g.nTX;
+  const int tile_first = (blockIdx.x / n_groups) * tiles_per_wg;
+  const int tile_count = min(tiles_per_wg, n_tiles - tile_first);
+  const int nchunks = c_in / CK;
+  const int n_items = tile_count * nchunks;
+  // (plain scalars: what the always_inline lambdas below capture stays in registers)
+  const int Zi = g.Zi, Yi = g.Yi, Xi = g.Xi, HX = g.HX, HY = g.HY, HXr = g.HXr, HXh = g.HXh;
+  const int xsplit = g.xsplit, in_mul = g.in_mul, in_off = g.in_off;
+  const int nTX = g.nTX, nTY = g.nTY, nTZ = g.nTZ, eTZ = g.eTZ, TYs = g.TY, TXs = g.TX;
+  const int TXm = g.TX - 1, TYm = g.TY - 1, lTX = g.lTX, lTXY = g.lTX + g.lTY;
+  const float rHX = g.rHX, rHY = g.rHY;
+  const int total = g.HZ * HY * HX * QPR;
+  const int quad = tid & (QPR - 1);
 
   int rowbase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int q = (wave * MT + mt) * 32 + i;
-    const int cx = q & (g.TX - 1), cy = (q >> g.lTX) & (g.TY - 1), cz = q >> (g.lTX + g.lTY);
-    const int xr = cx * g.cell_mul;  // (strided conv: even box column 2 cx -> row cx of the even half)
-    rowbase[mt] = ((cz * g.cell_mul) * g.HY + cy * g.cell_mul) * g.HXr + (g.xsplit ? cx : xr);
-    if (cz >= g.eTZ) rowbase[mt] = 0;  // no such cell: any staged row, the result is dropped
+    const int cx = q & TXm, cy = (q >> lTX) & TYm, cz = q >> lTXY;
+    // (strided conv: even box column 2 cx -> row cx of the even half)
+    rowbase[mt] = ((cz * g.cell_mul) * HY + cy * g.cell_mul) * HXr + (xsplit ? cx : cx * g.cell_mul);
+    if (cz >= eTZ) rowbase[mt] = 0;  // no such cell: any staged row, the result is dropped
   }
 
   f32x16 acc[MT][NB];
@@ -182,126 +204,209 @@ __global__ __launch_bounds__(256) void dconv_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
 
-  const int nchunks = c_in / CK;
   const int nbtot = c_out >> 5;
   const float4* __restrict__ Wp4 = reinterpret_cast<const float4*>(Wp) + (grp * NB) * 64 + lane;
   const int64_t wr8 = (int64_t)nbtot * 64;             // float4 per 8-channel step
   const int64_t wtap = (int64_t)(c_in >> 3) * wr8;     // float4 per tap
 
-  for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck) __syncthreads();  // every wave is done with the previous chunk
-    stage_chunk<CK>(sX, X, g, b, hz0, hy0, hx0, c_in, ck, in_scale, in_shift, mask_src, tid, 256);
+  auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % nTX;
+    tile /= nTX;
+    const int ty = tile % nTY;
+    tile /= nTY;
+    b = tile / nTZ;
+    z0 = (tile % nTZ) * eTZ, y0 = ty * TYs, x0 = tx * TXs;
+  };
+
+  // ---- the box of the NEXT item, global -> registers
+  float4 pf[PFN], pm[MASKED ? PFN : 1], psc, psh;
+  unsigned okbits = 0;
+  auto fetch = [&](int tl, int ck) __attribute__((always_inline)) {
+    int b, z0, y0, x0;
+    tile_origin(tile_first + tl, b, z0, y0, x0);
+    const int hz0 = z0 * in_mul + in_off, hy0 = y0 * in_mul + in_off, hx0 = x0 * in_mul + in_off;
+    const int c0 = ck * CK + quad * 4;
+    if (in_scale != nullptr) {
+      psc = ld4g(in_scale + c0);
+      psh = ld4g(in_shift + c0);
+    }
+    okbits = 0;
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      int hx, hy, hz;
+      decode_row(idx / QPR, HX, HY, rHX, rHY, hz, hy, hx);
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      const bool ok = idx < total && iz >= 0 && iz < Zi && iy >= 0 && iy < Yi && ix >= 0 && ix < Xi;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MASKED) pm[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (ok) {
+        const int64_t off = ((((int64_t)b * Zi + iz) * Yi + iy) * Xi + ix) * c_in + c0;
+        pf[u] = ld4g(X + off);
+        if (MASKED) pm[u] = ld4g(mask_src + off);
+        okbits |= 1u << u;
+      }
+    }
+  };
+  // ---- registers -> LDS (affine map and ReLU mask applied here; zeros outside the grid)
+  auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      if (idx >= total) continue;
+      int hx, hy, hz;
+      decode_row(idx / QPR, HX, HY, rHX, rHY, hz, hy, hx);
+      const int xr = xsplit ? (hx & 1) * HXh + (hx >> 1) : hx;
+      float4 v = pf[u];
+      if ((okbits >> u) & 1u) {
+        if (in_scale != nullptr) affine4(v, psc, psh);
+        if (MASKED) keep_positive(v, pm[u]);
+      }
+      *reinterpret_cast<float4*>(&sX[((hz * HY + hy) * HXr + xr) * LDR + quad * 4]) = v;
+    }
+  };
+
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+
+  float4 bq[2][NB][S], aq[2][MT][S];
+  fetch(0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int s = 0; s < S; ++s) bq[0][nb][s] = Wp4[s * wr8 + nb * 64];   // item 0, tap 0
+  int tl = 0, ck = 0;  // tile (local) and chunk of the current item
+  for (int item = 0; item < n_items; ++item) {
+    __syncthreads();  // every wave is done with the previous item (taps and epilogue)
+    deposit();
     __syncthreads();
 
+    // ---- the 27 taps of this item: 13 x 2 + 1, operands ping-ponged between two register sets (no
+    // copies).  Tap t's MFMAs are interleaved ONE BY ONE with the requests for tap t + 1 (weights
+    // from L1 / L2, cells from LDS): a wave issues in order, so whatever sits in a block before or
+    // after the MFMAs is time its SIMD's matrix pipe can only fill from the partner wave - and two
+    // workgroups that started together stay in phase, both in such a block at the same time
+    // (tools/micro/mfma_peak.hip: 16 MFMAs + 4 ds_read_b128 + 2 global loads interleaved sustain
+    // 134 TFLOP/s with two waves per SIMD, 127 with a dozen register copies behind them).
     const float4* __restrict__ wck = Wp4 + (int64_t)ck * S * wr8;
-    float4 bq[NB][S], aq[MT][S];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int s = 0; s < S; ++s) bq[nb][s] = wck[s * wr8 + nb * 64];
+    const int ntl = ck + 1 < nchunks ? tl : tl + 1, nck = ck + 1 < nchunks ? ck + 1 : 0;
+    const float4* __restrict__ wnext = Wp4 + (int64_t)nck * S * wr8;   // the next item's first tap
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int s = 0; s < S; ++s)
-        aq[mt][s] = *reinterpret_cast<const float4*>(&sX[rowbase[mt] * LDR + 8 * s + 4 * h]);
+        aq[0][mt][s] = *reinterpret_cast<const float4*>(&sX[rowbase[mt] * LDR + 8 * s + 4 * h]);
+    if (item + 1 < n_items) fetch(ntl, nck);   // the next box: in flight during all 27 taps
+    __builtin_amdgcn_sched_barrier(0);
 
-    // (the first tap's operands have landed before the loop is entered: otherwise the wait-count
-    // pass, merging loop entry and back edge, waits at the first MFMA of EVERY iteration for
-    // "older" loads - which then are the prefetches just issued)
-    __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll 1
-    for (int t = 0; t < 27; ++t) {
-      float4 bn[NB][S], an[MT][S];
-      if (t + 1 < 27) {  // tap t+1: weights from L1 / L2, cells from LDS - in flight during the MFMAs
-        const int t1 = t + 1;
+    // one tap: requests for tap `t1` (or, past the last tap, the next item's first weights) into
+    // register set `nxt`, MFMAs on set `cur`
+    auto tap = [&](int t1, auto cur_tag) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+      constexpr int kOther = 0x002 | 0x004 | 0x020 | 0x100;  // VALU, SALU, VMEM read, DS read
+      if (t1 < 27) {
         const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
-        const int delta = (kz * g.HY + ky) * g.HXr + (g.xsplit ? (kx & 1) * g.HXh + (kx >> 1) : kx);
+        const int delta = (kz * HY + ky) * HXr + (xsplit ? (kx & 1) * HXh + (kx >> 1) : kx);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int s = 0; s < S; ++s) bn[nb][s] = wck[t1 * wtap + s * wr8 + nb * 64];
+          for (int s = 0; s < S; ++s) bq[nxt][nb][s] = wck[t1 * wtap + s * wr8 + nb * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int s = 0; s < S; ++s)
-            an[mt][s] = *reinterpret_cast<const float4*>(
+            aq[nxt][mt][s] = *reinterpret_cast<const float4*>(
                 &sX[(rowbase[mt] + delta) * LDR + 8 * s + 4 * h]);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int s = 0; s < S; ++s) bq[nxt][nb][s] = wnext[s * wr8 + nb * 64];
       }
-      // the scheduler would sink those loads down to their first use (the copies below become the
-      // MFMA operands of the next iteration) and expose a full L2 round trip per tap: pin them
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].x, bq[nb][s].x, acc[mt][nb], 0, 0, 0);
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][mt][s].x, bq[cur][nb][s].x, acc[mt][nb], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].y, bq[nb][s].y, acc[mt][nb], 0, 0, 0);
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][mt][s].y, bq[cur][nb][s].y, acc[mt][nb], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].z, bq[nb][s].z, acc[mt][nb], 0, 0, 0);
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][mt][s].z, bq[cur][nb][s].z, acc[mt][nb], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s].w, bq[nb][s].w, acc[mt][nb], 0, 0, 0);
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][mt][s].w, bq[cur][nb][s].w, acc[mt][nb], 0, 0, 0);
+      }
+      // issue order: one MFMA, then up to two of the other requests, 4 * S * MT * NB times
+#pragma unroll
+      for (int k = 0; k < 4 * S * MT * NB; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kOther, 2, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < 27) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int s = 0; s < S; ++s) bq[nb][s] = bn[nb][s];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int s = 0; s < S; ++s) aq[mt][s] = an[mt][s];
-      }
+    };
+#pragma unroll 1
+    for (int t = 0; t < 26; t += 2) {
+      tap(t + 1, std::integral_constant<int, 0>());
+      tap(t + 2, std::integral_constant<int, 1>());
     }
-  }
+    tap(27, std::integral_constant<int, 0>());   // tap 26: set 0; set 1 gets the next item's first weights
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int s = 0; s < S; ++s) bq[0][nb][s] = bq[1][nb][s];
 
-  // Epilogue: every 32 x 32 block goes through a wave-private LDS tile and leaves as 16-byte pieces
-  // of output rows (4 store instructions per block instead of 16; the addend arrives the same way).
-  __syncthreads();  // the halo tile is free
-  float* stage = sX + wave * (32 * kStagePad);
-  const int c4 = lane & 7, r8 = lane >> 3;
+    if (ck + 1 == nchunks) {
+      // Epilogue of this tile: every 32 x 32 block goes through a wave-private LDS tile and leaves
+      // as 16-byte pieces of output rows (4 store instructions per block instead of 16; the addend
+      // arrives the same way).  The next item's box stays in flight meanwhile.
+      __syncthreads();  // the halo tile is free
+      int b, z0, y0, x0;
+      tile_origin(tile_first + tl, b, z0, y0, x0);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      acc_to_stage(stage, acc[mt][nb], i, h);
-      __builtin_amdgcn_wave_barrier();
-      const int n = (grp * NB + nb) * 32 + 4 * c4;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias != nullptr) bv = ld4g(bias + n);
+        for (int nb = 0; nb < NB; ++nb) {
+          acc_to_stage(stage, acc[mt][nb], i, h);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = r8 + 8 * j;
-        const int q = (wave * MT + mt) * 32 + m;
-        const int cz = q >> (g.lTX + g.lTY);
-        const int oz = z0 + cz, oy = y0 + ((q >> g.lTX) & (g.TY - 1)), ox = x0 + (q & (g.TX - 1));
-        float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
-        if (cz >= g.eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
-        const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
-        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-        if (addend != nullptr) {
-          const float4 a = ld4g(addend + off);
-          v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+          for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
+          __builtin_amdgcn_wave_barrier();
+          const int n = (grp * NB + nb) * 32 + 4 * c4;
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias != nullptr) bv = ld4g(bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = r8 + 8 * j;
+            const int q = (wave * MT + mt) * 32 + m;
+            const int cz = q >> lTXY;
+            const int oz = z0 + cz, oy = y0 + ((q >> lTX) & TYm), ox = x0 + (q & TXm);
+            float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+            if (cz >= eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
+            const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+            if (addend != nullptr) {
+              const float4 a = ld4g(addend + off);
+              v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+            }
+            if (relu) {
+              v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(Y + off) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        if (relu) {
-          v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(Y + off) = v;
       }
-      __builtin_amdgcn_wave_barrier();
     }
+    tl = ntl, ck = nck;
   }
 }
 
@@ -777,15 +882,17 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   }
   const int nbtot = c_out / 32;
   int mt = 1, nb = 1;
-  if (mode == 0 && cells_t >= 262144) mt = 2;
+  // (two M-tiles per wave for the big grids; with a ReLU mask the register prefetch is twice as
+  // wide - the 256-cell tile's 13 + 13 float4 spill, the 128-cell tile's 9 + 9 fit)
+  if (mode == 0 && cells_t >= 262144 && in_mask_src == nullptr) mt = 2;
   static const int force_mt = env_int("PV2_DCONV_MT", 0), force_nb = env_int("PV2_DCONV_NB", 0);
   if (mode == 0 && force_mt) mt = force_mt;
   pick_tile(128 * mt, g.Zt, g.Yt, g.Xt, &g.TZ, &g.eTZ, &g.TY, &g.TX);
   g.lTX = ilog2(g.TX), g.lTY = ilog2(g.TY);
   g.nTZ = (g.Zt + g.eTZ - 1) / g.eTZ, g.nTY = (g.Yt + g.TY - 1) / g.TY, g.nTX = (g.Xt + g.TX - 1) / g.TX;
   const int64_t n_tiles = (int64_t)b * g.nTZ * g.nTY * g.nTX;
-  if (mode != 1 && nbtot % 2 == 0 && n_tiles * (nbtot / 2) >= 512) nb = 2;
-  if (mode != 1 && force_nb && nbtot % force_nb == 0) nb = force_nb;
+  if (mode != 1 && mt == 1 && nbtot % 2 == 0 && n_tiles * (nbtot / 2) >= 512) nb = 2;
+  if (mode != 1 && mt == 1 && (force_nb == 1 || force_nb == 2) && nbtot % force_nb == 0) nb = force_nb;
   g.xsplit = 0, g.HXh = 0;
   int ck = 16;
   if (mode == 0) {
@@ -801,31 +908,53 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     ck = 8;                          // an M-tile read CONSECUTIVE rows (stride-2 rows conflict 2-way)
   }
   g.HXr = g.xsplit ? 2 * g.HXh : g.HX;
+  g.rHX = 1.0f / (float)g.HX, g.rHY = 1.0f / (float)g.HY;
   size_t lds = (size_t)g.HZ * g.HY * g.HXr * (ck + 4) * sizeof(float);
   const size_t epilogue = (size_t)4 * 32 * kStagePad * sizeof(float);
   if (lds < epilogue) lds = epilogue;
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
   const int n_groups = nbtot / nb;
-  const dim3 grid((unsigned)(n_tiles * n_groups));
   if (mode == 1) {
     if (int e = set_lds(dconvT_kernel, lds)) return e;
-    hipLaunchKernelGGL(dconvT_kernel, grid, dim3(256), lds, s, x, g, c_in, packed_w, c_out, n_groups,
-                       bias, addend, out);
+    hipLaunchKernelGGL(dconvT_kernel, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g, c_in,
+                       packed_w, c_out, n_groups, bias, addend, out);
     return pv2::check_launch("dconv3_forward(transposed)");
   }
-#define PV2_DCONV_LAUNCH(NB_, MT_, CK_)                                                                 \
+  // consecutive tiles per workgroup: enough workgroups for two full rounds of the 256 CUs x 2, and
+  // the deeper the pipeline the smaller the share of its un-overlapped first box
+  int tpw = 1;
+  static const int force_tpw = env_int("PV2_DCONV_TPW", 0);
+  while (tpw < 8 && n_tiles * n_groups / (tpw * 2) >= 1024) tpw *= 2;
+  if (force_tpw) tpw = force_tpw;
+  const dim3 grid((unsigned)(((n_tiles + tpw - 1) / tpw) * n_groups));
+  const int pfn = (g.HZ * g.HY * g.HX * (ck / 4) + 255) / 256;  // float4 of the box per thread
+  const bool masked = in_mask_src != nullptr;
+#define PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, MASKED_)                                                  \
   do {                                                                                                  \
-    if (int e = set_lds(dconv_kernel<NB_, MT_, CK_>, lds)) return e;                                    \
-    hipLaunchKernelGGL((dconv_kernel<NB_, MT_, CK_>), grid, dim3(256), lds, s, x, g, c_in, packed_w,    \
-                       c_out, n_groups, in_scale, in_shift, in_mask_src, bias, addend, relu, out);      \
+    if (int e = set_lds(dconv_kernel<NB_, MT_, CK_, PFN_, MASKED_>, lds)) return e;                     \
+    hipLaunchKernelGGL((dconv_kernel<NB_, MT_, CK_, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g,     \
+                       c_in, packed_w, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias,     \
+                       addend, relu, out);                                                              \
   } while (0)
+#define PV2_DCONV_MASK(NB_, MT_, CK_, PFN_)               \
+  do {                                                    \
+    if (masked) PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, true);   \
+    else PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, false);         \
+  } while (0)
+  PV2_REQUIRE(pfn <= 13, "dconv3_forward: halo box larger than the register prefetch");
   if (mode == 2) {
-    if (nb == 2) PV2_DCONV_LAUNCH(2, 1, 8);
-    else PV2_DCONV_LAUNCH(1, 1, 8);
-  } else if (nb == 2 && mt == 2) PV2_DCONV_LAUNCH(2, 2, 16);
-  else if (nb == 2) PV2_DCONV_LAUNCH(2, 1, 16);
-  else if (mt == 2) PV2_DCONV_LAUNCH(1, 2, 16);
-  else PV2_DCONV_LAUNCH(1, 1, 16);
+    if (nb == 2) PV2_DCONV_MASK(2, 1, 8, 13);
+    else PV2_DCONV_MASK(1, 1, 8, 13);
+  } else if (mt == 2) {
+    PV2_DCONV_MASK(1, 2, 16, 13);
+  } else if (pfn <= 9) {
+    if (nb == 2) PV2_DCONV_MASK(2, 1, 16, 9);
+    else PV2_DCONV_MASK(1, 1, 16, 9);
+  } else {
+    if (nb == 2) PV2_DCONV_MASK(2, 1, 16, 13);
+    else PV2_DCONV_MASK(1, 1, 16, 13);
+  }
+#undef PV2_DCONV_MASK
 #undef PV2_DCONV_LAUNCH
   return pv2::check_launch("dconv3_forward");
 }
