@@ -802,13 +802,19 @@ def main():
     lookahead = hasattr(raw_model, "prefetch") and not args.no_prefetch
 
     def stage(i):
-        b = clone_batch(batches[i % len(batches)])
-        if args.raw_points and "grid_coord" not in b:
+        if args.raw_points:
             # the device half of the input pipeline, inside the timed region: GridSample of the raw
-            # points (same voxels and order as the host transform, tests/test_gpu_voxelize.py)
-            from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample
+            # points (same voxels and order as the host transform, tests/test_gpu_voxelize.py), on the
+            # input stream - its one device -> host read must not wait for the previous step
+            from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample, input_stream
 
-            b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
+            with input_stream(device) as pipe:
+                b = clone_batch(batches[i % len(batches)])
+                if "grid_coord" not in b:
+                    b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
+                b = pipe.adopt(b)
+        else:
+            b = clone_batch(batches[i % len(batches)])
         return raw_model.prefetch(b) if lookahead else b
 
     staged = [stage(0)]

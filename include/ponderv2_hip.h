@@ -385,6 +385,11 @@ int pv2_maxpool3d_cl_forward(const float* x, int B, int Z, int Y, int X, int C, 
                              uint32_t* idx, pv2_stream_t stream);
 int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, int Z, int Y, int X,
                               int C, float* grad_x, pv2_stream_t stream);
+/* The same with the pooled tensor's OTHER gradient added in: grad_x = addend + unpool(grad_y).  In the
+ * U-Net an encoder level's output feeds both the next level's pooling and a decoder level's skip sum
+ * (unet3d.py:401-411); autograd would add the two gradients in a separate pass.  addend [as grad_x] or NULL. */
+int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend, int B,
+                                  int Z, int Y, int X, int C, float* grad_x, pv2_stream_t stream);
 
 /* Batched inverse of `batch` row-major n x n matrices, n <= 4 (one launch; Gauss-Jordan with partial
  * pivoting in double precision, result rounded to fp32): the camera / unit-cube transforms of the
@@ -833,6 +838,31 @@ int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int 
                                int c_g, const float* gy_mask_src, int mode, float* partial_ws,
                                float* dw, int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y,
                                int64_t s_x, pv2_stream_t stream);
+
+/* ---- Device GridSample (csrc/voxelize.hip) --------------------------------------------------------
+ * Train-mode GridSample of the reference's input pipeline (ponder/datasets/transform.py:1103-1145,
+ * hashes :1180-1213) on raw points already in HBM: one representative per occupied voxel, voxels in
+ * ascending UNSIGNED key order, de-duplicated on the reference's own 64-bit key (fnv-1a, or ravel when
+ * ravel_hash != 0).  Two calls around ONE device -> host read of the voxel count:
+ *   stage 1  coord [n,3] (float32, or float64 when coord_is_f64) -> grid [n,3] = floor(coord /
+ *            grid_size) - min, slot_of [n], the hash table (table_keys [table_size] pre-filled with
+ *            0xff bytes, table_count [table_size] zeroed; table_size a power of two >= 2 n), the
+ *            unsorted unique (key, slot) list and *n_vox (zeroed by the caller); minmax [6] scratch.
+ *   stage 2  sorts the list (rocPRIM, workspace of pv2_voxelize_workspace_bytes(n_vox)), builds each
+ *            voxel's member list and writes idx_unique [n_vox] = the ((draws mod max_count) mod
+ *            count)-th member of voxel v in point-index order, grid_coord [n_vox,3] (both int64).
+ *            cursor [n_vox] and max_count [1] zeroed by the caller; the rest is scratch. */
+int pv2_voxelize_stage1(const void* coord, int coord_is_f64, int64_t n, double grid_size, int ravel_hash,
+                        int64_t* minmax, uint64_t* table_keys, int32_t* table_count, int64_t table_size,
+                        int32_t* grid, int32_t* slot_of, uint64_t* uniq_keys, int32_t* uniq_slot,
+                        int32_t* n_vox, pv2_stream_t stream);
+size_t pv2_voxelize_workspace_bytes(int64_t n_vox);
+int pv2_voxelize_stage2(int64_t n, int64_t n_vox, const uint64_t* uniq_keys, const int32_t* uniq_slot,
+                        const int32_t* table_count, const int32_t* slot_of, const int32_t* grid,
+                        const int64_t* draws, uint64_t* sorted_keys, int32_t* sorted_slot,
+                        int32_t* rank_of_slot, int32_t* count, int32_t* start, int32_t* cursor,
+                        int32_t* members, int32_t* max_count, void* workspace, size_t workspace_bytes,
+                        int64_t* idx_unique, int64_t* grid_coord, pv2_stream_t stream);
 
 #ifdef __cplusplus
 }

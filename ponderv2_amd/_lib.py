@@ -167,6 +167,7 @@ SIGNATURES = {
         + [_P] * 8 + [_P]),
     "pv2_maxpool3d_cl_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pv2_maxpool3d_cl_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pv2_maxpool3d_cl_backward_add": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pv2_small_inverse": (c_int, [_P, c_int64, c_int, _P, _P]),
     "pv2_gather_rows": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
@@ -200,6 +201,11 @@ SIGNATURES["pv2_dconv3_backward_weight"] = (
     + [c_int64] * 5 + [_P])
 SIGNATURES["pv2_bn_statistics"] = (
     c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P])
+SIGNATURES["pv2_voxelize_stage1"] = (
+    c_int, [_P, c_int, c_int64, ctypes.c_double, c_int, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P])
+SIGNATURES["pv2_voxelize_workspace_bytes"] = (c_size_t, [c_int64])
+SIGNATURES["pv2_voxelize_stage2"] = (
+    c_int, [c_int64, c_int64] + [_P] * 14 + [_P, c_size_t, _P, _P, _P])
 
 _lib = None
 

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(
 // one thread per 4 channels of one INPUT cell
 __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(
     const float4* __restrict__ gy, const uint32_t* __restrict__ idx, int B, int Z, int Y, int X,
-    int c4, float4* __restrict__ gx) {
+    int c4, const float4* __restrict__ addend, float4* __restrict__ gx) {
   const int Zo = Z >> 1, Yo = Y >> 1, Xo = X >> 1;
   const int64_t total = (int64_t)B * Z * Y * X * c4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -65,17 +65,19 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(
     cell /= Y;
     const int z = (int)(cell % Z);
     const int b = (int)(cell / Z);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (addend: the other gradient of the pooled tensor - an encoder level's output also feeds a
+    // decoder level as its skip connection - summed here instead of by a separate pass)
+    float4 g = addend != nullptr ? addend[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int zo = z >> 1, yo = yy >> 1, xo = xx >> 1;
     if (zo < Zo && yo < Yo && xo < Xo) {  // (odd trailing planes are outside every window)
       const int64_t o = ((((int64_t)b * Zo + zo) * Yo + yo) * Xo + xo) * c4 + c;
       const uint32_t w = (uint32_t)(((z & 1) << 2) | ((yy & 1) << 1) | (xx & 1));
       const uint32_t pos = idx[o];
       const float4 v = gy[o];
-      if ((pos & 0xffu) == w) g.x = v.x;
-      if (((pos >> 8) & 0xffu) == w) g.y = v.y;
-      if (((pos >> 16) & 0xffu) == w) g.z = v.z;
-      if ((pos >> 24) == w) g.w = v.w;
+      if ((pos & 0xffu) == w) g.x += v.x;
+      if (((pos >> 8) & 0xffu) == w) g.y += v.y;
+      if (((pos >> 16) & 0xffu) == w) g.z += v.z;
+      if ((pos >> 24) == w) g.w += v.w;
     }
     gx[e] = g;
   }
@@ -102,8 +104,19 @@ int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, i
   const int64_t total = (int64_t)B * Z * Y * X * (C / 4);
   hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(pv2::grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float4*)grad_y, idx, B, Z, Y, X, C / 4,
-                     (float4*)grad_x);
+                     (const float4*)nullptr, (float4*)grad_x);
   return pv2::check_launch("maxpool3d_cl_backward");
+}
+
+int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend, int B,
+                                  int Z, int Y, int X, int C, float* grad_x, pv2_stream_t stream) {
+  PV2_REQUIRE(B >= 1 && Z >= 2 && Y >= 2 && X >= 2 && C >= 4 && (C % 4) == 0,
+              "pv2_maxpool3d_cl_backward_add: needs C % 4 == 0 and at least one 2x2x2 window");
+  const int64_t total = (int64_t)B * Z * Y * X * (C / 4);
+  hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(pv2::grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)grad_y, idx, B, Z, Y, X, C / 4,
+                     (const float4*)addend, (float4*)grad_x);
+  return pv2::check_launch("maxpool3d_cl_backward_add");
 }
 
 }  // extern "C"

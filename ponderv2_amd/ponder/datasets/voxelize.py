@@ -73,6 +73,7 @@ class GridSample:
 # can run on the GPU after the raw cloud has been uploaded instead of in a DataLoader worker.
 # ---------------------------------------------------------------------------------------------
 _SIGN = -(1 << 63)
+_KERNELS = __import__("os").environ.get("PV2_VOXELIZE_KERNELS", "1") != "0"
 
 
 def _as_i64(u):
@@ -131,6 +132,104 @@ def grid_sample_torch(coord, grid_size, hash_type="fnv", pick=None):
     return idx_unique, grid[idx_unique]
 
 
+def grid_sample_device(coord, grid_size, hash_type="fnv", pick=None):
+    """``grid_sample_torch`` on the hand-written kernels of csrc/voxelize.hip (device tensors only): the
+    raw points are de-duplicated through a hash table keyed by the reference's own 64-bit key and only
+    the unique keys are sorted - instead of two 64-bit sorts of every raw point.  Same voxel set, same
+    order, same representatives for equal draws; one device -> host read (the voxel count)."""
+    import torch
+
+    from ponderv2_amd import _lib
+    from ponderv2_amd.kernels import _ptr, _stream
+
+    assert coord.is_cuda and coord.dim() == 2 and coord.shape[1] == 3
+    if coord.dtype not in (torch.float32, torch.float64):
+        coord = coord.float()
+    coord = coord.contiguous()
+    dev, n = coord.device, coord.shape[0]
+    L, st = _lib.lib(), _stream(coord)
+    table = 1 << max(int(2 * n - 1).bit_length(), 4)
+    i32 = dict(dtype=torch.int32, device=dev)
+    tkeys = torch.full((table,), -1, dtype=torch.int64, device=dev)          # 0xff..ff = empty
+    ints = torch.zeros(table + 2, **i32)                                    # table counts | n_vox | max count
+    tcount, n_vox_dev, max_count = ints[:table], ints[table:table + 1], ints[table + 1:]
+    grid, slot_of = torch.empty((n, 3), **i32), torch.empty(n, **i32)
+    ukeys, uslot = torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, **i32)
+    minmax = torch.empty(6, dtype=torch.int64, device=dev)
+    _lib.check(L.pv2_voxelize_stage1(
+        _ptr(coord), int(coord.dtype == torch.float64), n, float(grid_size), int(hash_type != "fnv"),
+        _ptr(minmax), _ptr(tkeys), _ptr(tcount), table, _ptr(grid), _ptr(slot_of), _ptr(ukeys), _ptr(uslot),
+        _ptr(n_vox_dev), st), "pv2_voxelize_stage1")
+    n_vox = int(n_vox_dev.item())                                           # the one host read
+    if pick is None:   # raw draws; the kernel reduces them modulo the largest member count, then the voxel's
+        pick = torch.randint(0, 2 ** 31 - 1, (n_vox,), device=dev)
+    pick = pick.to(dev, torch.int64).contiguous()
+    assert pick.numel() == n_vox, (pick.numel(), n_vox)
+    skeys, sslot = torch.empty(n_vox, dtype=torch.int64, device=dev), torch.empty(n_vox, **i32)
+    rank = torch.empty(table, **i32)
+    per_vox = torch.zeros(3 * n_vox, **i32)                                 # count | start | cursor (zeroed)
+    members = torch.empty(n, **i32)
+    ws_bytes = int(L.pv2_voxelize_workspace_bytes(n_vox))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    idx_unique = torch.empty(n_vox, dtype=torch.int64, device=dev)
+    grid_coord = torch.empty((n_vox, 3), dtype=torch.int64, device=dev)
+    _lib.check(L.pv2_voxelize_stage2(
+        n, n_vox, _ptr(ukeys), _ptr(uslot), _ptr(tcount), _ptr(slot_of), _ptr(grid), _ptr(pick), _ptr(skeys),
+        _ptr(sslot), _ptr(rank), _ptr(per_vox[:n_vox]), _ptr(per_vox[n_vox:2 * n_vox]),
+        _ptr(per_vox[2 * n_vox:]), _ptr(members), _ptr(max_count), _ptr(ws), ws_bytes, _ptr(idx_unique),
+        _ptr(grid_coord), st), "pv2_voxelize_stage2")
+    return idx_unique, grid_coord
+
+
+_INPUT_STREAMS = {}
+
+
+class input_stream:
+    """``with input_stream(device): ...`` - the device half of the input pipeline (upload, GridSample) on
+    its OWN stream.  The transform reads the voxel count back to the host; on the training stream that
+    read waits for everything the trainer has queued (the whole previous step: the host then runs in
+    lock-step with the GPU, +6 ms per step measured); on a stream that carries only the batch's own
+    work it returns in microseconds.  On exit the training stream is made to wait for the input
+    stream, and the tensors handed over (``adopt``) are marked as used by it."""
+
+    def __init__(self, device):
+        import torch
+
+        self.device = torch.device(device)
+        self.on = self.device.type == "cuda"
+        if self.on:
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if key not in _INPUT_STREAMS:
+                _INPUT_STREAMS[key] = torch.cuda.Stream(device=self.device)
+            self.side = _INPUT_STREAMS[key]
+
+    def __enter__(self):
+        import torch
+
+        if self.on:
+            self.cur = torch.cuda.current_stream(self.device)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.side)
+        return False
+
+    def adopt(self, batch):
+        """The batch's tensors were allocated on the input stream and will be read (and later freed)
+        under the training stream."""
+        import torch
+
+        if self.on:
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(self.cur)
+        return batch
+
+
 def device_grid_sample(batch, grid_size=0.02, hash_type="fnv", keys=("coord", "feat", "segment"),
                        picks=None):
     """Train-mode GridSample of a collated batch of RAW points on whatever device the batch lives
@@ -146,8 +245,11 @@ def device_grid_sample(batch, grid_size=0.02, hash_type="fnv", keys=("coord", "f
     out = {k: [] for k in keys if k in batch}
     grids, new_ends, start = [], [], 0
     for b, end in enumerate(ends):
-        idx, grid = grid_sample_torch(batch["coord"][start:end], grid_size, hash_type,
-                                      None if picks is None else picks[b])
+        # device tensors: the HIP hash-insert / segmented-pick kernels (csrc/voxelize.hip); host
+        # tensors (tests, CPU-only boxes): the same transform composed of torch ops
+        sample = grid_sample_device if (batch["coord"].is_cuda and _KERNELS) else grid_sample_torch
+        idx, grid = sample(batch["coord"][start:end], grid_size, hash_type,
+                           None if picks is None else picks[b])
         for k in out:
             out[k].append(batch[k][start:end][idx])
         grids.append(grid)

@@ -18,7 +18,7 @@ from ..utils import comm
 from ..utils.optimizer import build_optimizer, build_scheduler
 from ..utils.registry import Registry
 from ..datasets.collate import loader_collate
-from ..datasets.voxelize import device_grid_sample
+from ..datasets.voxelize import device_grid_sample, input_stream
 from .defaults import create_ddp_model, worker_init_fn
 from .hooks import HOOKS, HookBase
 from ponderv2_amd.rownorm import flush_bn_counters
@@ -187,12 +187,20 @@ class Trainer(TrainerBase):
     def stage(self, batch):
         """A loader batch -> device-resident model input: the copy, the optional device-side
         GridSample, and the launch of its sparse-conv geometry on the side stream."""
-        batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
-                 for k, v in batch.items()}
-        if self.cfg.get("device_voxelize"):
+        if self.cfg.get("device_voxelize") and self.device.type == "cuda":
             # GridSample on the device: the loader streamed raw points (SURVEY 8(f) F3); the voxel
-            # set and its order equal the host transform's (datasets/voxelize.py)
-            batch = device_grid_sample(batch, **self.cfg.device_voxelize)
+            # set and its order equal the host transform's (datasets/voxelize.py).  Upload and
+            # transform ride the input stream: the transform's read of the voxel count then waits
+            # for this batch's own work only, not for the step the trainer has queued
+            with input_stream(self.device) as pipe:
+                batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
+                         for k, v in batch.items()}
+                batch = pipe.adopt(device_grid_sample(batch, **self.cfg.device_voxelize))
+        else:
+            batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
+                     for k, v in batch.items()}
+            if self.cfg.get("device_voxelize"):
+                batch = device_grid_sample(batch, **self.cfg.device_voxelize)
         model = self.model.module if hasattr(self.model, "module") else self.model
         if hasattr(model, "prefetch") and self.device.type == "cuda":
             batch = model.prefetch(batch)

@@ -15,14 +15,20 @@ def _lin(layer, x):
 
 class _ConditionedMLP(nn.Module):
     def __init__(self, in_dim, out_dim, hidden_size, n_blocks, points_factor, activation,
-                 out_activation=None):
+                 out_activation=None, fc_p_first=False):
         super().__init__()
         dims = [hidden_size] * (n_blocks + 1) + [out_dim]
         self.num_layers = len(dims)
         for l in range(self.num_layers - 1):
             setattr(self, f"lin{l}", nn.Linear(dims[l], dims[l + 1]))
+        # construction order = the reference's (decoders.py:22-25 fc_c then fc_p in SDFDecoder, :59-63
+        # and :99-103 fc_p then fc_c in the other two): the same seed then draws the same initial weights
+        # and state_dict() lists the keys in the same order
+        if fc_p_first:
+            self.fc_p = nn.Linear(3, hidden_size)
         self.fc_c = nn.ModuleList(nn.Linear(in_dim, hidden_size) for _ in range(self.num_layers - 1))
-        self.fc_p = nn.Linear(3, hidden_size)
+        if not fc_p_first:
+            self.fc_p = nn.Linear(3, hidden_size)
         self.activation = activation
         self.out_activation = out_activation
         self.points_factor = points_factor
@@ -62,9 +68,10 @@ class SDFDecoder(_ConditionedMLP):
 class RGBDecoder(_ConditionedMLP):
     def __init__(self, in_dim, out_dim=3, hidden_size=256, n_blocks=5, points_factor=1.0, **kwargs):
         super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor, nn.ReLU(),
-                         out_activation=torch.sigmoid)
+                         out_activation=torch.sigmoid, fc_p_first=True)
 
 
 class SemanticDecoder(_ConditionedMLP):
     def __init__(self, in_dim, out_dim, hidden_size=256, n_blocks=5, points_factor=1.0, **kwargs):
-        super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor, nn.ReLU())
+        super().__init__(in_dim, out_dim, hidden_size, n_blocks, points_factor, nn.ReLU(),
+                         fc_p_first=True)

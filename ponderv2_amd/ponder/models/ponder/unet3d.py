@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ponderv2_amd import dense_conv, sidestream
+from ponderv2_amd import dense_conv, dense_unet, sidestream
 from ..builder import MODELS
 
 
@@ -389,12 +389,17 @@ class UNet3Dv1m2(nn.Module):
     def forward(self, x, first=None, fold_final=False):
         """``fold_final``: stop in front of ``final_conv`` when the fused render head can apply it
         per sample (fused_head.FoldedVolume) - the 128-channel volume is then never built."""
-        skips = []
-        for level, encoder in enumerate(self.encoders):
-            x = first if (level == 0 and first is not None) else encoder(x)
-            skips.insert(0, x)
-        for decoder, skip in zip(self.decoders, skips[1:]):
-            x = decoder(skip, x)
+        x0 = first if first is not None else self.encoders[0](x)
+        if dense_unet.supported(self, x0):
+            # every level behind the first as ONE autograd node over the dense kernels (dense_unet.py)
+            x = dense_unet.forward(self, x0)
+        else:
+            skips, x = [x0], x0
+            for encoder in self.encoders[1:]:
+                x = encoder(x)
+                skips.insert(0, x)
+            for decoder, skip in zip(self.decoders, skips[1:]):
+                x = decoder(skip, x)
         if fold_final and not (self.testing and self.final_activation is not None):
             from ponderv2_amd import fused_head
             if fused_head.fold_supported(self.final_conv, x):

@@ -1,0 +1,98 @@
+"""The dense U-Net as one autograd node (ponderv2_amd/dense_unet.py) against the modular route through
+the same kernels (dense_conv.py units, one autograd node per op) - bit for bit - and against the
+stock modules in float64 (reference: ponder/models/ponder/unet3d.py:646-671)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(levels, device):
+    from ponderv2_amd.ponder.models.ponder.unet3d import UNet3Dv1m2
+
+    torch.manual_seed(3)
+    net = UNet3Dv1m2(in_channels=32, out_channels=32, f_maps=32, num_levels=levels)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    return net.to(device).train()
+
+
+def _step(net, x0, probe):
+    for p in net.parameters():
+        p.grad = None
+    x = x0.clone().requires_grad_(True)
+    out = net(None, first=x)
+    (out * probe).sum().backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    stats = {n: b.clone() for n, b in net.named_buffers() if "running" in n}
+    return out.detach().clone(), x.grad.clone(), grads, stats
+
+
+@pytest.mark.parametrize("levels,shape", [(3, (2, 32, 8, 16, 32)), (4, (1, 32, 8, 16, 16))])
+def test_fused_dense_unet_equals_the_modular_route_bitwise(device, monkeypatch, levels, shape):
+    from ponderv2_amd import dense_unet
+
+    net = _net(levels, device)
+    ref_net = copy.deepcopy(net)
+    torch.manual_seed(5)
+    x0 = torch.relu(torch.randn(*shape, device=device)).contiguous(memory_format=torch.channels_last_3d)
+    calls = []
+    orig = dense_unet.forward
+    monkeypatch.setattr(dense_unet, "forward", lambda *a: (calls.append(1), orig(*a))[1])
+    out_shape = net(None, first=x0).shape
+    assert calls, "the fused node is the default route"
+    probe = torch.randn(out_shape, device=device)
+    net2 = copy.deepcopy(ref_net)
+    got = _step(net2, x0, probe)
+    monkeypatch.setattr(dense_unet, "ENABLED", False)
+    want = _step(ref_net, x0, probe)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert got[2].keys() == want[2].keys()
+    for k in want[2]:
+        if k.endswith("upsample.bias"):   # column sums through atomics: order-dependent rounding
+            assert torch.allclose(got[2][k], want[2][k], rtol=1e-4, atol=1e-5 * float(want[2][k].abs().max() + 1)), k
+        else:
+            assert torch.equal(got[2][k], want[2][k]), k
+    for k in want[3]:
+        assert torch.equal(got[3][k], want[3][k]), k
+
+
+def test_fused_dense_unet_vs_stock_modules_float64(device):
+    """Values and every gradient against nn.MaxPool3d / BatchNorm3d / Conv3d / ConvTranspose3d in
+    float64 on the host."""
+    net = _net(3, device)
+    ref = copy.deepcopy(net).cpu().double()
+    torch.manual_seed(7)
+    x0 = torch.relu(torch.randn(2, 32, 8, 16, 32))
+    probe = torch.randn(2, 32, 8, 16, 32)
+    xd = x0.to(device).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    out = net(None, first=xd)
+    assert out.shape[1] == 32   # final_conv: 32 -> 32 (a 1x1x1 conv, not part of the fused node)
+    (out * probe.to(device)).sum().backward()
+    x64 = x0.double().requires_grad_(True)
+    skips, x = [x64], x64
+    for enc in ref.encoders[1:]:
+        x = enc.basic_module.ReLU(enc.basic_module.conv(enc.basic_module.batchnorm(enc.pooling(x))))
+        skips.insert(0, x)
+    for dec, skip in zip(ref.decoders, skips[1:]):
+        s = skip + dec.upsampling.upsample(x, output_size=list(skip.shape[2:]))
+        x = torch.relu(dec.basic_module.conv(dec.basic_module.batchnorm(s)))
+    ref_out = ref.final_conv(x)
+    (ref_out * probe.double()).sum().backward()
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+    assert rel(out.detach(), ref_out.detach()) < 2e-5
+    assert rel(xd.grad, x64.grad) < 2e-4
+    got = dict(net.named_parameters())
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        assert rel(got[name].grad, p.grad) < 2e-4, name

@@ -68,3 +68,50 @@ def test_device_voxelisation_of_a_raw_batch_on_the_gpu_feeds_the_backbone(device
     rb = K.build_subm_rulebook(coords, 3)
     assert rb.n_out == coords.shape[0] and rb.n_pairs >= rb.n_out   # every voxel pairs with itself
     assert int(rb.kstart_host[14] - rb.kstart_host[13]) == rb.n_out  # centre offset: all rows, no duplicates
+
+
+@pytest.mark.parametrize("hash_type", ["fnv", "ravel"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_voxelize_kernels_equal_the_sort_based_transform(device, hash_type, dtype):
+    """csrc/voxelize.hip (hash-table de-duplication on the reference's key, sort of the unique keys
+    only, segmented pick) against ``grid_sample_torch`` (two full sorts) and the host GridSample: the
+    same voxels in the same order, and for equal draws the SAME representative of every voxel."""
+    from ponderv2_amd.ponder.datasets import GridSample
+    from ponderv2_amd.ponder.datasets.voxelize import grid_sample_device, grid_sample_torch
+
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-3.0, 2.5, size=(300000, 3)).astype(np.float32)
+    pts[:5000] = pts[5000:10000]                       # exact duplicates as well
+    coord = torch.from_numpy(pts).to(device, dtype)
+    np.random.seed(3)
+    host = GridSample(grid_size=0.04, hash_type=hash_type, mode="train", keys=("coord",),
+                      return_grid_coord=True)(dict(coord=pts.copy()))
+    n_vox = len(host["grid_coord"])
+    draws = torch.from_numpy(rng.integers(0, 1 << 30, size=n_vox)).to(device)
+    idx_t, grid_t = grid_sample_torch(coord, 0.04, hash_type)       # (its own draws: count known here)
+    assert idx_t.numel() == n_vox
+    idx_k, grid_k = grid_sample_device(coord, 0.04, hash_type, pick=draws)
+    assert idx_k.dtype == torch.int64 and grid_k.dtype == torch.int64 and grid_k.shape == (n_vox, 3)
+    assert np.array_equal(grid_k.cpu().numpy(), host["grid_coord"])  # same voxels, same order
+    assert torch.equal(grid_k, grid_t)
+    # the representative is the ((draw mod max count) mod count)-th member in point-index order
+    cell = np.floor(pts.astype(np.float64) / 0.04).astype(np.int64)
+    cell -= cell.min(0)
+    got = idx_k.cpu().numpy()
+    assert np.array_equal(cell[got], host["grid_coord"])
+    key = (cell[:, 0] * (cell[:, 1].max() + 1) + cell[:, 1]) * (cell[:, 2].max() + 1) + cell[:, 2]
+    by_key = np.argsort(key, kind="stable")
+    sk = key[by_key]
+    starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+    counts = np.diff(np.r_[starts, len(sk)])
+    assert len(starts) == n_vox
+    t = (draws.cpu().numpy() % counts.max())
+    # voxels of `host` are in hash order, those of `starts` in ravel order: match through the coordinates
+    want = {}
+    for s0, c in zip(starts, counts):
+        want[tuple(cell[by_key[s0]])] = (by_key[s0:s0 + c], c)
+    for v in range(0, n_vox, max(1, n_vox // 2000)):
+        members, c = want[tuple(host["grid_coord"][v])]
+        assert got[v] == members[t[v] % c], v
+    idx_r, _ = grid_sample_device(coord, 0.04, hash_type)             # device-drawn representatives
+    assert np.array_equal(cell[idx_r.cpu().numpy()], host["grid_coord"])
