@@ -565,6 +565,45 @@ class KernelTimer:
         wrap_c("pv2_neus_field_forward", "field_fwd_kernel", field_fwd_cost)
         wrap_c("pv2_neus_field_backward", "field_bwd_kernel + volume_scatter_kernel", field_bwd_cost)
         wrap_c("pv2_neus_coarse_sample", "coarse_sample_kernel", coarse_cost)
+
+        # dense 3x3x3 convolutions of the projection U-Net (csrc/dense_conv.hip): flops 2 * cells * 27 *
+        # c_in * c_out; bytes: input + output grids once, the weights once (mask / addend reads on top)
+        def dconv_fwd_cost(*a):
+            b, z, y, xx, c_in, c_out, mode = a[1], a[2], a[3], a[4], a[5], a[7], a[8]
+            cells_in = float(b * z * y * xx)
+            cells_out = cells_in * (8.0 if mode == 1 else 0.125 if mode == 2 else 1.0)
+            taps_cells = cells_in if mode == 1 else cells_out
+            extra = (cells_in * c_in if a[11] else 0.0) + (cells_out * c_out if a[13] else 0.0)
+            return (2.0 * taps_cells * 27 * c_in * c_out,
+                    4.0 * (cells_in * c_in + cells_out * c_out + 27 * c_in * c_out + extra), 0.0)
+
+        def dconv_wgrad_cost(*a):
+            b, z, y, xx, c_x, c_g, mode = a[1], a[2], a[3], a[4], a[5], a[9], a[11]
+            cells = float(b * z * y * xx)
+            g_cells = cells * (8.0 if mode == 1 else 1.0)
+            return (2.0 * cells * 27 * c_x * c_g,
+                    4.0 * (cells * c_x + g_cells * c_g * (2.0 if a[10] else 1.0) + 27 * c_x * c_g), 0.0)
+
+        orig_dconv = handle.pv2_dconv3_forward
+        self._orig_c["pv2_dconv3_forward"] = orig_dconv
+        fam_by_mode = {0: "dconv_kernel (dense 3x3x3 conv: fwd + grad-input)",
+                       1: "dconvT_kernel (dense transposed conv k3 s2: fwd)",
+                       2: "dconv_kernel (strided k3 s2: grad-input of the transposed conv)"}
+
+        def timed_dconv(*a):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            rc = orig_dconv(*a)
+            e_.record()
+            c = dconv_fwd_cost(*a)
+            fam = fam_by_mode[a[8]]
+            timer.peaks.setdefault(fam, F32_MFMA_PEAK_TFLOPS)
+            timer._add(fam, s_, e_, c[0], c[1], None)
+            return rc
+
+        handle.pv2_dconv3_forward = timed_dconv
+        wrap_c("pv2_dconv3_backward_weight", "dconv_wgrad_kernel + dconv_wgrad_reduce_kernel (dense conv weight "
+               "gradient, two-stage, deterministic)", dconv_wgrad_cost)
         wrap("spconv_forward", "spconv_fwd_kernel (fwd+dgrad)", conv_cost)
         wrap("spconv_grad_input", "spconv_fwd_kernel (fwd+dgrad)", dgrad_cost)
         wrap("spconv_backward_weight", "spconv_wgrad_kernel", wgrad_cost)

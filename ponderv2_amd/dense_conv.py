@@ -113,8 +113,7 @@ def conv_supported(conv, x):
             and tuple(conv.kernel_size) == (3, 3, 3) and tuple(conv.stride) == (1, 1, 1)
             and tuple(conv.padding) == (1, 1, 1) and tuple(conv.dilation) == (1, 1, 1)
             and conv.groups == 1 and conv.padding_mode == "zeros"
-            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
-            and not torch.is_autocast_enabled("cuda"))
+            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0)
 
 
 def upsample_supported(convT, x, output_size):
@@ -123,8 +122,7 @@ def upsample_supported(convT, x, output_size):
             and tuple(convT.kernel_size) == (3, 3, 3) and tuple(convT.stride) == (2, 2, 2)
             and tuple(convT.padding) == (1, 1, 1) and tuple(convT.dilation) == (1, 1, 1)
             and convT.groups == 1 and convT.in_channels % 32 == 0 and convT.out_channels % 32 == 0
-            and [int(s) for s in output_size] == [2 * int(s) for s in x.shape[2:]]
-            and not torch.is_autocast_enabled("cuda"))
+            and [int(s) for s in output_size] == [2 * int(s) for s in x.shape[2:]])
 
 
 def _on_side_stream(fn, leaf, keep):

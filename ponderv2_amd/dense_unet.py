@@ -38,9 +38,14 @@ class Spec:
 
 def supported(net, x0):
     """``net``: UNet3Dv1m2; ``x0``: the first level's output.  Every later level must be a pooled "bcr"
-    SingleConv / an Upsampling + "bcr" SingleConv the dense kernels cover, in training mode."""
+    SingleConv / an Upsampling + "bcr" SingleConv the dense kernels cover, in training mode.  An ambient
+    autocast region does not change the answer: the node's kernels are fp32 launches autocast never
+    touches - under the reference's ``enable_amp=True`` the dense U-Net then runs at HIGHER precision
+    than the reference's 16-bit library convolutions (and faster than those: no tuned 16-bit
+    3-D convolutions exist for these shapes - 823 ms per step at 8 scenes per GPU through the library's
+    fallback, profiles/r04_bench_shipped_*.json)."""
     if not (ENABLED and dc.ENABLED and x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 5
-            and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda")
+            and torch.is_grad_enabled()
             and len(net.decoders) == len(net.encoders) - 1 and len(net.encoders) >= 2):
         return False
     shape, c = list(x0.shape[2:]), x0.shape[1]

@@ -55,8 +55,10 @@ def test_fused_dense_unet_equals_the_modular_route_bitwise(device, monkeypatch, 
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     assert got[2].keys() == want[2].keys()
     for k in want[2]:
-        if k.endswith("upsample.bias"):   # column sums through atomics: order-dependent rounding
-            assert torch.allclose(got[2][k], want[2][k], rtol=1e-4, atol=1e-5 * float(want[2][k].abs().max() + 1)), k
+        if k.endswith("upsample.bias"):
+            # a bias in front of a BatchNorm has an exactly-zero true gradient: what is compared is the
+            # rounding noise of column sums whose atomics add in a different order on every run
+            assert (got[2][k] - want[2][k]).abs().max() < 2e-4, k
         else:
             assert torch.equal(got[2][k], want[2][k]), k
     for k in want[3]:
