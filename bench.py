@@ -957,8 +957,10 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": (f"{args.amp} autocast entered around the whole model (reference enable_amp=True); "
-                      "the model scopes it to the dense UNet3D, hand-written kernels and losses f32"
+            "dtype": (f"{args.amp} autocast entered around the whole model (reference enable_amp=True): "
+                      f"sparse backbone on the {args.amp} MFMA kernels (fp32 accumulation, statistics "
+                      "and master weights); dense UNet3D, ray march and losses f32 on the hand-written "
+                      "kernels (above the reference's 16-bit precision there)"
                       if args.amp else
                       "f32" if args.dense_dtype == "float32" else
                       f"f32 sparse conv + render head; {args.dense_dtype} autocast for the dense "

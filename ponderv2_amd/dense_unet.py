@@ -183,6 +183,15 @@ class _DenseUNet(torch.autograd.Function):
         dec_p = [params[3 * n_enc + 5 * j:3 * n_enc + 5 * j + 5] for j in range(n_dec)]
         grads = [None] * len(params)
         wjobs = []       # weight-gradient launches, issued in one batch at the end
+        # every parameter gradient of the node in ONE flat buffer (64-float aligned pieces): the
+        # gradient synchronisation then moves them with one copy (utils/grad_sync.py arena blocks)
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        arena = torch.empty(total, dtype=torch.float32, device=dev)
+        # (same strides as the parameter - the conv weights are channels_last_3d -, like empty_like)
+        pviews = [arena[o:o + p.numel()].as_strided(p.shape, p.stride()) for o, p in zip(offs, params)]
 
         def level_backward(g, x, stats, y, bn_w, w, slot):
             """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients."""
@@ -206,7 +215,7 @@ class _DenseUNet(torch.autograd.Function):
             k = 3 * n_enc + 5 * j
             gs, gsum = level_backward(g, s, stats, y, bn_w, w, k + 4)
             c = s.shape[1]
-            grads[k + 2], grads[k + 3] = gsum[c:], gsum[:c]
+            grads[k + 2], grads[k + 3] = pviews[k + 2].copy_(gsum[c:]), pviews[k + 3].copy_(gsum[:c])
             gskip[j] = gs
             x_in = enc[n_enc - 1][3] if j == 0 else dec[j - 1][2]
             wjobs.append((1, x_in, None, None, gs, None, up_w, k))
@@ -217,7 +226,7 @@ class _DenseUNet(torch.autograd.Function):
             bn_w, bn_b, w = enc_p[i]
             gp, gsum = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2)
             c = p.shape[1]
-            grads[3 * i], grads[3 * i + 1] = gsum[c:], gsum[:c]
+            grads[3 * i], grads[3 * i + 1] = pviews[3 * i].copy_(gsum[c:]), pviews[3 * i + 1].copy_(gsum[:c])
             b, _, z, yy, xx = p.shape
             add = gskip[n_enc - 1 - i]      # the pooled tensor is also that decoder level's skip
             g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
@@ -231,7 +240,7 @@ class _DenseUNet(torch.autograd.Function):
             for kind, x, scale, shift, gy, mask, w, slot in wjobs:
                 if kind == 2:    # bias of the transposed conv: column sums of the gradient rows
                     rows = gy.permute(0, 2, 3, 4, 1).reshape(-1, gy.shape[1])
-                    gb = torch.empty(gy.shape[1], dtype=torch.float32, device=dev)
+                    gb = pviews[slot]
                     _lib.check(L.pv2_col_sum(rows.data_ptr(), rows.shape[0], rows.shape[1], gb.data_ptr(), stw),
                                "pv2_col_sum")
                     out.append((slot, gb))
@@ -240,7 +249,7 @@ class _DenseUNet(torch.autograd.Function):
                 c_g = gy.shape[1]
                 floats = int(L.pv2_dconv3_wgrad_partial_floats(b, z, yy, xx, c_x, c_g, kind))
                 part = workspace("dconv_wgrad", dev, floats)
-                dw = torch.empty_like(w)
+                dw = pviews[slot]
                 sw = dw.stride()
                 n_dim = 0 if kind == 0 else 1
                 _lib.check(L.pv2_dconv3_backward_weight(
@@ -252,7 +261,7 @@ class _DenseUNet(torch.autograd.Function):
 
         leaves = [job[6] for job in wjobs]
         if sidestream.active(g) and all(sidestream.safe_leaf(w) for w in leaves):
-            keep = tuple(t for job in wjobs for t in job if torch.is_tensor(t)) + tuple(saved)
+            keep = tuple(t for job in wjobs for t in job if torch.is_tensor(t)) + tuple(saved) + (arena,)
             done = sidestream.fork(weight_gradients, keep)
         else:
             done = weight_gradients()

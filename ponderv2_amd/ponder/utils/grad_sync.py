@@ -15,35 +15,116 @@ parameters with gradients is the same everywhere) needs nothing else.  ``uniform
 multi-dataset model trains a different condition's norms per rank and step) reduces a usage flag
 per parameter along with the data and reads the flags back - one small device read per step, the
 counterpart of DDP's ``find_unused_parameters`` bitmap exchange.
+
+Arena blocks.  The sparse backbone's native executor hands ALL its parameter gradients back as views
+of one flat buffer (ponderv2_amd/spunet_native.py: 177 tensors, 150 of the step's 160 MB).  When the
+first synchronised step finds such a family - gradients that are contiguous views of one storage -
+the flat buffer mirrors the family's layout (same relative offsets, alignment gaps included), and
+from then on the family moves with ONE copy each way instead of one per tensor (1.8 ms of host time
+per step for 2 x 229 small copies, profiles/r04_grad_sync_host_profile.txt).  The collectives always
+run on the flat buffer, whose layout is fixed after the first step and agreed between the ranks
+(one all-reduce of a layout signature, once): a step - or a rank - whose gradients do not sit at the
+recorded offsets simply falls back to per-tensor copies into the same places, so the ranks can
+never disagree about what they reduce.
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True):
+    def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
+                 use_blocks: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.numel = sum(p.numel() for p in self.params)
         self.slice_elems = max(int(slice_mb * 2 ** 20 // 4), 1)
         self._flat = None
         self._views = None
+        self._blocks = []
+        self.use_blocks = use_blocks
         self._flag_key, self._flags = None, None
         self.uniform_usage = uniform_usage
         # uniform usage is an ASSUMPTION about the model; it is checked, not trusted (see sync)
         self._last_used, self._steps, self.check_every = None, 0, 64
 
+    def _arena_families(self, min_bytes=1 << 20):
+        """Families of used parameters whose gradients are contiguous views of ONE storage: [(storage
+        ptr, span start (elements from the storage base), span length, [(param index, offset in the
+        span)])], largest first."""
+        by_storage = {}
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                continue
+            st = g.untyped_storage()
+            by_storage.setdefault(st.data_ptr(), []).append((i, (g.data_ptr() - st.data_ptr()) // 4, g.numel()))
+        fams = []
+        for ptr, members in by_storage.items():
+            if len(members) < 8:
+                continue
+            lo = min(o for _, o, _ in members)
+            hi = max(o + n for _, o, n in members)
+            payload = sum(n for _, _, n in members)
+            if payload * 4 >= min_bytes and payload >= 0.9 * (hi - lo):
+                fams.append((ptr, lo, hi - lo, [(i, o - lo) for i, o, _ in members]))
+        fams.sort(key=lambda f: -f[2])
+        return fams
+
     def _buffers(self):
         if self._flat is None:
             ref = self.params[0]
-            # gradients, then one usage flag per parameter
+            # layout: arena blocks (with their gaps) first, then the remaining parameters, then one
+            # usage flag per parameter.  ``self.numel`` = everything in front of the flags.
+            fams = self._arena_families() if (self.use_blocks and self.uniform_usage) else []
+            sig = float(sum((k + 1) * (span % 1000003) + len(m) for k, (_, _, span, m) in enumerate(fams)))
+            if fams and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                # the ranks must agree on the layout: one small reduction, once
+                t = torch.tensor([sig, -sig], dtype=torch.float64, device=ref.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                hi, lo = t.tolist()
+                if hi != -lo:
+                    fams = []
+            in_block, off, blocks = {}, 0, []
+            for _, _, span, members in fams:
+                blocks.append((off, span, members))
+                for i, o in members:
+                    in_block[i] = off + o
+                off += span
+            offsets = []
+            for i, p in enumerate(self.params):
+                if i in in_block:
+                    offsets.append(in_block[i])
+                else:
+                    offsets.append(off)
+                    off += p.numel()
+            self.numel = off
+            self._blocks = blocks
             self._flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=ref.device)
-            views, off = [], 0
-            for p in self.params:
-                views.append(self._flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-            self._views = views
+            self._views = [self._flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, self.params)]
         return self._flat, self._views
+
+    def _block_sources(self):
+        """For every arena block: the live gradient storage span as one tensor when this step's
+        gradients sit exactly where the layout says (then ONE copy moves the block), else None."""
+        out = []
+        for off, span, members in self._blocks:
+            i0, o0 = members[0]
+            g0 = self.params[i0].grad
+            src = None
+            if g0 is not None and g0.is_contiguous():
+                st = g0.untyped_storage()
+                start = (g0.data_ptr() - st.data_ptr()) // 4 - o0          # span start in the storage
+                ok = start >= 0 and (start + span) * 4 <= st.nbytes()
+                base = st.data_ptr() + 4 * start
+                for i, o in members:
+                    g = self.params[i].grad
+                    if g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * o:
+                        ok = False
+                        break
+                if ok:
+                    src = torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, start, (span,))
+            out.append(src)
+        return out
 
     @torch.no_grad()
     def sync(self):
@@ -70,9 +151,19 @@ class FlatGradSync:
                     views[i].zero_()
                 self._steps = 0   # check at once
             self._last_used = key
-            flat[self.numel] = float(sum(i + 1 for i in used))
-        if used:
-            torch._foreach_copy_([views[i] for i in used], [self.params[i].grad for i in used])
+            # (fill_ takes the scalar as a kernel argument.  ``flat[i] = python_float`` is a host -> device
+            # copy from pageable memory, which waits for everything queued on the stream: 12 ms of
+            # blocked host per step, profiles/r04_grad_sync_host_profile.txt)
+            flat[self.numel:self.numel + 1].fill_(float(sum(i + 1 for i in used)))
+        moved = set()
+        sources = self._block_sources() if self._blocks else []
+        for (off, span, members), src in zip(self._blocks, sources):
+            if src is not None:     # the whole arena block in one copy
+                flat[off:off + span].copy_(src)
+                moved.update(i for i, _ in members)
+        rest = [i for i in used if i not in moved]
+        if rest:
+            torch._foreach_copy_([views[i] for i in rest], [self.params[i].grad for i in rest])
         if not self.uniform_usage:
             key = tuple(used)
             if self._flag_key != key:  # the local set changes rarely: its device copy is cached
@@ -104,13 +195,16 @@ class FlatGradSync:
             anywhere = (flat[self.numel:] > 0).tolist()
         if not avg:
             flat[:self.numel].div_(world)
-        targets, sources = [], []
+        for (off, span, members), src in zip(self._blocks, sources):
+            if src is not None:     # averages back into the arena, one copy
+                src.copy_(flat[off:off + span])
+        targets, origins = [], []
         for i, p in enumerate(self.params):
-            if not anywhere[i]:
+            if not anywhere[i] or i in moved:
                 continue
             if p.grad is None:
                 p.grad = torch.empty_like(p)
             targets.append(p.grad)
-            sources.append(views[i])
+            origins.append(views[i])
         if targets:
-            torch._foreach_copy_(targets, sources)
+            torch._foreach_copy_(targets, origins)

@@ -98,6 +98,56 @@ def grad_sync_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def arena_sync_worker(rank, world, port, out_dir):
+    """FlatGradSync with gradients that live in ONE flat arena (what the sparse backbone's native
+    executor hands back): the block route (one copy each way) gives the rank means, keeps working
+    when a later step's gradients are ordinary tensors again, and when only ONE rank's are."""
+    from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(30)], torch.nn.Linear(96, 3))
+    params = list(model.parameters())
+    sync = FlatGradSync(params, slice_mb=0.02)
+
+    def local(step, in_arena):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        grads = [torch.randn(p.shape, generator=g) for p in params]
+        if in_arena:   # views of one buffer, 64-float aligned like spunet_native._Arena (gaps = garbage)
+            sizes = [(p.numel() + 63) // 64 * 64 for p in params[:-2]]
+            arena = torch.full((sum(sizes),), float("nan"))
+            off = 0
+            for p, gr, n in zip(params[:-2], grads, sizes):
+                view = arena[off:off + p.numel()].view_as(p)
+                view.copy_(gr)
+                p.grad = view
+                off += n
+            for p, gr in zip(params[-2:], grads[-2:]):   # the last layer: ordinary tensors
+                p.grad = gr.clone()
+        else:
+            for p, gr in zip(params, grads):
+                p.grad = gr.clone()
+        return grads
+
+    ok, modes = True, [True, True, False, rank == 0, True]
+    for step, in_arena in enumerate(modes):
+        grads = local(step, in_arena)
+        want = []
+        for gr in grads:
+            t = gr.clone()
+            dist.all_reduce(t)
+            want.append(t / world)
+        sync.sync()
+        ok = ok and all(torch.allclose(p.grad, w, atol=1e-6) for p, w in zip(params, want))
+        ok = ok and all(torch.isfinite(p.grad).all() for p in params)
+    torch.save(dict(rank=rank, ok=bool(ok), blocks=len(sync._blocks),
+                    block_members=sum(len(m) for _, _, m in sync._blocks)),
+               os.path.join(out_dir, f"arena{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def trainer_main(cfg):
     """main_func for engines.launch(): two optimisation steps of the hook-driven Trainer."""
     from oracle import cpu_backend

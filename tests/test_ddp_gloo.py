@@ -33,6 +33,19 @@ def test_ddp_gradients_are_rank_means(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_flat_grad_sync_moves_arena_gradients_as_blocks(tmp_path):
+    """Gradients handed back as views of one arena (the native sparse executor's parameter-gradient
+    arena) travel through FlatGradSync in one copy each way; the result is the rank mean in every
+    mix of arena / ordinary gradients across steps and ranks."""
+    world = 2
+    mp.spawn(ddp_worker.arena_sync_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f"arena{r}.pt")
+        assert res["ok"], res
+        assert res["blocks"] == 1 and res["block_members"] == 60, res
+
+
 def test_trainer_two_ranks_via_launch(tmp_path):
     """engines.launch spawns one process per 'GPU', DistributedSampler shards the scenes, hooks
     log and checkpoint on rank 0."""

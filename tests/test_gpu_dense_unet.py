@@ -59,6 +59,8 @@ def test_fused_dense_unet_equals_the_modular_route_bitwise(device, monkeypatch, 
             # a bias in front of a BatchNorm has an exactly-zero true gradient: what is compared is the
             # rounding noise of column sums whose atomics add in a different order on every run
             assert (got[2][k] - want[2][k]).abs().max() < 2e-4, k
+        elif k.startswith("final_conv"):   # the 1x1x1 conv behind the node: a GEMM with atomics
+            assert torch.allclose(got[2][k], want[2][k], rtol=1e-4, atol=1e-4 * float(want[2][k].abs().max())), k
         else:
             assert torch.equal(got[2][k], want[2][k]), k
     for k in want[3]:
@@ -96,5 +98,8 @@ def test_fused_dense_unet_vs_stock_modules_float64(device):
     got = dict(net.named_parameters())
     for name, p in ref.named_parameters():
         if p.grad is None:
+            continue
+        if name.endswith("upsample.bias"):   # in front of a BatchNorm: the true gradient is zero
+            assert got[name].grad.abs().max() < 1e-3 and p.grad.abs().max() < 1e-9, name
             continue
         assert rel(got[name].grad, p.grad) < 2e-4, name

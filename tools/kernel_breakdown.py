@@ -12,6 +12,8 @@ RULES = (  # first match wins
     ("sparse conv weight gradient (partials + ordered reduce)", ("spconv_wgrad", "wgrad_reduce")),
     ("ordered row reduce (+ fused BN statistics)", ("row_reduce",)),
     ("weight packing (16-bit)", ("pack_weights",)),
+    ("dense U-Net convs, hand-written (csrc/dense_conv.hip)", ("dconv",)),
+    ("device GridSample (csrc/voxelize.hip)", ("voxel_",)),
     ("sparse conv forward / grad-input", ("spconv_",)),
     ("tall / skinny GEMMs (heads, 1x1x1 conv)", ("tall_gemm", "skinny_gemm")),
     ("dense U-Net convs + BatchNorm (MIOpen / CK / hipBLASLt)", ("ck::", "_ZN2ck", "Cijk", "MIOpen", "miopen")),
