@@ -300,11 +300,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 #pragma unroll
       for (int u = 0; u < NB; ++u) w_nxt[u] = load_w(u, kk);
     }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      // all NB fragments of this reduction step first, then the MFMAs ROUND-ROBIN over the NB
-      // accumulators: consecutive MFMAs of a wave never wait for each other's result
-      float4 b[NB];
+    // the NB weight fragments of reduction step s + 1 are read from LDS while the 4 * NB MFMAs of step
+    // s run (ping-pong sets, reads interleaved with the MFMAs); the MFMAs go ROUND-ROBIN over the NB
+    // accumulators: consecutive MFMAs of a wave never wait for each other's result
+    auto read_b = [&](int s, float4 (&b)[NB]) __attribute__((always_inline)) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         if (!TRANS) {
@@ -314,19 +313,33 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
           b[nb] = make_float4(col[0], col[LDT], col[2 * LDT], col[3 * LDT]);
         }
       }
+    };
+    __builtin_amdgcn_sched_barrier(0);   // (the loads of slab t + 1 stay in front of the MFMAs)
+    float4 bb[2][NB];
+    read_b(0, bb[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < 4) read_b(s + 1, bb[cur ^ 1]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, b[nb].x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].x, bb[cur][nb].x, acc[nb], 0, 0, 0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, b[nb].y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].y, bb[cur][nb].y, acc[nb], 0, 0, 0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, b[nb].z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].z, bb[cur][nb].z, acc[nb], 0, 0, 0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, b[nb].w, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s].w, bb[cur][nb].w, acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4 * NB; ++q) {   // issue order: one MFMA, one LDS read of the next step
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
 #pragma unroll
       for (int u = 0; u < NB; ++u) store_w(buf ^ 1, u, w_nxt[u]);
@@ -439,20 +452,23 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float4 ra[UA], rb[UB];
-  auto load_step = [&](int s) {
+  // (all row indices first, then all row loads: read one by one in front of its load, every index
+  // cost an LDS round trip of its own - eight dependent ones per step, round 4)
+  auto load_step = [&](int s) __attribute__((always_inline)) {
+    int oo[UA], ii[UB];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) oo[u] = s_out[s * kStep + (tid + 256 * u) / (TN / 4)];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) ii[u] = s_in[s * kStep + (tid + 256 * u) / (TC / 4)];
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
-      const int q = tid + 256 * u;
-      const int row = q / (TN / 4), col = (q % (TN / 4)) * 4;
-      const int o = s_out[s * kStep + row];
-      ra[u] = ld4(dY + (int64_t)max(o, 0) * c_out + n0 + col, o >= 0 && n0 + col < c_out);
+      const int col = ((tid + 256 * u) % (TN / 4)) * 4;
+      ra[u] = ld4(dY + (int64_t)max(oo[u], 0) * c_out + n0 + col, oo[u] >= 0 && n0 + col < c_out);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int q = tid + 256 * u;
-      const int row = q / (TC / 4), col = (q % (TC / 4)) * 4;
-      const int r_in = s_in[s * kStep + row];
-      rb[u] = ld4(X + (int64_t)max(r_in, 0) * c_in + c0 + col, r_in >= 0 && c0 + col < c_in);
+      const int col = ((tid + 256 * u) % (TC / 4)) * 4;
+      rb[u] = ld4(X + (int64_t)max(ii[u], 0) * c_in + c0 + col, ii[u] >= 0 && c0 + col < c_in);
     }
   };
   auto store_step = [&](int buf) {
@@ -476,18 +492,37 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     const int buf = s & 1;
     const bool more = (s + 1) < nsteps;
     if (more) load_step(s + 1);
+    __builtin_amdgcn_sched_barrier(0);   // (the row loads stay in front of the MFMAs: see dense_conv.hip)
     const float* A = &sA[buf][wn * 64 + i];
     const float* B = &sB[buf][wc * 64 + i];
-#pragma unroll
-    for (int kk = wk; kk < kStep / 2; kk += WK) {
-      const int pr = 2 * kk + h;
-      const float a0 = A[pr * TN], a1 = A[pr * TN + 32];
-      const float b0 = B[pr * TC], b1 = B[pr * TC + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    // operands of pair couple kk + WK are read from LDS while the four MFMAs of couple kk run
+    // (ping-pong sets; before, every group of four MFMAs waited for its own four LDS reads)
+    constexpr int NKK = (kStep / 2 + WK - 1) / WK;
+    float fa[2][2], fb[2][2];
+    {
+      const int pr = 2 * wk + h;
+      fa[0][0] = A[pr * TN], fa[0][1] = A[pr * TN + 32];
+      fb[0][0] = B[pr * TC], fb[0][1] = B[pr * TC + 32];
     }
+#pragma unroll
+    for (int j = 0; j < NKK; ++j) {
+      const int cur = j & 1, nxt = cur ^ 1;
+      if (j + 1 < NKK) {
+        const int pr = 2 * (wk + (j + 1) * WK) + h;
+        fa[nxt][0] = A[pr * TN], fa[nxt][1] = A[pr * TN + 32];
+        fb[nxt][0] = B[pr * TC], fb[nxt][1] = B[pr * TC + 32];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // issue order: one MFMA, one of the next couple's reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_step(buf ^ 1);
     __syncthreads();
   }
