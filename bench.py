@@ -37,7 +37,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-PMC_FILE = "profiles/r03_pmc_fetch_write_per_kernel.json"
+PMC_FILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 
 
 def kernel_source_hash():
@@ -251,6 +251,7 @@ class KernelTimer:
         self.records = {}   # family -> list of (start, end, flops, bytes)
         self._orig, self._orig_c, self._handle = {}, {}, None
         self.l2_bytes = {}
+        self.survey = {}
         self.peaks = {}     # family -> dense MFMA peak of its operand type (TFLOP/s)
         self._depth = 0     # > 0 inside a wrapped call: nested wrapped calls are not recorded twice
         self._excl = None   # event pairs of the zero-fill launches inside the call being timed
@@ -485,6 +486,11 @@ class KernelTimer:
             # bytes THIS kernel has to move: every source row and the weights once, the pair
             # list, and one product row per pair written (the output rows of SURVEY 8d's formula
             # are written by stage 2, which is priced separately below)
+            # SURVEY 8(d)'s bytes of the whole conv (each feature row in once, each output row out
+            # once, weights once, the pair list): what `traffic` is ALSO reported against
+            timer.survey[fam] = timer.survey.get(fam, 0.0) + (
+                4.0 * (c["n_src"] * c["c_in"] + c["n_rows"] * c["c_out"]
+                       + c["K"] * c["c_in"] * c["c_out"]) + 8.0 * c["p"])
             return (2.0 * c["p"] * c["c_in"] * c["c_out"],
                     4.0 * (c["n_src"] * c["c_in"] + c["p"] * c["c_out"]
                            + c["K"] * c["c_in"] * c["c_out"]) + 8.0 * c["p"],
@@ -625,6 +631,7 @@ class KernelTimer:
     def reset(self):
         self.records = {}
         self.l2_bytes = {}
+        self.survey = {}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -642,6 +649,8 @@ class KernelTimer:
                             mfma_peak_tflops=self.peaks.get(fam, F32_MFMA_PEAK_TFLOPS)))
             out[-1]["frac_of_mfma_peak"] = out[-1]["tflops"] / out[-1]["mfma_peak_tflops"]
             out[-1]["frac_of_hbm_peak"] = out[-1]["alg_gbs"] / HBM_PEAK_GBS
+            if fam in getattr(self, "survey", {}):
+                out[-1]["alg_bytes_survey_per_launch"] = self.survey[fam] / max(len(recs), 1)
             if fam in self.l2_bytes:
                 out[-1]["l2_gather_gbs"] = self.l2_bytes[fam] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 out[-1]["frac_of_f32_mfma_peak"] = out[-1]["tflops"] / F32_MFMA_PEAK_TFLOPS
@@ -1009,6 +1018,11 @@ def main():
                                                       "the PMC passes; algorithmic bytes per launch = "
                                                       "alg_bytes_per_launch",
                                       "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                                      "alg_bytes_survey": dom.get("alg_bytes_survey_per_launch"),
+                                      "alg_bytes_survey_note": "SURVEY 8(d)'s bytes of the conv per launch: "
+                                      "4(N_in C_in + N_out C_out + K C_in C_out) + 8P; alg_bytes_per_launch "
+                                      "adds the product rows this two-stage form writes (the ordered row reduce "
+                                      "that reads them back is its own entry in `kernels`)",
                                       "alg_flops_per_launch": dom["alg_flops_per_launch"],
                                       "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
             else:
