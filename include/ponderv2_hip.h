@@ -387,9 +387,12 @@ int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, i
                               int C, float* grad_x, pv2_stream_t stream);
 /* The same with the pooled tensor's OTHER gradient added in: grad_x = addend + unpool(grad_y).  In the
  * U-Net an encoder level's output feeds both the next level's pooling and a decoder level's skip sum
- * (unet3d.py:401-411); autograd would add the two gradients in a separate pass.  addend [as grad_x] or NULL. */
-int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend, int B,
-                                  int Z, int Y, int X, int C, float* grad_x, pv2_stream_t stream);
+ * (unet3d.py:401-411); autograd would add the two gradients in a separate pass.  addend [as grad_x] or NULL.
+ * relu_mask_src [as grad_x] or NULL: the pooled tensor itself when it is a ReLU's output - the sum is
+ * zeroed where it was <= 0 (the ReLU backward of the level below, done here instead of by its consumers). */
+int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend,
+                                  const float* relu_mask_src, int B, int Z, int Y, int X, int C,
+                                  float* grad_x, pv2_stream_t stream);
 
 /* Batched inverse of `batch` row-major n x n matrices, n <= 4 (one launch; Gauss-Jordan with partial
  * pivoting in double precision, result rounded to fp32): the camera / unit-cube transforms of the
@@ -818,7 +821,8 @@ int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid
  *   (bias / addend only);  mode 2: strided conv k3 s2 p1, out = in / 2 (even sizes): mode 1's grad-input.
  *   in_scale / in_shift [c_in] or NULL: the BatchNorm3d in front of the conv (zero padding AFTER it);
  *   in_mask_src [as x] or NULL: x is zeroed where in_mask_src <= 0 (ReLU backward); bias [c_out] or
- *   NULL; addend [as out] or NULL (the decoder's skip features, unet3d.py:401-411).
+ *   NULL; addend [as out] or NULL (the decoder's skip features, unet3d.py:401-411); out_mask_src [as out]
+ *   or NULL: the result is zeroed where out_mask_src <= 0 (modes 0 / 2: a gradient about to pass a ReLU).
  * pv2_dconv3_backward_weight: dw[n*s_n + c*s_c + kz*s_z + ky*s_y + kx*s_x] = sum over cells of
  *   mask(gy)[cell_g][n] * (x * in_scale + in_shift)[cell_x][c]; mode 0 (conv k3 s1 p1: x the conv
  *   input [b,z,y,xx,c_x], gy [b,z,y,xx,c_g]) or mode 1 (transposed: x the coarse input, gy
@@ -831,7 +835,7 @@ int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out,
 int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,
                        const float* in_mask_src, const float* bias, const float* addend, int relu,
-                       float* out, pv2_stream_t stream);
+                       const float* out_mask_src, float* out, pv2_stream_t stream);
 int64_t pv2_dconv3_wgrad_partial_floats(int b, int z, int y, int xx, int c_x, int c_g, int mode);
 int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int c_x,
                                const float* in_scale, const float* in_shift, const float* gy,

@@ -52,7 +52,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -167,7 +167,7 @@ SIGNATURES = {
         + [_P] * 8 + [_P]),
     "pv2_maxpool3d_cl_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pv2_maxpool3d_cl_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "pv2_maxpool3d_cl_backward_add": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pv2_maxpool3d_cl_backward_add": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pv2_small_inverse": (c_int, [_P, c_int64, c_int, _P, _P]),
     "pv2_gather_rows": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "pv2_scatter_add": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
@@ -194,7 +194,7 @@ SIGNATURES["pv2_trilinear_backward_backward_16"] = (
 SIGNATURES["pv2_dconv3_packed_floats"] = (c_int64, [c_int, c_int])
 SIGNATURES["pv2_dconv3_pack_weights"] = (c_int, [_P, c_int, c_int] + [c_int64] * 5 + [c_int, _P, _P])
 SIGNATURES["pv2_dconv3_forward"] = (
-    c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P])
+    c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P])
 SIGNATURES["pv2_dconv3_wgrad_partial_floats"] = (c_int64, [c_int] * 7)
 SIGNATURES["pv2_dconv3_backward_weight"] = (
     c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P]

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void dconv_kernel(
     int n_groups, int tiles_per_wg, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* __restrict__ mask_src,
     const float* __restrict__ bias, const float* __restrict__ addend, int relu,
-    float* __restrict__ Y) {
+    const float* __restrict__ out_mask_src, float* __restrict__ Y) {
   constexpr int S = CK / 8, LDR = CK + 4, QPR = CK / 4;
   extern __shared__ __attribute__((aligned(16))) float sX[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -400,6 +400,9 @@ __global__ __launch_bounds__(256, 2) void dconv_kernel(
             if (relu) {
               v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
             }
+            // the result is a gradient that next passes a ReLU backwards: masked here, once, instead
+            // of by each of its two consumers while they stage it (grad-input and grad-weight)
+            if (out_mask_src != nullptr) keep_positive(v, ld4g(out_mask_src + off));
             *reinterpret_cast<float4*>(Y + off) = v;
           }
           __builtin_amdgcn_wave_barrier();
@@ -854,7 +857,7 @@ int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out,
 int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,
                        const float* in_mask_src, const float* bias, const float* addend, int relu,
-                       float* out, pv2_stream_t stream) {
+                       const float* out_mask_src, float* out, pv2_stream_t stream) {
   PV2_REQUIRE(x != nullptr && packed_w != nullptr && out != nullptr, "dconv3_forward: null pointer");
   PV2_REQUIRE(mode >= 0 && mode <= 2, "dconv3_forward: mode must be 0, 1 or 2");
   PV2_REQUIRE(c_in % 16 == 0 && c_out % 32 == 0 && c_in > 0 && c_out > 0,
@@ -863,7 +866,7 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   PV2_REQUIRE(b > 0 && z > 0 && y > 0 && xx > 0, "dconv3_forward: empty grid");
   if (mode == 2) PV2_REQUIRE(z % 2 == 0 && y % 2 == 0 && xx % 2 == 0, "dconv3_forward: mode 2 needs even input sizes");
   if (mode == 1)
-    PV2_REQUIRE(in_scale == nullptr && in_mask_src == nullptr && relu == 0,
+    PV2_REQUIRE(in_scale == nullptr && in_mask_src == nullptr && relu == 0 && out_mask_src == nullptr,
                 "dconv3_forward: mode 1 takes bias / addend only");
   hipStream_t s = (hipStream_t)stream;
   DGeom g;
@@ -934,7 +937,7 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     if (int e = set_lds(dconv_kernel<NB_, MT_, CK_, PFN_, MASKED_>, lds)) return e;                     \
     hipLaunchKernelGGL((dconv_kernel<NB_, MT_, CK_, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g,     \
                        c_in, packed_w, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias,     \
-                       addend, relu, out);                                                              \
+                       addend, relu, out_mask_src, out);                                                \
   } while (0)
 #define PV2_DCONV_MASK(NB_, MT_, CK_, PFN_)               \
   do {                                                    \

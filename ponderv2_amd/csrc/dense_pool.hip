@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(
 // one thread per 4 channels of one INPUT cell
 __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(
     const float4* __restrict__ gy, const uint32_t* __restrict__ idx, int B, int Z, int Y, int X,
-    int c4, const float4* __restrict__ addend, float4* __restrict__ gx) {
+    int c4, const float4* __restrict__ addend, const float4* __restrict__ mask_src,
+    float4* __restrict__ gx) {
   const int Zo = Z >> 1, Yo = Y >> 1, Xo = X >> 1;
   const int64_t total = (int64_t)B * Z * Y * X * c4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -79,6 +80,13 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(
       if (((pos >> 16) & 0xffu) == w) g.z += v.z;
       if ((pos >> 24) == w) g.w += v.w;
     }
+    if (mask_src != nullptr) {   // the pooled tensor was a ReLU's output: its gradient passes where it was > 0
+      const float4 m = mask_src[e];
+      if (!(m.x > 0.f)) g.x = 0.f;
+      if (!(m.y > 0.f)) g.y = 0.f;
+      if (!(m.z > 0.f)) g.z = 0.f;
+      if (!(m.w > 0.f)) g.w = 0.f;
+    }
     gx[e] = g;
   }
 }
@@ -104,18 +112,19 @@ int pv2_maxpool3d_cl_backward(const float* grad_y, const uint32_t* idx, int B, i
   const int64_t total = (int64_t)B * Z * Y * X * (C / 4);
   hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(pv2::grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float4*)grad_y, idx, B, Z, Y, X, C / 4,
-                     (const float4*)nullptr, (float4*)grad_x);
+                     (const float4*)nullptr, (const float4*)nullptr, (float4*)grad_x);
   return pv2::check_launch("maxpool3d_cl_backward");
 }
 
-int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend, int B,
-                                  int Z, int Y, int X, int C, float* grad_x, pv2_stream_t stream) {
+int pv2_maxpool3d_cl_backward_add(const float* grad_y, const uint32_t* idx, const float* addend,
+                                  const float* relu_mask_src, int B, int Z, int Y, int X, int C,
+                                  float* grad_x, pv2_stream_t stream) {
   PV2_REQUIRE(B >= 1 && Z >= 2 && Y >= 2 && X >= 2 && C >= 4 && (C % 4) == 0,
               "pv2_maxpool3d_cl_backward_add: needs C % 4 == 0 and at least one 2x2x2 window");
   const int64_t total = (int64_t)B * Z * Y * X * (C / 4);
   hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(pv2::grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float4*)grad_y, idx, B, Z, Y, X, C / 4,
-                     (const float4*)addend, (float4*)grad_x);
+                     (const float4*)addend, (const float4*)relu_mask_src, (float4*)grad_x);
   return pv2::check_launch("maxpool3d_cl_backward_add");
 }
 

@@ -57,7 +57,7 @@ def pack_weights(weight, out_dim, flip):
 
 
 def conv3_forward(x, packed, c_out, mode=0, in_scale=None, in_shift=None, mask_src=None, bias=None,
-                  addend=None, relu=False):
+                  addend=None, relu=False, out_mask_src=None):
     """``[relu](conv(mask(x * in_scale + in_shift)) + bias + addend)``; mode 0: k3 s1 p1, 1: transposed
     k3 s2 p1 (2x), 2: strided k3 s2 p1 (1/2)."""
     _require_device(x, packed)
@@ -78,7 +78,8 @@ def conv3_forward(x, packed, c_out, mode=0, in_scale=None, in_shift=None, mask_s
         assert addend.shape == out.shape
     _lib.check(_lib.lib().pv2_dconv3_forward(
         _ptr(x), b, z, y, xx, c_in, _ptr(packed), c_out, mode, _ptr(in_scale), _ptr(in_shift),
-        _ptr(mask_src), _ptr(bias), _ptr(addend), int(relu), _ptr(out), _stream(x)),
+        _ptr(mask_src), _ptr(bias), _ptr(addend), int(relu),
+        _ptr(None if out_mask_src is None else _cl(out_mask_src)), _ptr(out), _stream(x)),
         "pv2_dconv3_forward")
     return out
 

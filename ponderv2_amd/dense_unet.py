@@ -99,7 +99,7 @@ def _pack(L, st, w, out_dim, flip):
 
 
 def _conv(L, st, x, packed, c_out, mode, scale=None, shift=None, mask=None, bias=None, addend=None,
-          relu=False):
+          relu=False, out_mask=None):
     b, c_in, z, y, xx = x.shape
     if mode == 0:
         out = _vol(b, c_out, z, y, xx, x.device)
@@ -111,7 +111,8 @@ def _conv(L, st, x, packed, c_out, mode, scale=None, shift=None, mask=None, bias
                                     shift, None if mask is None else mask.data_ptr(),
                                     None if bias is None else bias.data_ptr(),
                                     None if addend is None else addend.data_ptr(), int(relu),
-                                    out.data_ptr(), st), "pv2_dconv3_forward")
+                                    None if out_mask is None else out_mask.data_ptr(), out.data_ptr(), st),
+               "pv2_dconv3_forward")
     return out
 
 
@@ -193,12 +194,15 @@ class _DenseUNet(torch.autograd.Function):
         # (same strides as the parameter - the conv weights are channels_last_3d -, like empty_like)
         pviews = [arena[o:o + p.numel()].as_strided(p.shape, p.stride()) for o, p in zip(offs, params)]
 
-        def level_backward(g, x, stats, y, bn_w, w, slot):
-            """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients."""
+        def level_backward(g, x, stats, y, bn_w, w, slot, masked):
+            """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients.
+            ``masked``: ``g`` already passed the ReLU backwards (its producer zeroed it where y <= 0);
+            otherwise both consumers apply the mask while they stage it."""
             c = x.shape[1]
             base = stats.data_ptr()
-            gxn = _conv(L, st, g, _pack(L, st, w, 1, True), c, 0, mask=y)
-            wjobs.append((0, x, base + 8 * c, base + 12 * c, g, y, w, slot))
+            m = None if masked else y
+            gxn = _conv(L, st, g, _pack(L, st, w, 1, True), c, 0, mask=m)
+            wjobs.append((0, x, base + 8 * c, base + 12 * c, g, m, w, slot))
             b, _, z, yy, xx = x.shape
             n = b * z * yy * xx
             gsum = torch.empty(2 * c, dtype=torch.float32, device=dev)
@@ -213,25 +217,31 @@ class _DenseUNet(torch.autograd.Function):
             s, stats, y = dec[j]
             up_w, up_b, bn_w, bn_b, w = dec_p[j]
             k = 3 * n_enc + 5 * j
-            gs, gsum = level_backward(g, s, stats, y, bn_w, w, k + 4)
+            # (the node's incoming gradient is the only one that arrives unmasked)
+            gs, gsum = level_backward(g, s, stats, y, bn_w, w, k + 4, masked=j != n_dec - 1)
             c = s.shape[1]
             grads[k + 2], grads[k + 3] = pviews[k + 2].copy_(gsum[c:]), pviews[k + 3].copy_(gsum[:c])
             gskip[j] = gs
             x_in = enc[n_enc - 1][3] if j == 0 else dec[j - 1][2]
             wjobs.append((1, x_in, None, None, gs, None, up_w, k))
             wjobs.append((2, None, None, None, gs, None, up_b, k + 1))
-            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False), up_w.shape[0], 2)
+            # grad-input of the transposed conv = the gradient of x_in, a ReLU's output (the level
+            # below): masked in this kernel's epilogue
+            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False), up_w.shape[0], 2, out_mask=x_in)
         for i in reversed(range(n_enc)):
             p, idx, stats, y = enc[i]
             bn_w, bn_b, w = enc_p[i]
-            gp, gsum = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2)
+            gp, gsum = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2, masked=True)
             c = p.shape[1]
             grads[3 * i], grads[3 * i + 1] = pviews[3 * i].copy_(gsum[c:]), pviews[3 * i + 1].copy_(gsum[:c])
             b, _, z, yy, xx = p.shape
             add = gskip[n_enc - 1 - i]      # the pooled tensor is also that decoder level's skip
             g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
-            _lib.check(L.pv2_maxpool3d_cl_backward_add(gp.data_ptr(), idx.data_ptr(), add.data_ptr(), b, 2 * z,
-                                                       2 * yy, 2 * xx, c, g.data_ptr(), st),
+            # the pooled tensor: the previous encoder level's ReLU output (mask its gradient here), or
+            # the node's input x0 (whatever produced it owns its own backward)
+            below = enc[i - 1][3].data_ptr() if i > 0 else None
+            _lib.check(L.pv2_maxpool3d_cl_backward_add(gp.data_ptr(), idx.data_ptr(), add.data_ptr(), below, b,
+                                                       2 * z, 2 * yy, 2 * xx, c, g.data_ptr(), st),
                        "pv2_maxpool3d_cl_backward_add")
 
         def weight_gradients():
