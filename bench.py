@@ -850,20 +850,18 @@ def main():
     lookahead = hasattr(raw_model, "prefetch") and not args.no_prefetch
 
     def stage(i):
-        if args.raw_points:
-            # the device half of the input pipeline, inside the timed region: GridSample of the raw
-            # points (same voxels and order as the host transform, tests/test_gpu_voxelize.py), on the
-            # input stream - its one device -> host read must not wait for the previous step
-            from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample, input_stream
+        # on the input stream, as engines/train.py stages a loader batch: the batch's own short work
+        # (here a clone; with --raw-points the device half of the input pipeline: GridSample of the raw
+        # points, same voxels and order as the host transform, tests/test_gpu_voxelize.py) and the
+        # launch of its sparse-conv geometry must not queue behind the step the host has enqueued
+        from ponderv2_amd.ponder.datasets.voxelize import device_grid_sample, input_stream
 
-            with input_stream(device) as pipe:
-                b = clone_batch(batches[i % len(batches)])
-                if "grid_coord" not in b:
-                    b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
-                b = pipe.adopt(b)
-        else:
+        with input_stream(device) as pipe:
             b = clone_batch(batches[i % len(batches)])
-        return raw_model.prefetch(b) if lookahead else b
+            if args.raw_points and "grid_coord" not in b:
+                b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
+            b = pipe.adopt(b)
+            return raw_model.prefetch(b) if lookahead else b
 
     staged = [stage(0)]
 

@@ -490,7 +490,11 @@ def prefetch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int =
     dev = indices.device
     side = _GEOMETRY_STREAMS.get(dev.index)
     if side is None:
-        side = _GEOMETRY_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        # HIGH priority by default: ~190 tiny dependent kernels that otherwise wait for a gap between
+        # the training stream's kernels, one gap each - the tables of the next batch then arrive
+        # 5-6 ms into its own step and the host stalls on their counts (round 4, tools/profile_host.py)
+        prio = int(os.environ.get("PV2_GEOMETRY_PRIORITY", "-1"))
+        side = _GEOMETRY_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=prio)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         indices.record_stream(side)

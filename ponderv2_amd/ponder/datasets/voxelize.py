@@ -5,6 +5,8 @@ hash functions :1180-1213).  Integer work: the 64-bit hashes wrap mod 2^64 exact
 uint64 arithmetic does in the reference, and the same ``np.argsort`` / ``np.random.randint`` calls
 are made in the same order so identical seeds pick identical representatives.
 """
+import os
+
 import numpy as np
 
 _FNV_OFFSET = np.uint64(14695981039346656037)
@@ -200,7 +202,9 @@ class input_stream:
         if self.on:
             key = self.device.index if self.device.index is not None else torch.cuda.current_device()
             if key not in _INPUT_STREAMS:
-                _INPUT_STREAMS[key] = torch.cuda.Stream(device=self.device)
+                # (high priority: short kernels whose result the host waits for)
+                _INPUT_STREAMS[key] = torch.cuda.Stream(
+                    device=self.device, priority=int(os.environ.get("PV2_INPUT_PRIORITY", "-1")))
             self.side = _INPUT_STREAMS[key]
 
     def __enter__(self):

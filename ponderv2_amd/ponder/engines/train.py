@@ -187,23 +187,26 @@ class Trainer(TrainerBase):
     def stage(self, batch):
         """A loader batch -> device-resident model input: the copy, the optional device-side
         GridSample, and the launch of its sparse-conv geometry on the side stream."""
-        if self.cfg.get("device_voxelize") and self.device.type == "cuda":
-            # GridSample on the device: the loader streamed raw points (SURVEY 8(f) F3); the voxel
-            # set and its order equal the host transform's (datasets/voxelize.py).  Upload and
-            # transform ride the input stream: the transform's read of the voxel count then waits
-            # for this batch's own work only, not for the step the trainer has queued
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        if self.device.type == "cuda":
+            # Upload, the optional device-side GridSample (the loader streamed raw points, SURVEY 8(f)
+            # F3; same voxel set and order as the host transform, datasets/voxelize.py) and the
+            # launch of the sparse-conv geometry all ride the input stream: the transform's read of
+            # the voxel count and the geometry's tables then wait for this batch's own work only,
+            # not for the step the trainer has queued on the training stream
             with input_stream(self.device) as pipe:
                 batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
                          for k, v in batch.items()}
-                batch = pipe.adopt(device_grid_sample(batch, **self.cfg.device_voxelize))
+                if self.cfg.get("device_voxelize"):
+                    batch = device_grid_sample(batch, **self.cfg.device_voxelize)
+                batch = pipe.adopt(batch)
+                if hasattr(model, "prefetch"):
+                    batch = model.prefetch(batch)
         else:
             batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
                      for k, v in batch.items()}
             if self.cfg.get("device_voxelize"):
                 batch = device_grid_sample(batch, **self.cfg.device_voxelize)
-        model = self.model.module if hasattr(self.model, "module") else self.model
-        if hasattr(model, "prefetch") and self.device.type == "cuda":
-            batch = model.prefetch(batch)
         batch["_staged"] = True
         return batch
 

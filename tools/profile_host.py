@@ -21,10 +21,15 @@ else:
     opt = build_optimizer(dict(type="SGD", lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-4), model)
     batch = bench.make_batch(0, 2, 2, dev)
 PREFETCH = "--prefetch" in sys.argv
-staged = [model.prefetch(bench.clone_batch(batch)) if PREFETCH else bench.clone_batch(batch)]
+from ponderv2_amd.ponder.datasets.voxelize import input_stream
+def stage():   # as bench.py / engines/train.py: on the input stream
+    with input_stream(dev) as pipe:
+        b = pipe.adopt(bench.clone_batch(batch))
+        return model.prefetch(b) if PREFETCH else b
+staged = [stage()]
 def step():
     cur = staged.pop()
-    staged.append(model.prefetch(bench.clone_batch(batch)) if PREFETCH else bench.clone_batch(batch))
+    staged.append(stage())
     with torch.autocast("cuda", dtype=AMP or torch.bfloat16, enabled=AMP is not None):
         out = model(cur)
     opt.zero_grad(set_to_none=True); out["loss"].backward(); opt.step(); return out
@@ -46,7 +51,23 @@ def sect():
         vol = model.prepare_volume(d); t.append(time.perf_counter())
     out = model.render_func(ray, vol); t.append(time.perf_counter())
     res = model.render_loss(out, ray); t.append(time.perf_counter())
-    opt.zero_grad(set_to_none=True); res[0].backward(); t.append(time.perf_counter())
+    # backward phases: the moment the gradient reaches each section boundary (engine thread clock)
+    stamps = []
+    def mark(name, x):
+        x = getattr(x, "pre", x)
+        if torch.is_tensor(x) and x.requires_grad:
+            x.register_hook(lambda g, name=name: stamps.append((name, time.perf_counter())))
+    for k, v in out.items():
+        mark("render_out", v)
+    mark("volume", vol[0]); mark("backbone_feat", d["sparse_backbone_feat"])
+    first = next(p for n, p in model.named_parameters() if "conv_input" in n)
+    mark("first_layer_weight", first)
+    opt.zero_grad(set_to_none=True); tb = time.perf_counter(); res[0].backward(); t.append(time.perf_counter())
+    seen = {}
+    for n, ts in stamps:
+        seen.setdefault(n, []).append(ts)
+    print("   backward: " + " | ".join("%s %.2f..%.2f" % (n, 1e3 * (min(v) - tb), 1e3 * (max(v) - tb))
+                                       for n, v in seen.items()) + " | returns %.2f" % (1e3 * (t[-1] - tb)), flush=True)
     opt.step(); t.append(time.perf_counter())
     torch.cuda.synchronize(); t.append(time.perf_counter())
     names = ["backbone_fwd", "prepare_ray", "prepare_volume", "render", "losses", "backward", "opt", "drain"]
@@ -56,6 +77,54 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): step()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("10 steps: host %.2f ms/step, wall %.2f ms/step" % ((t1 - t0) * 100, (t2 - t0) * 100), flush=True)
+# the same loop with host stamps inside: which part takes longer in the steady state than from an idle
+# device (= where the host waits for the device)?
+acc = [0.0] * 5
+def step_stamped():
+    t = [time.perf_counter()]
+    cur = staged.pop()
+    staged.append(stage()); t.append(time.perf_counter())
+    with torch.autocast("cuda", dtype=AMP or torch.bfloat16, enabled=AMP is not None):
+        out = model(cur)
+    t.append(time.perf_counter())
+    opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+    out["loss"].backward(); t.append(time.perf_counter())
+    opt.step(); t.append(time.perf_counter())
+    for i in range(5):
+        acc[i] += t[i + 1] - t[i]
+for _ in range(3): step_stamped()
+torch.cuda.synchronize(); acc = [0.0] * 5; t0 = time.perf_counter()
+for _ in range(10): step_stamped()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("steady state, host ms per step: " + " | ".join("%s %.2f" % (n, a * 100) for n, a in zip(
+    ["stage+prefetch", "forward", "zero_grad", "backward", "opt"], acc))
+    + " | host %.2f wall %.2f" % ((t1 - t0) * 100, (t2 - t0) * 100), flush=True)
+# ... and the forward's sections in the steady state (wrapped methods, host clock)
+import functools
+from ponderv2_amd import spunet_native
+sec = {}
+def wrap(obj, name, label=None):
+    fn = getattr(obj, name)
+    label = label or name
+    @functools.wraps(fn)
+    def inner(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            sec[label] = sec.get(label, 0.0) + time.perf_counter() - t
+    setattr(obj, name, inner)
+for nm in ("extract_feature", "prepare_ray", "prepare_volume", "render_func", "render_loss"):
+    wrap(model, nm)
+wrap(model.backbone, "_geometry", "  backbone._geometry")
+wrap(spunet_native, "run", "  spunet_native.run")
+if hasattr(model, "_mask_blocks"):
+    wrap(model, "_mask_blocks", "  mask_blocks")
+for _ in range(3): step()
+torch.cuda.synchronize(); sec.clear()
+for _ in range(10): step()
+torch.cuda.synchronize()
+print("steady state, forward sections (host ms per step): " + " | ".join("%s %.2f" % (k.strip(), v * 100) for k, v in sec.items()), flush=True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
