@@ -448,7 +448,52 @@ int pv2_bn_backward_mixed(const void* dy, const void* x, int x_dtype, const void
 int pv2_bn_statistics(const float* x, int64_t n, int c, const float* weight, const float* bias,
                       float eps, float momentum, float* running_mean, float* running_var,
                       float* workspace, float* mean_invstd, float* affine, pv2_stream_t stream);
+/* The same for a matrix followed by `extra_zero_rows` all-zero rows that are not stored (the empty
+ * cells of the dense grid whose occupied cells are the rows of x; negative when x carries zero rows
+ * the matrix does not have - capacity-sized cell arrays), and the backward of that
+ * normalisation: total_parts [n_total_parts][c], added in order, is the column sum of the gradient over
+ * ALL rows, stored or not.  gsum [2c] = (d bias, d weight).  See pv2_cells_* below. */
+int pv2_bn_statistics_padded(const float* x, int64_t n_rows, int64_t extra_zero_rows, int c,
+                             const float* weight, const float* bias, float eps, float momentum,
+                             float* running_mean, float* running_var, float* workspace,
+                             float* mean_invstd, float* affine, pv2_stream_t stream);
+int pv2_bn_backward_padded(const float* dy, const float* x, int64_t n_rows, int64_t extra_zero_rows,
+                           int c, const float* mean_invstd, const float* weight,
+                           const float* total_parts, int n_total_parts, float* workspace,
+                           float* gsum, float* dx, pv2_stream_t stream);
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * First level of the projection network from the occupied cells (csrc/cells_level.hip).  The
+ * reference scatters the backbone features into a dense grid (ponder_indoor_base.py:177-342
+ * to_dense) and runs UNet3D's first BatchNorm3d -> Conv3d(3x3x3) -> ReLU on it (unet3d.py:292-318);
+ * here the normalised grid is  y0 + [occupied] * x * scale  and the convolution is a constant part
+ * (by border class) plus a sparse convolution of the cell rows.
+ *   pv2_cells_tap_table      table [27][cap] int32: the output row cell i (dense row lin[i], -1 =
+ *                            padding) feeds through tap k, or -1
+ *   pv2_cells_fold_weights   conv weight (any strides, in elements) -> w_okc / ws_okc [c_out][27][c_in]
+ *                            (plain / times scale) and u [27][c_out] = sum_c W[o,c,tap] * y0[c];
+ *                            affine = [scale | y0] as pv2_bn_statistics_padded writes it
+ *   pv2_cells_expand         out (B, Z, Y, X, c_out) = bias + sum of u over the taps inside the grid
+ *   pv2_cells_backward_table g (B, Z, Y, X, c_out) -> gu [27][c_out] (gradient of u) and
+ *                            gy0_parts [27][c_in] (tap-wise shares of d y0); workspace:
+ *                            pv2_cells_backward_workspace_floats
+ *   pv2_cells_dw_finish      dW[o,c,tap] = dws_okc[o,tap,c] * scale[c] + gu[tap][o] * y0[c] */
+int pv2_cells_tap_table(const int64_t* lin, int64_t cap, int z, int y, int x, int32_t* table,
+                        pv2_stream_t stream);
+int pv2_cells_fold_weights(const float* weight, int64_t s_out, int64_t s_in, int64_t s_z, int64_t s_y,
+                           int64_t s_x, int c_out, int c_in, const float* affine, float* w_okc,
+                           float* ws_okc, float* u, pv2_stream_t stream);
+int pv2_cells_expand(const float* u, const float* bias_or_null, int b, int z, int y, int x, int c_out,
+                     float* out, pv2_stream_t stream);
+int64_t pv2_cells_backward_workspace_floats(int b, int z, int y, int c_out);
+int pv2_cells_backward_table(const float* g, int b, int z, int y, int x, int c_out,
+                             const float* weight, int64_t s_out, int64_t s_in, int64_t s_z,
+                             int64_t s_y, int64_t s_x, int c_in, float* workspace, float* gu,
+                             float* gy0_parts, pv2_stream_t stream);
+int pv2_cells_dw_finish(const float* dws_okc, const float* gu, const float* affine, int c_out, int c_in,
+                        float* dweight, int64_t s_out, int64_t s_in, int64_t s_z, int64_t s_y,
+                        int64_t s_x, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Alpha compositing along rays ("ray march" of SURVEY.md section 8b).  Replaces the cumprod /

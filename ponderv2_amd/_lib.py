@@ -52,7 +52,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -201,6 +201,20 @@ SIGNATURES["pv2_dconv3_backward_weight"] = (
     + [c_int64] * 5 + [_P])
 SIGNATURES["pv2_bn_statistics"] = (
     c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P])
+SIGNATURES["pv2_bn_statistics_padded"] = (
+    c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P])
+SIGNATURES["pv2_bn_backward_padded"] = (
+    c_int, [_P, _P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, _P, _P])
+SIGNATURES["pv2_cells_tap_table"] = (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P])
+SIGNATURES["pv2_cells_fold_weights"] = (
+    c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P])
+SIGNATURES["pv2_cells_expand"] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P])
+SIGNATURES["pv2_cells_backward_workspace_floats"] = (c_int64, [c_int, c_int, c_int, c_int])
+SIGNATURES["pv2_cells_backward_table"] = (
+    c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int64,
+            c_int, _P, _P, _P, _P])
+SIGNATURES["pv2_cells_dw_finish"] = (
+    c_int, [_P, _P, _P, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P])
 SIGNATURES["pv2_voxelize_stage1"] = (
     c_int, [_P, c_int, c_int64, ctypes.c_double, c_int, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P])
 SIGNATURES["pv2_voxelize_workspace_bytes"] = (c_size_t, [c_int64])

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0, int64_t n,
     float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ out, const float* __restrict__ aff_w = nullptr,
-    const float* __restrict__ aff_b = nullptr, float* __restrict__ affine = nullptr) {
+    const float* __restrict__ aff_b = nullptr, float* __restrict__ affine = nullptr,
+    int64_t extra_zero_rows = 0, const float* __restrict__ extra_g0 = nullptr, int n_extra_g0 = 0,
+    const float* __restrict__ mean_invstd_in = nullptr) {
   __shared__ double r0[kCombineThreads];
   __shared__ double r1[kCombineThreads];
   const int tid = threadIdx.x, q = tid >> 5, cc = tid & 31;
@@ -269,6 +271,14 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     t1 += r1[k * 32 + cc];
   }
   if (MODE == 0) {
+    if (extra_zero_rows != 0) {
+      // `extra_zero_rows` all-zero rows that were never stored (the empty cells of a dense grid whose
+      // occupied cells are the rows of x): each adds (0 - shift) and (0 - shift)^2; n counts them.
+      // Negative: x carries that many zero rows MORE than the matrix has (capacity-sized cell arrays)
+      const double sft = (double)ld<EX>(x0, ch);
+      t0 -= (double)extra_zero_rows * sft;
+      t1 += (double)extra_zero_rows * sft * sft;
+    }
     const double inv_n = 1.0 / (double)n;
     const double d = t0 * inv_n;                 // mean - shift
     const double mean = (double)ld<EX>(x0, ch) + d;
@@ -288,6 +298,15 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
       running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
     }
   } else {
+    if (extra_g0 != nullptr) {
+      // the rows that were never stored (see MODE 0) all have xhat = -mean * invstd; the sum of THEIR
+      // gradients is (total - stored), with the total handed over in n_extra_g0 ordered pieces
+      double g0 = 0.0;
+      for (int k = 0; k < n_extra_g0; ++k) g0 += (double)extra_g0[(int64_t)k * c + ch];
+      const double xh = -(double)mean_invstd_in[ch] * (double)mean_invstd_in[c + ch];
+      t1 += xh * (g0 - t0);
+      t0 = g0;
+    }
     out[ch] = (float)t0;
     out[c + ch] = (float)t1;
   }
@@ -316,9 +335,10 @@ __global__ __launch_bounds__(kThreads) void bn_backward_apply_kernel(
     const typename EY::type* __restrict__ dy, const typename EX::type* __restrict__ x,
     const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd,
     const float* __restrict__ w, const float* __restrict__ gsum, int64_t n, int c,
-    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres) {
+    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres,
+    int64_t n_norm = 0) {
   const int64_t total = n * c;
-  const float inv_n = 1.0f / (float)n;
+  const float inv_n = 1.0f / (float)(n_norm > 0 ? n_norm : n);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int ch = (int)(i % c);
@@ -365,9 +385,10 @@ __global__ __launch_bounds__(kThreads) void bn_backward_apply_vec_kernel(
     const typename EY::type* __restrict__ dy, const typename EX::type* __restrict__ x,
     const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd,
     const float* __restrict__ w, const float* __restrict__ gsum, int64_t n, int c,
-    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres) {
+    typename EX::type* __restrict__ dx, typename EY::type* __restrict__ dres,
+    int64_t n_norm = 0) {
   const int64_t total = n * c;
-  const float inv_n = 1.0f / (float)n;
+  const float inv_n = 1.0f / (float)(n_norm > 0 ? n_norm : n);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += stride) {
     const int ch = (int)(i % c);
@@ -629,6 +650,77 @@ int pv2_bn_statistics(const float* x, int64_t n, int c, const float* weight, con
                      workspace, blocks, c, x, n, eps, momentum, running_mean, running_var, mean_invstd,
                      weight, bias, affine);
   return pv2::check_launch("bn_statistics");
+}
+
+// The same statistics for a matrix whose trailing `extra_zero_rows` rows are all zero and were never
+// stored: x holds the occupied cells of a mostly empty dense grid (n_rows of them), the BatchNorm3d in
+// front of the projection network's first convolution normalises over every cell
+// (ponder/models/ponder/sparse_input.py; reference ponder_indoor_base.py:177-342 builds the grid).
+int pv2_bn_statistics_padded(const float* x, int64_t n_rows, int64_t extra_zero_rows, int c,
+                             const float* weight, const float* bias, float eps, float momentum,
+                             float* running_mean, float* running_var, float* workspace,
+                             float* mean_invstd, float* affine, pv2_stream_t stream) {
+  PV2_REQUIRE(x != nullptr && workspace != nullptr && mean_invstd != nullptr && affine != nullptr,
+              "bn_statistics_padded: null pointer");
+  PV2_REQUIRE(n_rows > 0 && n_rows + extra_zero_rows > 0 && c > 0 && c <= kMaxChannels,
+              "bn_statistics_padded: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks;
+  int64_t rpb;
+  partial_geometry(n_rows, c, &blocks, &rpb);
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((col_partials_vec_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       x, (const float*)nullptr, (const float*)nullptr, nullptr, n_rows, c, rpb,
+                       workspace);
+  else
+    hipLaunchKernelGGL((col_partials_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       x, (const float*)nullptr, (const float*)nullptr, nullptr, n_rows, c, rpb,
+                       workspace);
+  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
+                     workspace, blocks, c, x, n_rows + extra_zero_rows, eps, momentum, running_mean,
+                     running_var, mean_invstd, weight, bias, affine, extra_zero_rows);
+  return pv2::check_launch("bn_statistics_padded");
+}
+
+// Backward of that normalisation.  dy / x: the stored rows; the gradient rows of the rows that were
+// never stored are known only by their column sums TOTAL over all rows (stored + not stored), handed
+// over as `n_total_parts` ordered pieces total_parts[k][c] (added in order of k).
+// gsum[0..c) = d bias, gsum[c..2c) = d weight; dx for the stored rows.
+int pv2_bn_backward_padded(const float* dy, const float* x, int64_t n_rows, int64_t extra_zero_rows,
+                           int c, const float* mean_invstd, const float* weight,
+                           const float* total_parts, int n_total_parts, float* workspace,
+                           float* gsum, float* dx, pv2_stream_t stream) {
+  PV2_REQUIRE(dy != nullptr && x != nullptr && mean_invstd != nullptr && total_parts != nullptr &&
+                  workspace != nullptr && gsum != nullptr && dx != nullptr,
+              "bn_backward_padded: null pointer");
+  PV2_REQUIRE(n_rows > 0 && n_rows + extra_zero_rows > 0 && c > 0 && c <= kMaxChannels && n_total_parts > 0,
+              "bn_backward_padded: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks;
+  int64_t rpb;
+  partial_geometry(n_rows, c, &blocks, &rpb);
+  const bool vec = (c % 8) == 0;
+  if (vec)
+    hipLaunchKernelGGL((col_partials_vec_kernel<1, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       dy, x, (const float*)nullptr, mean_invstd, n_rows, c, rpb, workspace);
+  else
+    hipLaunchKernelGGL((col_partials_kernel<1, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
+                       dy, x, (const float*)nullptr, mean_invstd, n_rows, c, rpb, workspace);
+  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
+                     workspace, blocks, c, (const float*)nullptr, n_rows, 0.f, 0.f, nullptr, nullptr,
+                     gsum, nullptr, nullptr, nullptr, (int64_t)0, total_parts, n_total_parts,
+                     mean_invstd);
+  const int64_t n_norm = n_rows + extra_zero_rows;
+  if (vec)
+    hipLaunchKernelGGL((bn_backward_apply_vec_kernel<F32, F32>),
+                       dim3(pv2::grid_for(n_rows * c / 8, kThreads)), dim3(kThreads), 0, s, dy, x,
+                       (const float*)nullptr, mean_invstd, weight, gsum, n_rows, c, dx,
+                       (float*)nullptr, n_norm);
+  else
+    hipLaunchKernelGGL((bn_backward_apply_kernel<F32, F32>), dim3(pv2::grid_for(n_rows * c, kThreads)),
+                       dim3(kThreads), 0, s, dy, x, (const float*)nullptr, mean_invstd, weight, gsum,
+                       n_rows, c, dx, (float*)nullptr, n_norm);
+  return pv2::check_launch("bn_backward_padded");
 }
 
 int pv2_col_sum(const float* x, int64_t n, int c, float* out, pv2_stream_t stream) {

@@ -31,9 +31,11 @@ ENABLED = os.environ.get("PV2_DENSE_UNET", "1") != "0"
 class Spec:
     """What the node needs besides tensors: the modules (for eps / momentum / running statistics)."""
 
-    def __init__(self, encoders, decoders):
+    def __init__(self, encoders, decoders, premask_input=False):
         self.encoders = encoders      # [(bn, conv)], levels 1..
         self.decoders = decoders      # [(convT, bn, conv)]
+        # x0 is a ReLU's output whose producer expects its gradient already multiplied by (x0 > 0)
+        self.premask_input = premask_input
 
 
 def supported(net, x0):
@@ -239,7 +241,8 @@ class _DenseUNet(torch.autograd.Function):
             g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
             # the pooled tensor: the previous encoder level's ReLU output (mask its gradient here), or
             # the node's input x0 (whatever produced it owns its own backward)
-            below = enc[i - 1][3].data_ptr() if i > 0 else None
+            below = (enc[i - 1][3].data_ptr() if i > 0
+                     else x0.data_ptr() if spec.premask_input else None)
             _lib.check(L.pv2_maxpool3d_cl_backward_add(gp.data_ptr(), idx.data_ptr(), add.data_ptr(), below, b,
                                                        2 * z, 2 * yy, 2 * xx, c, g.data_ptr(), st),
                        "pv2_maxpool3d_cl_backward_add")
@@ -281,8 +284,11 @@ class _DenseUNet(torch.autograd.Function):
         return (gx0, None) + tuple(grads)
 
 
-def forward(net, x0):
-    """encoders[1:] and decoders of ``net`` (UNet3Dv1m2) applied to the first level's output."""
+def forward(net, x0, premask_input=False):
+    """encoders[1:] and decoders of ``net`` (UNet3Dv1m2) applied to the first level's output.
+    ``premask_input``: x0 is a ReLU output and its producer takes the gradient already masked with
+    (x0 > 0) - applied for free in the epilogue of the node's last backward kernel
+    (cells_level.claim_premasked)."""
     encoders = [(e.basic_module.batchnorm, e.basic_module.conv) for e in net.encoders[1:]]
     decoders = [(d.upsampling.upsample, d.basic_module.batchnorm, d.basic_module.conv) for d in net.decoders]
     params = []
@@ -290,4 +296,4 @@ def forward(net, x0):
         params += [bn.weight, bn.bias, conv.weight]
     for up, bn, conv in decoders:
         params += [up.weight, up.bias, bn.weight, bn.bias, conv.weight]
-    return _DenseUNet.apply(x0, Spec(encoders, decoders), *params)
+    return _DenseUNet.apply(x0, Spec(encoders, decoders, premask_input), *params)

@@ -77,6 +77,11 @@ def _tap_table(cells):
     Cross-correlation: out[p] += W_k . in[p + k - 1], so cell q reaches p = q - (k - 1)."""
     zs, ys, xs = cells.dims
     lin = cells.lin
+    if lin.is_cuda and lin.dtype == torch.int64 and cells.n_rows < 2 ** 31:
+        from ponderv2_amd import cells_level
+
+        if cells_level.ENABLED:       # one launch (csrc/cells_level.hip) instead of ~35
+            return cells_level.tap_table(cells)
     x = lin % xs
     y = torch.div(lin, xs, rounding_mode="floor") % ys
     z = torch.div(lin, xs * ys, rounding_mode="floor") % zs
@@ -205,6 +210,10 @@ def conv3d_on_cells(cells, delta, weight, y0=None, bias=None, relu=False):
 def bn_conv_relu_on_cells(bn, conv, cells):
     """relu(conv(batchnorm3d(dense))) - one "bcr" level of UNet3D (unet3d.py SingleConv) - from the
     occupied cells.  Training-mode statistics run over all batch*Z*Y*X positions."""
+    from ponderv2_amd import cells_level
+
+    if cells_level.supported(bn, conv, cells):   # the same level as one autograd node on HIP kernels
+        return cells_level.bn_conv_relu(bn, conv, cells)
     x = cells.feat
     n_tot = float(cells.n_rows)
     if bn.training or not bn.track_running_stats:

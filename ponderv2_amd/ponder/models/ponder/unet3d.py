@@ -392,7 +392,8 @@ class UNet3Dv1m2(nn.Module):
         x0 = first if first is not None else self.encoders[0](x)
         if dense_unet.supported(self, x0):
             # every level behind the first as ONE autograd node over the dense kernels (dense_unet.py)
-            x = dense_unet.forward(self, x0)
+            from ponderv2_amd import cells_level
+            x = dense_unet.forward(self, x0, premask_input=cells_level.claim_premasked(x0))
         else:
             skips, x = [x0], x0
             for encoder in self.encoders[1:]:

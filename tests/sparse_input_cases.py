@@ -32,12 +32,11 @@ def dense_reference(lin, feat, B, dims, bn, conv, with_bn):
     return conv(dense)
 
 
-def run(device, dtype, with_bn, seed=0):
+def run(device, dtype, with_bn, seed=0, c_in=8, c_out=6, dims=(5, 12, 9), n_vox=220):
     from ponderv2_amd.ponder.models.ponder.sparse_input import (bn_conv_relu_on_cells,
                                                                  cells_from_voxels, conv3d_on_cells)
 
-    lin, feat, B, dims = make_case(seed)
-    c_in, c_out = feat.shape[1], 6
+    lin, feat, B, dims = make_case(seed, dims=dims, c_in=c_in, n_vox=n_vox)
     torch.manual_seed(seed + 1)
     bn_ref = nn.BatchNorm3d(c_in, eps=1e-3, momentum=0.1).double()
     conv_ref = nn.Conv3d(c_in, c_out, 3, padding=1, bias=not with_bn).double()

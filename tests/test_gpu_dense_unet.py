@@ -44,7 +44,7 @@ def test_fused_dense_unet_equals_the_modular_route_bitwise(device, monkeypatch, 
     x0 = torch.relu(torch.randn(*shape, device=device)).contiguous(memory_format=torch.channels_last_3d)
     calls = []
     orig = dense_unet.forward
-    monkeypatch.setattr(dense_unet, "forward", lambda *a: (calls.append(1), orig(*a))[1])
+    monkeypatch.setattr(dense_unet, "forward", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     out_shape = net(None, first=x0).shape
     assert calls, "the fused node is the default route"
     probe = torch.randn(out_shape, device=device)

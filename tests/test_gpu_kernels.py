@@ -514,6 +514,68 @@ def test_sparse_first_layer_equals_dense_layer_gpu(device, with_bn):
     assert max(errs.values()) < 2e-5, errs
 
 
+@pytest.mark.parametrize("c_in,c_out,dims,n_vox", [(8, 4, (5, 12, 9), 220), (96, 32, (4, 18, 37), 900),
+                                                   (16, 8, (1, 2, 33), 40), (12, 16, (3, 1, 2), 14)])
+def test_cells_level_node_equals_dense_layer(device, c_in, c_out, dims, n_vox):
+    """The first projection level as one node on the HIP kernels (cells_level.py): output, all
+    gradients and the running statistics against the dense float64 layer; grids with axes of size
+    one and two included (every border class)."""
+    import sparse_input_cases as sic
+    from ponderv2_amd import cells_level
+
+    calls = []
+    real = cells_level._CellsLevel.apply
+    cells_level._CellsLevel.apply = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        errs = sic.run(device, torch.float32, True, seed=3, c_in=c_in, c_out=c_out, dims=dims, n_vox=n_vox)
+    finally:
+        cells_level._CellsLevel.apply = real
+    assert calls, "the composite ran instead of the node"
+    assert max(errs.values()) < 3e-5, errs
+
+
+def test_cells_level_premasked_gradient_and_tap_table(device):
+    """A consumer that claims the ReLU mask hands the node a premasked gradient: same gradients as
+    when the node masks itself.  And the tap table kernel equals the torch composite."""
+    import os
+
+    import sparse_input_cases as sic
+    from ponderv2_amd import cells_level
+    from ponderv2_amd.ponder.models.ponder import sparse_input as si
+
+    lin, feat, B, dims = sic.make_case(5, dims=(4, 10, 7), c_in=16, n_vox=300)
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm3d(16, eps=1e-3).to(device).train()
+    conv = torch.nn.Conv3d(16, 8, 3, padding=1, bias=False).to(device)
+    probe = torch.randn(B, 8, *dims, device=device)
+
+    def once(premask):
+        f = feat.float().to(device).requires_grad_(True)
+        cells = si.cells_from_voxels(f, lin.to(device), B, dims)
+        vol = si.bn_conv_relu_on_cells(bn, conv, cells)
+        g = probe
+        if premask:
+            assert cells_level.claim_premasked(vol)
+            g = probe * (vol.detach() > 0)
+        for p in (bn.weight, bn.bias, conv.weight):
+            p.grad = None
+        vol.backward(g)
+        torch.cuda.synchronize()
+        return [f.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), conv.weight.grad.clone()]
+
+    for a, b in zip(once(False), once(True)):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+    cells = si.cells_from_voxels(feat.float().to(device), lin.to(device), B, dims)
+    fast = cells_level.tap_table(cells)
+    cells_level.ENABLED = False
+    try:
+        slow = si._tap_table(cells)
+    finally:
+        cells_level.ENABLED = True
+    assert torch.equal(fast, slow)
+
+
 # ------------------------------------------------------------------ compositing (raymarch.hip)
 @pytest.mark.parametrize("rays,samples", [(1, 1), (5, 64), (1030, 132), (300, 96), (17, 256)])
 def test_raymarch_weights_vs_oracle(device, rays, samples):
