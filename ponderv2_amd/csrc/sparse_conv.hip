@@ -16,10 +16,11 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "mfma_split.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using pv2::f32x16;
 
 __device__ __forceinline__ int find_offset(const int32_t* __restrict__ tile_start, int K,
                                            int tile) {
@@ -203,7 +204,13 @@ constexpr int kWPad = kKC + 4;
 // (reduction axis outermost): slabs are staged reduction-major in LDS (coalesced 16-byte reads
 // along the output-channel axis, no transposed copy of the weights in HBM) and the B fragment is
 // four 4-byte LDS reads instead of one 16-byte read.
-template <int NB, bool TRANS>
+// SPLIT: the products run on the bf16 matrix cores (mfma_split.h): every operand is cut into three
+// bf16 pieces - the gathered rows in registers, the weight slab on its way into LDS, where it lives as
+// three planes of [NT rows][32 bf16 + 16 bytes of padding] (conflict-free ds_read_b128 of the eight
+// reduction steps a lane owns) - and six v_mfma_f32_32x32x16_bf16 per 16 reduction steps and column
+// block replace sixteen fp32 MFMAs of half the length: the same sums to within fp32 rounding.
+constexpr int kRowDw = 20;   // dwords per row of a piece plane
+template <int NB, bool TRANS, bool SPLIT>
 __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     const float* __restrict__ X, int c_in, const float* __restrict__ W, int K, int c_out,
     const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
@@ -212,12 +219,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
   constexpr int NT = 32 * NB;
   constexpr int LDT = NT + 4;  // row stride of the reduction-major (TRANS) slab
   // two weight slabs; the product-row epilogue re-uses the space as four 32 x 32 staging tiles
-  constexpr int kSlabFloats = NT * kWPad;
+  constexpr int kSlabFloats = SPLIT ? 3 * NT * kRowDw : NT * kWPad;
   constexpr int kStageFloats = 32 * kWPad;
   constexpr int kLdsFloats = 2 * kSlabFloats > 4 * kStageFloats ? 2 * kSlabFloats : 4 * kStageFloats;
   __shared__ __attribute__((aligned(16))) float sBuf[kLdsFloats];
   float(*sW)[kSlabFloats] = reinterpret_cast<float(*)[kSlabFloats]>(sBuf);
-  static_assert(kKC * LDT <= NT * kWPad, "TRANS slab fits the same buffer");
+  static_assert(SPLIT || kKC * LDT <= NT * kWPad, "TRANS slab fits the same buffer");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int tile = blockIdx.x / n_groups + tile_base;
   if (tile >= skip_lo) tile += skip_len;  // the tiles of the centre offset ran in the store pass
@@ -281,6 +288,106 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
+  const int nslab = c_in / kKC;
+  if constexpr (SPLIT) {
+    unsigned* sP = reinterpret_cast<unsigned*>(sBuf);
+    // A: lane (i, h) owns reduction steps 16 st + 8 h .. + 7 of its row for st = 0, 1
+    const float* xrow2 = X + (int64_t)row_in * c_in + 8 * h;
+    // weight items.  Plain: float4 (row r0 + 32 u, steps 4 c4 .. + 3) -> two dwords per piece at
+    // [row][2 c4].  TRANS: item q = tid + 256 u < 128 NB is the step pair rr2 = q & 15 of the four output
+    // channels 4 (q >> 4) .. + 3: two float4 (steps 2 rr2 and 2 rr2 + 1), one dword per piece and channel
+    // at [channel][rr2] - lanes run along the steps, so the transposing writes spread over all banks
+    constexpr int NW = TRANS ? (NB + 1) / 2 : NB;
+    float4 wa[NW], wb[NW];
+    auto load_items = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        if (!TRANS) {
+          wa[u] = ld4(wbase + u * wstride + kk, n0 + r0 + 32 * u < c_out);
+        } else {
+          const int q = tid + 256 * u;
+          const int rr2 = q & 15, nn = n0 + 4 * (q >> 4);
+          const bool ok = q < 128 * NB && nn < c_out;
+          const float* src = W + ((int64_t)(kk + 2 * rr2) * K + k) * c_out + nn;
+          wa[u] = ld4(src, ok);
+          wb[u] = ld4(src + (int64_t)K * c_out, ok);
+        }
+      }
+    };
+    auto store_items = [&](int buf) __attribute__((always_inline)) {
+      unsigned* dst = sP + buf * kSlabFloats;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        if (!TRANS) {
+          const float x[4] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w};
+          float r1[4], r2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
+          unsigned* d = dst + (r0 + 32 * u) * kRowDw + 2 * c4;
+          *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+          *reinterpret_cast<uint2*>(d + NT * kRowDw) =
+              make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
+          *reinterpret_cast<uint2*>(d + 2 * NT * kRowDw) =
+              make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
+        } else {
+          const int q = tid + 256 * u;
+          if (q < 128 * NB) {
+            const int rr2 = q & 15, nl = 4 * (q >> 4);
+            const float xa[4] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w};
+            const float xb[4] = {wb[u].x, wb[u].y, wb[u].z, wb[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a1 = pv2::bf16_rest(xa[j]), b1 = pv2::bf16_rest(xb[j]);
+              unsigned* d = dst + (nl + j) * kRowDw + rr2;
+              d[0] = pv2::pack_hi(xa[j], xb[j]);
+              d[NT * kRowDw] = pv2::pack_hi(a1, b1);
+              d[2 * NT * kRowDw] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
+            }
+          }
+        }
+      }
+    };
+    float4 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow2 + 16 * (s >> 1) + 4 * (s & 1), pv);
+    load_items(0);
+    store_items(0);
+    __syncthreads();
+    for (int t = 0; t < nslab; ++t) {
+      const int buf = t & 1;
+      const bool more = (t + 1) < nslab;
+      if (more) {
+        const int kk = (t + 1) * kKC;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a_nxt[s] = ld4(xrow2 + kk + 16 * (s >> 1) + 4 * (s & 1), pv);
+        load_items(kk);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the loads of slab t + 1 stay in front of the MFMAs)
+      const unsigned* src = sP + buf * kSlabFloats + i * kRowDw + 4 * h;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const pv2::Split8 pa = pv2::split8(a_cur[2 * st], a_cur[2 * st + 1]);
+        pv2::bf16x8 pb[NB][3];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            pb[nb][pc] = *reinterpret_cast<const pv2::bf16x8*>(src + (pc * NT + nb * 32) * kRowDw + 8 * st);
+        // the six terms, smallest first, each ROUND-ROBIN over the NB accumulators
+#define PV2_TERM(ta, tb)                  \
+  _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = pv2::mfma_bf16(pa.p[ta], pb[nb][tb], acc[nb]);
+        PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        store_items(buf ^ 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
+      }
+      __syncthreads();
+    }
+  } else {
   float4 a_cur[4], a_nxt[4], w_nxt[NB];
 #pragma unroll
   for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow + 8 * s, pv);
@@ -288,7 +395,6 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
   for (int u = 0; u < NB; ++u) store_w(0, u, load_w(u, 0));
   __syncthreads();
 
-  const int nslab = c_in / kKC;
   for (int t = 0; t < nslab; ++t) {
     const int buf = t & 1;
     const bool more = (t + 1) < nslab;
@@ -348,6 +454,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     }
     __syncthreads();
   }
+  }   // !SPLIT
 
   if (store == 2 && (c_out & 3) == 0) {
     // product rows: the wave's 32 result rows are CONSECUTIVE rows of Y (row = pair index), so each
@@ -804,37 +911,59 @@ int launch_fwd(const float* X, int c_in, const float* W, int K, int c_out, const
   return pv2::check_launch("spconv_fwd");
 }
 
-template <int NB, bool TRANS>
-int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
-                   const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
-                   float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi,
-                   bool products = false) {
+// PV2_FP32_MFMA=1: every product on v_mfma_f32_32x32x2_f32 (the round-3 kernels) instead of the
+// bf16-piece form
+bool use_split() {
+  static const bool v = [] {
+    const char* e = getenv("PV2_FP32_MFMA");
+    return !(e != nullptr && e[0] == '1');
+  }();
+  return v;
+}
+
+template <int NB, bool TRANS, bool SPLIT>
+int launch_fwd_lds_t(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
+                     const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
+                     float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi, bool products) {
   const int n_groups = (c_out + NB * 32 - 1) / (NB * 32);
   if (n_tiles * n_groups > 0x7fffffffLL) {
     pv2::set_error("pv2_spconv_forward: grid too large");
     return PV2_E_BADARG;
   }
   if (products) {  // one result row per pair, plain stores (Y = the product-row buffer)
-    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS, SPLIT>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
                        0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0, 0x7fffffff, 0, 2);
   } else if (center_hi > center_lo) {
     // pass A: the centre offset touches every output row exactly once -> plain stores initialise
     // the output (no zero-fill, no atomics); pass B: every other offset accumulates on top.
     const int64_t nc = center_hi - center_lo;
-    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS, SPLIT>), dim3((unsigned)(nc * n_groups)), dim3(256), 0,
                        s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y,
                        (int)center_lo, 0x7fffffff, 0, 1);
     const int64_t rest = n_tiles - nc;
     if (rest > 0)
-      hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(rest * n_groups)), dim3(256),
+      hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS, SPLIT>), dim3((unsigned)(rest * n_groups)), dim3(256),
                          0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0,
                          (int)center_lo, (int)nc, 0);
   } else {
-    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
+    hipLaunchKernelGGL((spconv_fwd_lds_kernel<NB, TRANS, SPLIT>), dim3((unsigned)(n_tiles * n_groups)), dim3(256),
                        0, s, X, c_in, W, K, c_out, pi, po, ks, ts, n_groups, Y, 0,
                        0x7fffffff, 0, 0);
   }
   return pv2::check_launch("spconv_fwd_lds");
+}
+
+template <int NB, bool TRANS>
+int launch_fwd_lds(const float* X, int c_in, const float* W, int K, int c_out, const int32_t* pi,
+                   const int32_t* po, const int32_t* ks, const int32_t* ts, int64_t n_tiles,
+                   float* Y, hipStream_t s, int64_t center_lo, int64_t center_hi,
+                   bool products = false) {
+  // (TRANS stages pairs of reduction rows: c_out % 4 == 0 is required of it anyway)
+  if (use_split())
+    return launch_fwd_lds_t<NB, TRANS, true>(X, c_in, W, K, c_out, pi, po, ks, ts, n_tiles, Y, s, center_lo,
+                                             center_hi, products);
+  return launch_fwd_lds_t<NB, TRANS, false>(X, c_in, W, K, c_out, pi, po, ks, ts, n_tiles, Y, s, center_lo,
+                                            center_hi, products);
 }
 
 }  // namespace
