@@ -298,71 +298,87 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
     // channels 4 (q >> 4) .. + 3: two float4 (steps 2 rr2 and 2 rr2 + 1), one dword per piece and channel
     // at [channel][rr2] - lanes run along the steps, so the transposing writes spread over all banks
     constexpr int NW = TRANS ? (NB + 1) / 2 : NB;
-    float4 wa[NW], wb[NW];
-    auto load_items = [&](int kk) __attribute__((always_inline)) {
+    // Register sets of the slabs in flight: with the six bf16 MFMAs a 32-step slab is ~0.6 us of matrix
+    // work per workgroup - less than one trip to L2 / HBM -, so the loads run TWO slabs ahead: while slab
+    // t is multiplied, slab t + 1 has arrived (its weights go to LDS at the end of the iteration) and
+    // slab t + 2 is being fetched into the set slab t came from.
+    struct Slab {
+      float4 a[4];
+      float4 wa[NW], wb[NW];
+    };
+    Slab sl[2];
+    // (UNCONDITIONAL loads: a predicated load is a branch around it, and the s_waitcnt pass merges the
+    // two paths to vmcnt(0) - waiting for the slab just requested.  Pairs past the end read row 0,
+    // weight rows / columns past c_out are clamped to the last ones: none of it is stored.)
+    auto ldu4 = [](const float* q) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(q); };
+    const float* wrow[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      if (!TRANS) {
+        wrow[u] = W + ((int64_t)min(n0 + r0 + 32 * u, c_out - 1) * K + k) * c_in + 4 * c4;
+      } else {
+        const int q = min(tid + 256 * u, 128 * NB - 1);
+        wrow[u] = W + ((int64_t)(2 * (q & 15)) * K + k) * c_out + min(n0 + 4 * (q >> 4), c_out - 4);
+      }
+    }
+    auto load_slab = [&](Slab& d, int kk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) d.a[s] = ldu4(xrow2 + kk + 16 * (s >> 1) + 4 * (s & 1));
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
         if (!TRANS) {
-          wa[u] = ld4(wbase + u * wstride + kk, n0 + r0 + 32 * u < c_out);
+          d.wa[u] = ldu4(wrow[u] + kk);
         } else {
-          const int q = tid + 256 * u;
-          const int rr2 = q & 15, nn = n0 + 4 * (q >> 4);
-          const bool ok = q < 128 * NB && nn < c_out;
-          const float* src = W + ((int64_t)(kk + 2 * rr2) * K + k) * c_out + nn;
-          wa[u] = ld4(src, ok);
-          wb[u] = ld4(src + (int64_t)K * c_out, ok);
+          const float* src = wrow[u] + (int64_t)kk * K * c_out;
+          d.wa[u] = ldu4(src);
+          d.wb[u] = ldu4(src + (int64_t)K * c_out);
         }
       }
     };
-    auto store_items = [&](int buf) __attribute__((always_inline)) {
+    auto store_items = [&](const Slab& d, int buf) __attribute__((always_inline)) {
       unsigned* dst = sP + buf * kSlabFloats;
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
         if (!TRANS) {
-          const float x[4] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w};
+          const float x[4] = {d.wa[u].x, d.wa[u].y, d.wa[u].z, d.wa[u].w};
           float r1[4], r2[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
-          unsigned* d = dst + (r0 + 32 * u) * kRowDw + 2 * c4;
-          *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
-          *reinterpret_cast<uint2*>(d + NT * kRowDw) =
+          unsigned* o = dst + (r0 + 32 * u) * kRowDw + 2 * c4;
+          *reinterpret_cast<uint2*>(o) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+          *reinterpret_cast<uint2*>(o + NT * kRowDw) =
               make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
-          *reinterpret_cast<uint2*>(d + 2 * NT * kRowDw) =
+          *reinterpret_cast<uint2*>(o + 2 * NT * kRowDw) =
               make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
         } else {
           const int q = tid + 256 * u;
           if (q < 128 * NB) {
             const int rr2 = q & 15, nl = 4 * (q >> 4);
-            const float xa[4] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w};
-            const float xb[4] = {wb[u].x, wb[u].y, wb[u].z, wb[u].w};
+            const float xa[4] = {d.wa[u].x, d.wa[u].y, d.wa[u].z, d.wa[u].w};
+            const float xb[4] = {d.wb[u].x, d.wb[u].y, d.wb[u].z, d.wb[u].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float a1 = pv2::bf16_rest(xa[j]), b1 = pv2::bf16_rest(xb[j]);
-              unsigned* d = dst + (nl + j) * kRowDw + rr2;
-              d[0] = pv2::pack_hi(xa[j], xb[j]);
-              d[NT * kRowDw] = pv2::pack_hi(a1, b1);
-              d[2 * NT * kRowDw] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
+              unsigned* o = dst + (nl + j) * kRowDw + rr2;
+              o[0] = pv2::pack_hi(xa[j], xb[j]);
+              o[NT * kRowDw] = pv2::pack_hi(a1, b1);
+              o[2 * NT * kRowDw] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
             }
           }
         }
       }
     };
-    float4 a_cur[4], a_nxt[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a_cur[s] = ld4(xrow2 + 16 * (s >> 1) + 4 * (s & 1), pv);
-    load_items(0);
-    store_items(0);
-    __syncthreads();
-    for (int t = 0; t < nslab; ++t) {
+    float4 a_cur[4];
+    // one iteration: multiply slab t (A in a_cur, weights in LDS buffer t & 1); `nxt` holds slab t + 1,
+    // `far` (the set slab t came from) receives slab t + 2
+    // (no branch between the loads and their use: slabs past the end are clamped to the last one -
+    // a redundant load and LDS store at the tail - so that the compiler's own s_waitcnt counts the
+    // loads of slab t + 2 as still in flight when slab t + 1 is consumed; a conditional prefetch
+    // merges to vmcnt(0) at the join)
+    auto iteration = [&](int t, Slab& nxt, Slab& far) __attribute__((always_inline)) {
       const int buf = t & 1;
-      const bool more = (t + 1) < nslab;
-      if (more) {
-        const int kk = (t + 1) * kKC;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a_nxt[s] = ld4(xrow2 + kk + 16 * (s >> 1) + 4 * (s & 1), pv);
-        load_items(kk);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (the loads of slab t + 1 stay in front of the MFMAs)
+      load_slab(far, min(t + 2, nslab - 1) * kKC);
+      __builtin_amdgcn_sched_barrier(0);   // (those loads stay in front of the MFMAs)
       const unsigned* src = sP + buf * kSlabFloats + i * kRowDw + 4 * h;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -380,13 +396,23 @@ __global__ __launch_bounds__(256) void spconv_fwd_lds_kernel(
 #undef PV2_TERM
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        store_items(buf ^ 1);
+      store_items(nxt, buf ^ 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
-      }
+      for (int s = 0; s < 4; ++s) a_cur[s] = nxt.a[s];
       __syncthreads();
+    };
+    load_slab(sl[0], 0);
+    store_items(sl[0], 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_cur[s] = sl[0].a[s];
+    load_slab(sl[1], min(1, nslab - 1) * kKC);
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < nslab; t += 2) {
+      iteration(t, sl[1], sl[0]);
+      iteration(t + 1, sl[0], sl[1]);
     }
+    if (t < nslab) iteration(t, sl[1], sl[0]);
   } else {
   float4 a_cur[4], a_nxt[4], w_nxt[NB];
 #pragma unroll
