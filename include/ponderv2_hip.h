@@ -853,7 +853,9 @@ int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid
  * Encoder, :359-493 Decoder / Upsampling) - forward, grad-input, grad-weight.  Grids are fp32
  * (b, z, y, x, c): the channels_last_3d storage of a (b, c, z, y, x) tensor.
  *
- * pv2_dconv3_pack_weights: the weight in MFMA fragment order, once per optimiser step.
+ * pv2_dconv3_pack_weights: the weight in MFMA fragment order, once per optimiser step, for the
+ * pv2_dconv3_forward mode it will be used with (mode 0 runs on the bf16 matrix cores: its weights are
+ * stored as three bf16 pieces per value, csrc/mfma_split.h; pv2_dconv3_packed_floats sizes the buffer).
  *   packed[t][ck][nb][s][lane][q] = w[out*s_out + red*s_red + kz*s_z + ky*s_y + kx*s_x] with out = nb*32
  *   + (lane & 31), red = ck*16 + 8s + 4(lane >> 5) + q, (kz,ky,kx) = tap (flip ? 26 - t : t).
  *   n_out % 32 == 0 (the output channels of the launch that will use it), n_red % 16 == 0.
@@ -873,9 +875,9 @@ int pv2_trilinear_backward_backward_16(const void* g_ginput, const void* g_ggrid
  *   input [b,z,y,xx,c_x], gy [b,z,y,xx,c_g]) or mode 1 (transposed: x the coarse input, gy
  *   [b,2z,2y,2xx,c_g]).  Partial slabs in partial_ws (pv2_dconv3_wgrad_partial_floats), summed in a fixed
  *   order: bitwise repeatable.  c_x % 32 == 0, c_g % 32 == 0. */
-int64_t pv2_dconv3_packed_floats(int c_out, int c_in);
+int64_t pv2_dconv3_packed_floats(int c_out, int c_in, int mode);
 int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
-                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, float* packed,
+                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, int mode, float* packed,
                             pv2_stream_t stream);
 int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,

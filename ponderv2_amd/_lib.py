@@ -52,7 +52,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -191,8 +191,8 @@ SIGNATURES["pv2_trilinear_backward_16"] = (
 SIGNATURES["pv2_trilinear_backward_backward_16"] = (
     c_int, [_P, _P, _P, c_int, POINTER(VolumeDesc), _P, _P, POINTER(PointsDesc), _P, _P, _P,
             c_int, c_int, c_int, _P])
-SIGNATURES["pv2_dconv3_packed_floats"] = (c_int64, [c_int, c_int])
-SIGNATURES["pv2_dconv3_pack_weights"] = (c_int, [_P, c_int, c_int] + [c_int64] * 5 + [c_int, _P, _P])
+SIGNATURES["pv2_dconv3_packed_floats"] = (c_int64, [c_int, c_int, c_int])
+SIGNATURES["pv2_dconv3_pack_weights"] = (c_int, [_P, c_int, c_int] + [c_int64] * 5 + [c_int, c_int, _P, _P])
 SIGNATURES["pv2_dconv3_forward"] = (
     c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P])
 SIGNATURES["pv2_dconv3_wgrad_partial_floats"] = (c_int64, [c_int] * 7)

@@ -32,10 +32,11 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "mfma_split.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using pv2::f32x16;
 
 struct DGeom {
   int B, Zi, Yi, Xi;  // input grid (what is staged)
@@ -402,6 +403,241 @@ __global__ __launch_bounds__(256, 2) void dconv_kernel(
             }
             // the result is a gradient that next passes a ReLU backwards: masked here, once, instead
             // of by each of its two consumers while they stage it (grad-input and grad-weight)
+            if (out_mask_src != nullptr) keep_positive(v, ld4g(out_mask_src + off));
+            *reinterpret_cast<float4*>(Y + off) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    tl = ntl, ck = nck;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dconv_kernel for the conv k3 s1 p1 with the products on the bf16 matrix cores (mfma_split.h): the
+// halo box is cut into its three bf16 pieces on the way into LDS - a cell's row holds 3 x 16 bf16
+// (+ 16 bytes of padding: 28 dwords, conflict-free ds_read_b128 for 16 consecutive rows) -, the
+// weights arrive pre-cut in fragment order (dconv_pack_split_kernel), and six
+// v_mfma_f32_32x32x16_bf16 per tap, 16-channel chunk and 32 x 32 block replace eight fp32 MFMAs of
+// twice the length.  Same pipeline of items otherwise (see dconv_kernel).
+//   Wq[t][c16][nb][piece][lane] (16 bytes): lane (i, h) holds the piece of
+//   W[out = nb*32 + i][red = c16*16 + 8h .. + 7][tap t]
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowW = 28;   // dwords per cell row of the split halo tile
+
+template <int NB, int MT, int PFN, bool MASKED>
+__global__ __launch_bounds__(256, 2) void dconv_split_kernel(
+    const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
+    int n_groups, int tiles_per_wg, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ mask_src,
+    const float* __restrict__ bias, const float* __restrict__ addend, int relu,
+    const float* __restrict__ out_mask_src, float* __restrict__ Y) {
+  constexpr int CK = 16, QPR = 4;
+  extern __shared__ __attribute__((aligned(16))) float sX[];
+  unsigned* sU = reinterpret_cast<unsigned*>(sX);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int grp = blockIdx.x % n_groups;
+  const int n_tiles = g.B * g.nTZ * g.nTY * g.nTX;
+  const int tile_first = (blockIdx.x / n_groups) * tiles_per_wg;
+  const int tile_count = min(tiles_per_wg, n_tiles - tile_first);
+  const int nchunks = c_in / CK;
+  const int n_items = tile_count * nchunks;
+  const int Zi = g.Zi, Yi = g.Yi, Xi = g.Xi, HX = g.HX, HY = g.HY;
+  const int in_off = g.in_off;
+  const int nTX = g.nTX, nTY = g.nTY, nTZ = g.nTZ, eTZ = g.eTZ, TYs = g.TY, TXs = g.TX;
+  const int TXm = g.TX - 1, TYm = g.TY - 1, lTX = g.lTX, lTXY = g.lTX + g.lTY;
+  const float rHX = g.rHX, rHY = g.rHY;
+  const int total = g.HZ * HY * HX * QPR;
+  const int quad = tid & (QPR - 1);
+
+  int rowbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = (wave * MT + mt) * 32 + i;
+    const int cx = q & TXm, cy = (q >> lTX) & TYm, cz = q >> lTXY;
+    rowbase[mt] = (cz * HY + cy) * HX + cx;
+    if (cz >= eTZ) rowbase[mt] = 0;  // no such cell: any staged row, the result is dropped
+  }
+
+  f32x16 acc[MT][NB];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
+
+  const int nbtot = c_out >> 5;
+  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane;
+  const int64_t wc16 = (int64_t)nbtot * 3 * 64;       // fragments per 16-channel chunk
+  const int64_t wtap = (int64_t)nchunks * wc16;       // fragments per tap
+
+  auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % nTX;
+    tile /= nTX;
+    const int ty = tile % nTY;
+    tile /= nTY;
+    b = tile / nTZ;
+    z0 = (tile % nTZ) * eTZ, y0 = ty * TYs, x0 = tx * TXs;
+  };
+
+  float4 pf[PFN], pm[MASKED ? PFN : 1], psc, psh;
+  unsigned okbits = 0;
+  auto fetch = [&](int tl, int ck) __attribute__((always_inline)) {
+    int b, z0, y0, x0;
+    tile_origin(tile_first + tl, b, z0, y0, x0);
+    const int hz0 = z0 + in_off, hy0 = y0 + in_off, hx0 = x0 + in_off;
+    const int c0 = ck * CK + quad * 4;
+    if (in_scale != nullptr) {
+      psc = ld4g(in_scale + c0);
+      psh = ld4g(in_shift + c0);
+    }
+    okbits = 0;
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      int hx, hy, hz;
+      decode_row(idx / QPR, HX, HY, rHX, rHY, hz, hy, hx);
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      const bool ok = idx < total && iz >= 0 && iz < Zi && iy >= 0 && iy < Yi && ix >= 0 && ix < Xi;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MASKED) pm[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (ok) {
+        const int64_t off = ((((int64_t)b * Zi + iz) * Yi + iy) * Xi + ix) * c_in + c0;
+        pf[u] = ld4g(X + off);
+        if (MASKED) pm[u] = ld4g(mask_src + off);
+        okbits |= 1u << u;
+      }
+    }
+  };
+  // registers -> LDS: affine map, ReLU mask, then the three bf16 pieces (8 bytes each per float4)
+  auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      if (idx >= total) continue;
+      float4 v = pf[u];
+      if ((okbits >> u) & 1u) {
+        if (in_scale != nullptr) affine4(v, psc, psh);
+        if (MASKED) keep_positive(v, pm[u]);
+      }
+      const float x[4] = {v.x, v.y, v.z, v.w};
+      float r1[4], r2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
+      unsigned* d = sU + (idx / QPR) * kRowW + 2 * quad;   // (box rows are stored in box order)
+      *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+      *reinterpret_cast<uint2*>(d + 8) = make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
+      *reinterpret_cast<uint2*>(d + 16) = make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
+    }
+  };
+
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+
+  pv2::bf16x8 bq[2][NB][3], aq[2][MT][3];
+  fetch(0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bq[0][nb][pc] = Wl[(nb * 3 + pc) * 64];   // item 0, tap 0
+  int tl = 0, ck = 0;
+  for (int item = 0; item < n_items; ++item) {
+    __syncthreads();  // every wave is done with the previous item (taps and epilogue)
+    deposit();
+    __syncthreads();
+
+    const pv2::bf16x8* __restrict__ wck = Wl + (int64_t)ck * wc16;
+    const int ntl = ck + 1 < nchunks ? tl : tl + 1, nck = ck + 1 < nchunks ? ck + 1 : 0;
+    const pv2::bf16x8* __restrict__ wnext = Wl + (int64_t)nck * wc16;   // the next item's first tap
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        aq[0][mt][pc] = *reinterpret_cast<const pv2::bf16x8*>(&sU[rowbase[mt] * kRowW + 8 * pc + 4 * h]);
+    if (item + 1 < n_items) fetch(ntl, nck);   // the next box: in flight during all 27 taps
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto tap = [&](int t1, auto cur_tag) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+      constexpr int kOther = 0x002 | 0x004 | 0x020 | 0x100;  // VALU, SALU, VMEM read, DS read
+      if (t1 < 27) {
+        const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+        const int delta = (kz * HY + ky) * HX + kx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wck[t1 * wtap + (nb * 3 + pc) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            aq[nxt][mt][pc] = *reinterpret_cast<const pv2::bf16x8*>(
+                &sU[(rowbase[mt] + delta) * kRowW + 8 * pc + 4 * h]);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wnext[(nb * 3 + pc) * 64];
+      }
+#define PV2_TERM(ta, tb)                                      \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)           \
+  _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)           \
+    acc[mt][nb] = pv2::mfma_bf16(aq[cur][mt][ta], bq[cur][nb][tb], acc[mt][nb]);
+      PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+      // issue order: one MFMA, then up to two of the other requests
+#pragma unroll
+      for (int k = 0; k < 6 * MT * NB; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kOther, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int t = 0; t < 26; t += 2) {
+      tap(t + 1, std::integral_constant<int, 0>());
+      tap(t + 2, std::integral_constant<int, 1>());
+    }
+    tap(27, std::integral_constant<int, 0>());   // tap 26: set 0; set 1 gets the next item's first weights
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[0][nb][pc] = bq[1][nb][pc];
+
+    if (ck + 1 == nchunks) {
+      __syncthreads();  // the halo tile is free
+      int b, z0, y0, x0;
+      tile_origin(tile_first + tl, b, z0, y0, x0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc_to_stage(stage, acc[mt][nb], i, h);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
+          __builtin_amdgcn_wave_barrier();
+          const int n = (grp * NB + nb) * 32 + 4 * c4;
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias != nullptr) bv = ld4g(bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = r8 + 8 * j;
+            const int q = (wave * MT + mt) * 32 + m;
+            const int cz = q >> lTXY;
+            const int oz = z0 + cz, oy = y0 + ((q >> lTX) & TYm), ox = x0 + (q & TXm);
+            float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+            if (cz >= eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
+            const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+            if (addend != nullptr) {
+              const float4 a = ld4g(addend + off);
+              v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+            }
+            if (relu) {
+              v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            }
             if (out_mask_src != nullptr) keep_positive(v, ld4g(out_mask_src + off));
             *reinterpret_cast<float4*>(Y + off) = v;
           }
@@ -785,6 +1021,34 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(
   packed[e] = W[out * s_out + red * s_red + (tap / 9) * s_z + ((tap / 3) % 3) * s_y + (tap % 3) * s_x];
 }
 
+// Wq[t][c16][nb][piece][lane][d] (dword d = reduction steps 2d, 2d + 1 of the lane's eight): the three
+// bf16 pieces of W[out = nb*32 + (lane & 31)][red = c16*16 + 8 (lane >> 5) + 2d (+1)][tap], tap as above.
+__global__ __launch_bounds__(256) void dconv_pack_split_kernel(
+    const float* __restrict__ W, int n_out, int n_red, int64_t s_out, int64_t s_red, int64_t s_z,
+    int64_t s_y, int64_t s_x, int flip, unsigned* __restrict__ packed) {
+  const int64_t total = (int64_t)27 * n_out * n_red / 2;   // (out, red pair) items; three dwords each
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int d = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  int64_t rest = e >> 8;
+  const int nbtot = n_out >> 5, nc16 = n_red >> 4;
+  const int nb = (int)(rest % nbtot);
+  rest /= nbtot;
+  const int c16 = (int)(rest % nc16);
+  const int t = (int)(rest / nc16);
+  const int tap = flip ? 26 - t : t;
+  const int out = nb * 32 + (lane & 31);
+  const int red = c16 * 16 + 8 * (lane >> 5) + 2 * d;
+  const float* src = W + out * s_out + red * s_red + (tap / 9) * s_z + ((tap / 3) % 3) * s_y + (tap % 3) * s_x;
+  const float a = src[0], b = src[s_red];
+  const float a1 = pv2::bf16_rest(a), b1 = pv2::bf16_rest(b);
+  unsigned* dst = packed + ((((int64_t)t * nc16 + c16) * nbtot + nb) * 3 * 64 + lane) * 4 + d;
+  dst[0] = pv2::pack_hi(a, b);
+  dst[64 * 4] = pv2::pack_hi(a1, b1);
+  dst[2 * 64 * 4] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
+}
+
 int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -834,18 +1098,36 @@ int env_int(const char* name, int fallback) {
   return e ? atoi(e) : fallback;
 }
 
+// the conv k3 s1 p1 runs on the bf16 matrix cores (dconv_split_kernel) unless PV2_FP32_MFMA=1
+bool split_conv(int mode) {
+  static const bool on = env_int("PV2_FP32_MFMA", 0) != 1;
+  return on && mode == 0;
+}
+
 }  // namespace
 
 extern "C" {
 
-int64_t pv2_dconv3_packed_floats(int c_out, int c_in) { return (int64_t)27 * c_out * c_in; }
+// (mode: the pv2_dconv3_forward mode the packed weight is for - the formats differ)
+int64_t pv2_dconv3_packed_floats(int c_out, int c_in, int mode) {
+  const int64_t n = (int64_t)27 * c_out * c_in;
+  return split_conv(mode) ? n * 3 / 2 : n;   // three bf16 pieces per weight
+}
 
 int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
-                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, float* packed,
+                            int64_t s_z, int64_t s_y, int64_t s_x, int flip, int mode, float* packed,
                             pv2_stream_t stream) {
   PV2_REQUIRE(w != nullptr && packed != nullptr, "dconv3_pack_weights: null pointer");
   PV2_REQUIRE(n_out > 0 && n_out % 32 == 0 && n_red > 0 && n_red % 16 == 0,
               "dconv3_pack_weights: output channels must be a multiple of 32, reduction channels of 16");
+  PV2_REQUIRE(mode >= 0 && mode <= 2, "dconv3_pack_weights: mode must be 0, 1 or 2");
+  if (split_conv(mode)) {
+    const int64_t items = (int64_t)27 * n_out * n_red / 2;
+    hipLaunchKernelGGL(dconv_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, n_out, n_red, s_out, s_red, s_z, s_y, s_x, flip,
+                       reinterpret_cast<unsigned*>(packed));
+    return pv2::check_launch("dconv3_pack_weights(split)");
+  }
   const int64_t total = (int64_t)27 * n_out * n_red;
   hipLaunchKernelGGL(dconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, n_out, n_red, s_out, s_red, s_z, s_y, s_x, flip, packed);
@@ -884,10 +1166,12 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     g.Zt = g.Zo, g.Yt = g.Yo, g.Xt = g.Xo;
   }
   const int nbtot = c_out / 32;
+  const bool split = split_conv(mode);
   int mt = 1, nb = 1;
   // (two M-tiles per wave for the big grids; with a ReLU mask the register prefetch is twice as
-  // wide - the 256-cell tile's 13 + 13 float4 spill, the 128-cell tile's 9 + 9 fit)
-  if (mode == 0 && cells_t >= 262144 && in_mask_src == nullptr) mt = 2;
+  // wide - the 256-cell tile's 13 + 13 float4 spill, the 128-cell tile's 9 + 9 fit.  The split
+  // kernel's halo tile is 112 bytes per cell: the 256-cell tile's box would leave one workgroup per CU)
+  if (mode == 0 && cells_t >= 262144 && in_mask_src == nullptr && !split) mt = 2;
   static const int force_mt = env_int("PV2_DCONV_MT", 0), force_nb = env_int("PV2_DCONV_NB", 0);
   if (mode == 0 && force_mt) mt = force_mt;
   pick_tile(128 * mt, g.Zt, g.Yt, g.Xt, &g.TZ, &g.eTZ, &g.TY, &g.TX);
@@ -912,7 +1196,7 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   }
   g.HXr = g.xsplit ? 2 * g.HXh : g.HX;
   g.rHX = 1.0f / (float)g.HX, g.rHY = 1.0f / (float)g.HY;
-  size_t lds = (size_t)g.HZ * g.HY * g.HXr * (ck + 4) * sizeof(float);
+  size_t lds = (size_t)g.HZ * g.HY * g.HXr * (split ? kRowW : ck + 4) * sizeof(float);
   const size_t epilogue = (size_t)4 * 32 * kStagePad * sizeof(float);
   if (lds < epilogue) lds = epilogue;
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
@@ -945,6 +1229,31 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     else PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, false);         \
   } while (0)
   PV2_REQUIRE(pfn <= 13, "dconv3_forward: halo box larger than the register prefetch");
+  if (split) {
+    const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
+#define PV2_DSPLIT_LAUNCH(NB_, PFN_, MASKED_)                                                           \
+  do {                                                                                                  \
+    if (int e = set_lds(dconv_split_kernel<NB_, 1, PFN_, MASKED_>, lds)) return e;                      \
+    hipLaunchKernelGGL((dconv_split_kernel<NB_, 1, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g, c_in, \
+                       wq, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias, addend, relu,   \
+                       out_mask_src, out);                                                              \
+  } while (0)
+#define PV2_DSPLIT_MASK(NB_, PFN_)                    \
+  do {                                                \
+    if (masked) PV2_DSPLIT_LAUNCH(NB_, PFN_, true);   \
+    else PV2_DSPLIT_LAUNCH(NB_, PFN_, false);         \
+  } while (0)
+    if (pfn <= 9) {
+      if (nb == 2) PV2_DSPLIT_MASK(2, 9);
+      else PV2_DSPLIT_MASK(1, 9);
+    } else {
+      if (nb == 2) PV2_DSPLIT_MASK(2, 13);
+      else PV2_DSPLIT_MASK(1, 13);
+    }
+#undef PV2_DSPLIT_MASK
+#undef PV2_DSPLIT_LAUNCH
+    return pv2::check_launch("dconv3_forward(split)");
+  }
   if (mode == 2) {
     if (nb == 2) PV2_DCONV_MASK(2, 1, 8, 13);
     else PV2_DCONV_MASK(1, 1, 8, 13);

@@ -41,17 +41,21 @@ def _new_volume(b, c, z, y, x, like):
     return torch.empty((b, z, y, x, c), dtype=torch.float32, device=like.device).permute(0, 4, 1, 2, 3)
 
 
-def pack_weights(weight, out_dim, flip):
+def pack_weights(weight, out_dim, flip, mode=0):
     """The (transposed) conv weight ``[d0, d1, 3, 3, 3]`` in MFMA fragment order; ``out_dim`` names the
-    dimension that plays the launch's output channels, the other one is reduced over."""
+    dimension that plays the launch's output channels, the other one is reduced over.  ``mode``: the
+    ``conv3_forward`` mode the result is for (the kernels' weight formats differ: mode 0 takes three
+    bf16 pieces per value, csrc/mfma_split.h)."""
     _require_device(weight)
     assert weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.dtype == torch.float32
     red_dim = 1 - out_dim
     n_out, n_red = weight.shape[out_dim], weight.shape[red_dim]
-    packed = torch.empty(27 * n_out * n_red, dtype=torch.float32, device=weight.device)
+    L = _lib.lib()
+    packed = torch.empty(int(L.pv2_dconv3_packed_floats(n_out, n_red, mode)), dtype=torch.float32,
+                         device=weight.device)
     st = weight.stride()
-    _lib.check(_lib.lib().pv2_dconv3_pack_weights(
-        _ptr(weight), n_out, n_red, st[out_dim], st[red_dim], st[2], st[3], st[4], int(flip),
+    _lib.check(L.pv2_dconv3_pack_weights(
+        _ptr(weight), n_out, n_red, st[out_dim], st[red_dim], st[2], st[3], st[4], int(flip), mode,
         _ptr(packed), _stream(weight)), "pv2_dconv3_pack_weights")
     return packed
 
@@ -204,7 +208,7 @@ class _UpsampleAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, skip, x, weight, bias):
         x = _cl(x)
-        packed = pack_weights(weight, 1, False)
+        packed = pack_weights(weight, 1, False, mode=1)
         out = conv3_forward(x, packed, weight.shape[1], 1, bias=bias, addend=skip)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -226,7 +230,7 @@ class _UpsampleAdd(torch.autograd.Function):
                 return g_w, g_b
             gw, gb = _on_side_stream(weight_half, weight, (g, x))
         if ctx.needs_input_grad[1]:
-            packed_s = pack_weights(weight, 0, False)
+            packed_s = pack_weights(weight, 0, False, mode=2)
             gx = conv3_forward(g, packed_s, weight.shape[0], 2)
         return gskip, gx, gw, gb
 

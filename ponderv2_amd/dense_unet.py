@@ -91,12 +91,14 @@ def _vol(b, c, z, y, x, dev):
     return torch.empty((b, z, y, x, c), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
 
 
-def _pack(L, st, w, out_dim, flip):
+def _pack(L, st, w, out_dim, flip, mode=0):
     n_out, n_red = w.shape[out_dim], w.shape[1 - out_dim]
-    packed = torch.empty(27 * n_out * n_red, dtype=torch.float32, device=w.device)
+    packed = torch.empty(int(L.pv2_dconv3_packed_floats(n_out, n_red, mode)), dtype=torch.float32,
+                         device=w.device)
     s = w.stride()
     _lib.check(L.pv2_dconv3_pack_weights(w.data_ptr(), n_out, n_red, s[out_dim], s[1 - out_dim], s[2],
-                                         s[3], s[4], int(flip), packed.data_ptr(), st), "pv2_dconv3_pack_weights")
+                                         s[3], s[4], int(flip), mode, packed.data_ptr(), st),
+               "pv2_dconv3_pack_weights")
     return packed
 
 
@@ -159,7 +161,7 @@ class _DenseUNet(torch.autograd.Function):
         for (up, bn, conv), skip in zip(spec.decoders, skips[1:]):
             up_w, up_b, bn_w, bn_b, w = params[pi:pi + 5]
             pi += 5
-            s = _conv(L, st, x, _pack(L, st, up_w, 1, False), up_w.shape[1], 1, bias=up_b, addend=skip)
+            s = _conv(L, st, x, _pack(L, st, up_w, 1, False, 1), up_w.shape[1], 1, bias=up_b, addend=skip)
             y, stats = _bn_conv(L, st, s, bn, bn_w, bn_b, w)
             saved += [s, stats, y]
             x = y
@@ -229,7 +231,7 @@ class _DenseUNet(torch.autograd.Function):
             wjobs.append((2, None, None, None, gs, None, up_b, k + 1))
             # grad-input of the transposed conv = the gradient of x_in, a ReLU's output (the level
             # below): masked in this kernel's epilogue
-            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False), up_w.shape[0], 2, out_mask=x_in)
+            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False, 2), up_w.shape[0], 2, out_mask=x_in)
         for i in reversed(range(n_enc)):
             p, idx, stats, y = enc[i]
             bn_w, bn_b, w = enc_p[i]

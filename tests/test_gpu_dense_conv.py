@@ -90,10 +90,10 @@ def test_transposed_conv_forward_and_grad_input(device, shape, c_in, c_out):
     gy = torch.randn_like(ref)
     ref.backward(gy)
     wd = w.to(device)
-    got = dc.conv3_forward(cl(vol.detach().float().to(device)), dc.pack_weights(wd, 1, False), c_out, 1,
+    got = dc.conv3_forward(cl(vol.detach().float().to(device)), dc.pack_weights(wd, 1, False, mode=1), c_out, 1,
                            bias=bias.to(device), addend=cl(skip.to(device)))
     assert rel(got, ref.detach() + skip.double()) < TOL
-    gx = dc.conv3_forward(cl(gy.float().to(device)), dc.pack_weights(wd, 0, False), c_in, 2)
+    gx = dc.conv3_forward(cl(gy.float().to(device)), dc.pack_weights(wd, 0, False, mode=2), c_in, 2)
     assert gx.shape == vol.shape and rel(gx, vol.grad) < TOL
 
 

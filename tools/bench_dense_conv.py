@@ -64,7 +64,7 @@ for name, kind, ci, co, (z, y, x) in LAYERS:
         geom = ((2, 2, 2), (1, 1, 1), (1, 1, 1), True, (1, 1, 1), 1)
         gy = cl(torch.randn(B, co, 2 * z, 2 * y, 2 * x, device=dev))
         flops = 2.0 * B * z * y * x * 27 * ci * co
-        pf, pb = dc.pack_weights(w, 1, False), dc.pack_weights(w, 0, False)
+        pf, pb = dc.pack_weights(w, 1, False, mode=1), dc.pack_weights(w, 0, False, mode=2)
         ours = [lambda: dc.conv3_forward(xin, pf, co, 1, addend=gy),
                 lambda: dc.conv3_forward(gy, pb, ci, 2),
                 lambda: dc.conv3_backward_weight(xin, gy, w, 1, n_dim=1)]
