@@ -536,12 +536,18 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
   float* stage = sX + wave * (32 * kStagePad);
   const int c4 = lane & 7, r8 = lane >> 3;
 
-  pv2::bf16x8 bq[2][NB][3], aq[2][MT][3];
+  // Weight fragments run TWO taps ahead (three register sets, tap T lives in set T % 3 - 27 % 3 == 0, so
+  // the numbering carries over from item to item): a tap is six MFMAs per block, ~200 cycles - less
+  // than a trip to L2, where most of the 27 x 3 KB of a chunk's fragments live.  Cells come from LDS
+  // one tap ahead (two sets).
+  pv2::bf16x8 bq[3][NB][3], aq[2][MT][3];
   fetch(0, 0);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int T = 0; T < 2; ++T)
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) bq[0][nb][pc] = Wl[(nb * 3 + pc) * 64];   // item 0, tap 0
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[T][nb][pc] = Wl[T * wtap + (nb * 3 + pc) * 64];   // item 0, taps 0, 1
   int tl = 0, ck = 0;
   for (int item = 0; item < n_items; ++item) {
     __syncthreads();  // every wave is done with the previous item (taps and epilogue)
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
 
     const pv2::bf16x8* __restrict__ wck = Wl + (int64_t)ck * wc16;
     const int ntl = ck + 1 < nchunks ? tl : tl + 1, nck = ck + 1 < nchunks ? ck + 1 : 0;
-    const pv2::bf16x8* __restrict__ wnext = Wl + (int64_t)nck * wc16;   // the next item's first tap
+    const pv2::bf16x8* __restrict__ wnext = Wl + (int64_t)nck * wc16;   // the next item's taps
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -559,32 +565,35 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
     if (item + 1 < n_items) fetch(ntl, nck);   // the next box: in flight during all 27 taps
     __builtin_amdgcn_sched_barrier(0);
 
-    auto tap = [&](int t1, auto cur_tag) __attribute__((always_inline)) {
-      constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+    // tap t: MFMAs on cell set t % 2 and weight set t % 3; requests: cells of tap t + 1, weights of
+    // tap t + 2 (past the item's last tap: the next item's taps 0 and 1)
+    auto tap = [&](int t, auto a_tag, auto w_tag) __attribute__((always_inline)) {
+      constexpr int ac = decltype(a_tag)::value, an = ac ^ 1;
+      constexpr int wc = decltype(w_tag)::value, wn = (wc + 2) % 3;
       constexpr int kOther = 0x002 | 0x004 | 0x020 | 0x100;  // VALU, SALU, VMEM read, DS read
-      if (t1 < 27) {
-        const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
-        const int delta = (kz * HY + ky) * HX + kx;
+      {
+        const int T = t + 2;
+        const pv2::bf16x8* __restrict__ src = T < 27 ? wck + T * wtap : wnext + (T - 27) * wtap;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wck[t1 * wtap + (nb * 3 + pc) * 64];
+          for (int pc = 0; pc < 3; ++pc) bq[wn][nb][pc] = src[(nb * 3 + pc) * 64];
+      }
+      if (t + 1 < 27) {
+        const int t1 = t + 1;
+        const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+        const int delta = (kz * HY + ky) * HX + kx;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc)
-            aq[nxt][mt][pc] = *reinterpret_cast<const pv2::bf16x8*>(
+            aq[an][mt][pc] = *reinterpret_cast<const pv2::bf16x8*>(
                 &sU[(rowbase[mt] + delta) * kRowW + 8 * pc + 4 * h]);
-      } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wnext[(nb * 3 + pc) * 64];
       }
 #define PV2_TERM(ta, tb)                                      \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)           \
   _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)           \
-    acc[mt][nb] = pv2::mfma_bf16(aq[cur][mt][ta], bq[cur][nb][tb], acc[mt][nb]);
+    acc[mt][nb] = pv2::mfma_bf16(aq[ac][mt][ta], bq[wc][nb][tb], acc[mt][nb]);
       PV2_SPLIT_TERMS(PV2_TERM)
 #undef PV2_TERM
       // issue order: one MFMA, then up to two of the other requests
@@ -595,16 +604,21 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
 #pragma unroll 1
-    for (int t = 0; t < 26; t += 2) {
-      tap(t + 1, std::integral_constant<int, 0>());
-      tap(t + 2, std::integral_constant<int, 1>());
+    for (int t = 0; t < 24; t += 6) {
+      tap(t, I0(), I0());
+      tap(t + 1, I1(), I1());
+      tap(t + 2, I0(), I2());
+      tap(t + 3, I1(), I0());
+      tap(t + 4, I0(), I1());
+      tap(t + 5, I1(), I2());
     }
-    tap(27, std::integral_constant<int, 0>());   // tap 26: set 0; set 1 gets the next item's first weights
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) bq[0][nb][pc] = bq[1][nb][pc];
+    tap(24, I0(), I0());
+    tap(25, I1(), I1());
+    tap(26, I0(), I2());
 
     if (ck + 1 == nchunks) {
       __syncthreads();  // the halo tile is free
@@ -1172,6 +1186,8 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   // wide - the 256-cell tile's 13 + 13 float4 spill, the 128-cell tile's 9 + 9 fit.  The split
   // kernel's halo tile is 112 bytes per cell: the 256-cell tile's box would leave one workgroup per CU)
   if (mode == 0 && cells_t >= 262144 && in_mask_src == nullptr && !split) mt = 2;
+  static const int split_mt = env_int("PV2_DSPLIT_MT", 1);
+  if (split && cells_t >= 262144 && in_mask_src == nullptr) mt = split_mt;
   static const int force_mt = env_int("PV2_DCONV_MT", 0), force_nb = env_int("PV2_DCONV_NB", 0);
   if (mode == 0 && force_mt) mt = force_mt;
   pick_tile(128 * mt, g.Zt, g.Yt, g.Xt, &g.TZ, &g.eTZ, &g.TY, &g.TX);
@@ -1231,13 +1247,18 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   PV2_REQUIRE(pfn <= 13, "dconv3_forward: halo box larger than the register prefetch");
   if (split) {
     const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
-#define PV2_DSPLIT_LAUNCH(NB_, PFN_, MASKED_)                                                           \
-  do {                                                                                                  \
-    if (int e = set_lds(dconv_split_kernel<NB_, 1, PFN_, MASKED_>, lds)) return e;                      \
-    hipLaunchKernelGGL((dconv_split_kernel<NB_, 1, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g, c_in, \
-                       wq, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias, addend, relu,   \
-                       out_mask_src, out);                                                              \
+#define PV2_DSPLIT_LAUNCH_MT(NB_, MT_, PFN_, MASKED_)                                                     \
+  do {                                                                                                   \
+    if (int e = set_lds(dconv_split_kernel<NB_, MT_, PFN_, MASKED_>, lds)) return e;                     \
+    hipLaunchKernelGGL((dconv_split_kernel<NB_, MT_, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g, c_in, \
+                       wq, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias, addend, relu,    \
+                       out_mask_src, out);                                                               \
   } while (0)
+#define PV2_DSPLIT_LAUNCH(NB_, PFN_, MASKED_) PV2_DSPLIT_LAUNCH_MT(NB_, 1, PFN_, MASKED_)
+    if (mt == 2) {
+      PV2_DSPLIT_LAUNCH_MT(1, 2, 13, false);
+      return pv2::check_launch("dconv3_forward(split)");
+    }
 #define PV2_DSPLIT_MASK(NB_, PFN_)                    \
   do {                                                \
     if (masked) PV2_DSPLIT_LAUNCH(NB_, PFN_, true);   \
@@ -1252,6 +1273,7 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     }
 #undef PV2_DSPLIT_MASK
 #undef PV2_DSPLIT_LAUNCH
+#undef PV2_DSPLIT_LAUNCH_MT
     return pv2::check_launch("dconv3_forward(split)");
   }
   if (mode == 2) {
