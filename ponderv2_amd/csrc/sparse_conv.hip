@@ -683,6 +683,167 @@ __global__ __launch_bounds__(256) void spconv_wgrad_lds_kernel(
     }
 }
 
+// The weight gradient on the bf16 matrix cores (mfma_split.h).  The reduction runs over PAIRS, and a
+// lane of v_mfma_f32_32x32x16_bf16 owns eight consecutive reduction steps of one channel: both
+// operands - rows of dY and X, channel-contiguous in memory - are transposed on their way into LDS.
+// A staging item is a couple of consecutive pairs x four channels: two 16-byte loads, and for each
+// channel and piece ONE dword (the couple's two bf16) written to [channel][piece][couple] - lanes run
+// along the couples, so the transposing writes are conflict-free.  Channel rows are padded to KS/2 * 3
+// + 4 dwords (52 for 32-pair steps, 100 for 64): ds_read_b128 of 16 consecutive channels hits 64
+// distinct banks.  One LDS buffer; the rows of the next TWO steps travel in registers.
+// Waves: WN x WC x WK as in the fp32 kernel; wave wk takes the 16-pair sub-steps wk, wk + WK, ...
+template <int WN, int WC, int WK>
+__global__ __launch_bounds__(256) void spconv_wgrad_split_kernel(
+    const float* __restrict__ X, int c_in, const float* __restrict__ dY, int c_out, int K,
+    const int32_t* __restrict__ pair_in, const int32_t* __restrict__ pair_out,
+    const int32_t* __restrict__ kstart, const int32_t* __restrict__ tile_start, int tile_pairs,
+    int n_ntile, int n_ctile, float* __restrict__ dW, float* __restrict__ part) {
+  static_assert(WN * WC * WK == 4, "4 waves");
+  constexpr int TN = 64 * WN, TC = 64 * WC;
+  constexpr int KS = WK == 4 ? 64 : 32;          // pairs per step
+  constexpr int NSUB = KS / 16;                  // 16-pair MFMA sub-steps per step
+  constexpr int PW = KS / 2;                     // dwords per piece of a channel row
+  constexpr int RW = 3 * PW + 4;                 // dwords per channel row
+  constexpr int CPL = KS / 2;                    // pair couples per step
+  constexpr int ITEMS_A = CPL * (TN / 4), ITEMS_B = CPL * (TC / 4);
+  constexpr int UA = ITEMS_A / 256, UB = ITEMS_B / 256;   // staging items per thread
+  static_assert(ITEMS_A % 256 == 0 && ITEMS_B % 256 == 0, "whole items per thread");
+  // dynamic LDS: the operand tile, then the tile's pair lists (2 x tile_pairs ints; 57 KB at 512 pairs)
+  extern __shared__ __attribute__((aligned(16))) unsigned sT[];
+  int* s_in = reinterpret_cast<int*>(sT + (TN + TC) * RW);
+  int* s_out = s_in + tile_pairs;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int per_tile = n_ntile * n_ctile;
+  const int tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
+  const int n0 = (sub / n_ctile) * TN, c0 = (sub % n_ctile) * TC;
+  if (tile >= tile_start[K]) return;  // grid sized from an upper bound of the pair counts
+  const int k = find_offset(tile_start, K, tile);
+  const int p0 = kstart[k] + (tile - tile_start[k]) * tile_pairs;
+  const int cnt = min(kstart[k + 1] - p0, tile_pairs);
+  const int nsteps = (cnt + KS - 1) / KS;
+  // (pairs past the end: row 0 with a zero factor - the loads stay unconditional, see the forward kernel)
+  for (int t = tid; t < nsteps * KS; t += 256) {
+    s_in[t] = t < cnt ? pair_in[p0 + t] : -1;
+    s_out[t] = t < cnt ? pair_out[p0 + t] : -1;
+  }
+  __syncthreads();
+
+  const int wk = wave % WK, wc = (wave / WK) % WC, wn = wave / (WK * WC);
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  struct Regs {
+    float4 a0[UA], a1[UA], b0[UB], b1[UB];
+    float za[UA][2], zb[UB][2];     // 1 / 0: the pair exists
+  };
+  Regs rg[2];
+  // item (u): couple q = item % CPL, channel quad cq = item / CPL
+  auto load_step = [&](Regs& d, int s) __attribute__((always_inline)) {
+    const int sb = min(s, nsteps - 1) * KS;   // (steps past the end: clamped, loaded and never used)
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int item = tid + 256 * u;
+      const int q = item % CPL, col = min(n0 + 4 * (item / CPL), c_out - 4);
+      const int r0 = s_out[sb + 2 * q], r1 = s_out[sb + 2 * q + 1];
+      d.a0[u] = *reinterpret_cast<const float4*>(dY + (int64_t)max(r0, 0) * c_out + col);
+      d.a1[u] = *reinterpret_cast<const float4*>(dY + (int64_t)max(r1, 0) * c_out + col);
+      d.za[u][0] = r0 >= 0 ? 1.f : 0.f, d.za[u][1] = r1 >= 0 ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int item = tid + 256 * u;
+      const int q = item % CPL, col = min(c0 + 4 * (item / CPL), c_in - 4);
+      const int r0 = s_in[sb + 2 * q], r1 = s_in[sb + 2 * q + 1];
+      d.b0[u] = *reinterpret_cast<const float4*>(X + (int64_t)max(r0, 0) * c_in + col);
+      d.b1[u] = *reinterpret_cast<const float4*>(X + (int64_t)max(r1, 0) * c_in + col);
+      d.zb[u][0] = r0 >= 0 ? 1.f : 0.f, d.zb[u][1] = r1 >= 0 ? 1.f : 0.f;
+    }
+  };
+  auto put = [&](unsigned* row, const float4& v0, const float4& v1, float z0, float z1, int q)
+      __attribute__((always_inline)) {
+    const float x0[4] = {v0.x * z0, v0.y * z0, v0.z * z0, v0.w * z0};
+    const float x1[4] = {v1.x * z1, v1.y * z1, v1.z * z1, v1.w * z1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a1 = pv2::bf16_rest(x0[j]), b1 = pv2::bf16_rest(x1[j]);
+      unsigned* d = row + j * RW + q;
+      d[0] = pv2::pack_hi(x0[j], x1[j]);
+      d[PW] = pv2::pack_hi(a1, b1);
+      d[2 * PW] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
+    }
+  };
+  auto store_step = [&](const Regs& d) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int item = tid + 256 * u;
+      put(sT + (4 * (item / CPL)) * RW, d.a0[u], d.a1[u], d.za[u][0], d.za[u][1], item % CPL);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int item = tid + 256 * u;
+      put(sT + (TN + 4 * (item / CPL)) * RW, d.b0[u], d.b1[u], d.zb[u][0], d.zb[u][1], item % CPL);
+    }
+  };
+  auto multiply = [&]() __attribute__((always_inline)) {
+    const unsigned* arow = sT + (wn * 64 + i) * RW + 4 * h;
+    const unsigned* brow = sT + (TN + wc * 64 + i) * RW + 4 * h;
+#pragma unroll
+    for (int st = wk; st < NSUB; st += WK) {
+      pv2::bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          fa[a][pc] = *reinterpret_cast<const pv2::bf16x8*>(arow + a * 32 * RW + pc * PW + 8 * st);
+          fb[a][pc] = *reinterpret_cast<const pv2::bf16x8*>(brow + a * 32 * RW + pc * PW + 8 * st);
+        }
+#define PV2_TERM(ta, tb)                            \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)     \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b)     \
+    acc[a][b] = pv2::mfma_bf16(fa[a][ta], fb[b][tb], acc[a][b]);
+      PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+    }
+  };
+
+  load_step(rg[0], 0);
+  load_step(rg[1], 1);
+  auto iteration = [&](int s, Regs& cur) __attribute__((always_inline)) {
+    store_step(cur);            // step s (its loads were issued two iterations ago)
+    load_step(cur, s + 2);      // ... and the set is free for step s + 2
+    __syncthreads();
+    multiply();
+    __syncthreads();            // every wave is done reading before the next step overwrites
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    iteration(s, rg[0]);
+    iteration(s + 1, rg[1]);
+  }
+  if (s < nsteps) iteration(s, rg[0]);
+
+  float* slab = part + ((int64_t)tile * WK + wk) * c_out * c_in;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < c_out) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int c = c0 + wc * 64 + b * 32 + i;
+          if (c < c_in) slab[(int64_t)n * c_in + c] = acc[a][b][r];
+        }
+      }
+    }
+}
+
 // Dense "tall" GEMM  Y[M, N] = X[M, K] . W[N, K]^T (+ bias): the MLP heads of the render field
 // (M = rays x samples ~ 1e5, K and N <= 512).  Same structure as spconv_fwd_lds_kernel without the
 // rulebook: 128 rows per workgroup, the weight slab shared through LDS, A fragments streamed from
@@ -1083,9 +1244,28 @@ int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout
       return PV2_E_BADARG;
     }
 #define PV2_LAUNCH_WGRAD_LDS(WN, WC, WK)                                                          \
-  hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, false>), dim3((unsigned)blocks),        \
-                     dim3(256), 0, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out, kstart,   \
-                     tile_start, tile_pairs, n_ntile, n_ctile, dweight, part)
+  do {                                                                                            \
+    if (part != nullptr && use_split()) {                                                         \
+      constexpr int ks = WK == 4 ? 64 : 32;                                                       \
+      const size_t lds = ((size_t)(64 * WN + 64 * WC) * (3 * ks / 2 + 4) + 2 * (size_t)tile_pairs) * 4; \
+      if (lds > 65536) {                                                                          \
+        static bool allowed = false; /* (per instantiation: the macro expands once per variant) */ \
+        if (!allowed) {                                                                           \
+          if (int e = pv2::hip_status(hipFuncSetAttribute(                                        \
+                  reinterpret_cast<const void*>(&spconv_wgrad_split_kernel<WN, WC, WK>),          \
+                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)))                        \
+            return e;                                                                             \
+          allowed = true;                                                                         \
+        }                                                                                         \
+      }                                                                                           \
+      hipLaunchKernelGGL((spconv_wgrad_split_kernel<WN, WC, WK>), dim3((unsigned)blocks),         \
+                         dim3(256), lds, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out,     \
+                         kstart, tile_start, tile_pairs, n_ntile, n_ctile, dweight, part);        \
+    } else                                                                                        \
+      hipLaunchKernelGGL((spconv_wgrad_lds_kernel<WN, WC, WK, false>), dim3((unsigned)blocks),    \
+                         dim3(256), 0, s, in_feat, c_in, dout, c_out, K, pair_in, pair_out,       \
+                         kstart, tile_start, tile_pairs, n_ntile, n_ctile, dweight, part);        \
+  } while (0)
     if (blocks > 0) {
       if (big_n && big_c) PV2_LAUNCH_WGRAD_LDS(2, 2, 1);
       else if (big_n) PV2_LAUNCH_WGRAD_LDS(2, 1, 2);
