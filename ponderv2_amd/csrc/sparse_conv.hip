@@ -828,20 +828,53 @@ __global__ __launch_bounds__(256) void spconv_wgrad_split_kernel(
   }
   if (s < nsteps) iteration(s, rg[0]);
 
-  float* slab = part + ((int64_t)tile * WK + wk) * c_out * c_in;
+  // ONE slab per tile: the WK waves that share a 64 x 64 block add their accumulators through LDS in
+  // wave order (the operand tile is free: the loop ended with a barrier), then the block leaves as
+  // 16-byte pieces of its rows.  (Four slabs per tile made the ordered reduction of the narrow layers
+  // a chain of 60 dependent loads per output.)
+  if constexpr (WK == 1) {   // nothing to add: straight from the accumulators (128-byte row segments)
+    float* slab1 = part + (int64_t)tile * c_out * c_in;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (n < c_out) {
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (n < c_out) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int c = c0 + wc * 64 + b * 32 + i;
-          if (c < c_in) slab[(int64_t)n * c_in + c] = acc[a][b][r];
+          for (int b = 0; b < 2; ++b) {
+            const int c = c0 + wc * 64 + b * 32 + i;
+            if (c < c_in) slab1[(int64_t)n * c_in + c] = acc[a][b][r];
+          }
         }
       }
+    return;
+  }
+  float* red = reinterpret_cast<float*>(sT) + (wn * WC + wc) * 4096;   // [64][64] per block
+#pragma unroll
+  for (int w = 0; w < WK; ++w) {
+    if (wk == w) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* d = &red[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + b * 32 + i];
+            *d = w == 0 ? acc[a][b][r] : *d + acc[a][b][r];
+          }
     }
+    __syncthreads();
+  }
+  float* slab = part + (int64_t)tile * c_out * c_in;
+  for (int e = tid; e < TN * (TC / 4); e += 256) {
+    const int row = e / (TC / 4), c4 = e % (TC / 4);
+    const int n = n0 + row, c = c0 + 4 * c4;
+    if (n < c_out && c < c_in) {
+      const float* src = reinterpret_cast<const float*>(sT) +
+                         ((row >> 6) * WC + (c4 >> 4)) * 4096 + (row & 63) * 64 + 4 * (c4 & 15);
+      *reinterpret_cast<float4*>(slab + (int64_t)n * c_in + c) = *reinterpret_cast<const float4*>(src);
+    }
+  }
 }
 
 // Dense "tall" GEMM  Y[M, N] = X[M, K] . W[N, K]^T (+ bias): the MLP heads of the render field
@@ -1176,6 +1209,7 @@ int pv2_spconv_forward_tile(int c_in, int c_out) {
 
 // split-K factor over the waves of a weight-gradient workgroup (see spconv_wgrad_lds_kernel)
 static int wgrad_split_k(int c_in, int c_out) {
+  if (use_split()) return 1;   // (the bf16-piece kernel adds its waves' shares itself)
   const bool big_n = c_out > 64, big_c = c_in > 64;
   return (big_n && big_c) ? 1 : (big_n || big_c) ? 2 : 4;
 }
@@ -1188,30 +1222,44 @@ namespace {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     const float4* __restrict__ part, const int32_t* __restrict__ tile_start, int K, int wk,
     int c_out, int c_in4, float4* __restrict__ dW) {
+  // a workgroup = 64 outputs (16 bytes each) x 4 slab lanes: lane j adds slabs j, j + 4, ... in
+  // order, the four sub-sums are added in lane order - a fixed order, four times shorter chains
+  __shared__ float4 s_sub[256];
   const int64_t total = (int64_t)c_out * K * c_in4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int c4 = (int)(e % c_in4);
-    const int k = (int)((e / c_in4) % K);
-    const int n = (int)(e / ((int64_t)c_in4 * K));
-    const int64_t t0 = (int64_t)tile_start[k] * wk, t1 = (int64_t)tile_start[k + 1] * wk;
+  const int lane4 = threadIdx.x >> 6, o = threadIdx.x & 63;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t e = base + o;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t slab4 = (int64_t)c_out * c_in4;
-    const float4* src = part + (int64_t)n * c_in4 + c4;
-    int64_t t = t0;
-    for (; t + 4 <= t1; t += 4) {  // four loads in flight, added in slab order
-      const float4 v0 = src[t * slab4], v1 = src[(t + 1) * slab4];
-      const float4 v2 = src[(t + 2) * slab4], v3 = src[(t + 3) * slab4];
-      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    if (e < total) {
+      const int c4 = (int)(e % c_in4);
+      const int k = (int)((e / c_in4) % K);
+      const int n = (int)(e / ((int64_t)c_in4 * K));
+      const int64_t t0 = (int64_t)tile_start[k] * wk, t1 = (int64_t)tile_start[k + 1] * wk;
+      const int64_t slab4 = (int64_t)c_out * c_in4;
+      const float4* src = part + (int64_t)n * c_in4 + c4;
+      int64_t t = t0 + lane4;
+      for (; t + 4 < t1; t += 8) {  // two loads in flight per lane, added in slab order
+        const float4 v0 = src[t * slab4], v1 = src[(t + 4) * slab4];
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      }
+      for (; t < t1; t += 4) {
+        const float4 v = src[t * slab4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
     }
-    for (; t < t1; ++t) {
-      const float4 v = src[t * slab4];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    s_sub[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane4 == 0 && e < total) {
+      float4 r = s_sub[o];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        const float4 v = s_sub[j * 64 + o];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      }
+      dW[e] = r;
     }
-    dW[e] = acc;
+    __syncthreads();
   }
 }
 
@@ -1275,7 +1323,7 @@ int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout
 #undef PV2_LAUNCH_WGRAD_LDS
     if (part != nullptr) {
       const int64_t total4 = (int64_t)c_out * K * (c_in / 4);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pv2::grid_for(total4, 256)), dim3(256), 0, s,
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pv2::grid_for(total4, 64)), dim3(256), 0, s,
                          (const float4*)part, tile_start, K, wgrad_split_k(c_in, c_out), c_out,
                          c_in / 4, (float4*)dweight);
     }
