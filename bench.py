@@ -34,6 +34,19 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
+# fp32 products computed as SIX bf16 MFMAs over three exact bf16 pieces per operand (csrc/mfma_split.h):
+# the matrix roofline of those kernels, in fp32-equivalent (= algorithmic) TFLOP/s
+SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+SPLIT_ON = os.environ.get("PV2_FP32_MFMA") != "1"
+SPLIT_FAMILIES = ("spconv_fwd_lds_kernel", "spconv_wgrad_split_kernel", "dconv_split_kernel",
+                  "dconvT_split_kernel")
+
+
+def mfma_peak_of(family, default):
+    """Dense matrix peak that bounds a kernel family, in algorithmic TFLOP/s."""
+    if SPLIT_ON and family.startswith(SPLIT_FAMILIES):
+        return SPLIT_MFMA_PEAK_TFLOPS
+    return default
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -42,7 +55,7 @@ PMC_FILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 
 def kernel_source_hash():
     """sha256 (16 hex digits) over the sources of the sparse-conv kernels (csrc/sparse_conv*.hip +
-    common.h) - the kernels the `roofline` line is about: what their per-kernel PMC measurement
+    common.h, mfma_split.h) - the kernels the `roofline` line is about: what their per-kernel PMC measurement
     stays valid for.  tools/pmc_to_json.py stamps the same value into the PMC file."""
     import hashlib
 
@@ -50,7 +63,7 @@ def kernel_source_hash():
     src = os.path.join(ROOT, "ponderv2_amd", "csrc")
     files = sorted(os.path.join(src, f) for f in os.listdir(src)
                    if f.startswith("sparse_conv") and f.endswith(".hip"))
-    for f in files + [os.path.join(src, "common.h")]:
+    for f in files + [os.path.join(src, "common.h"), os.path.join(src, "mfma_split.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -376,7 +389,8 @@ class KernelTimer:
             if c_in % 4 or c_out % 4:
                 return "spconv_wgrad_kernel (stem, any channel count)"
             big_n, big_c = c_out > 64, c_in > 64
-            return "spconv_wgrad_lds_kernel<%s>%s" % (
+            return "%s<%s>%s" % (
+                "spconv_wgrad_split_kernel" if SPLIT_ON and K.USE_WGRAD_DET else "spconv_wgrad_lds_kernel",
                 "2, 2, 1" if big_n and big_c else "2, 1, 2" if big_n else "1, 2, 2" if big_c else "1, 1, 4",
                 " + wgrad_reduce_kernel (two-stage, deterministic)" if K.USE_WGRAD_DET else "")
 
@@ -592,8 +606,10 @@ class KernelTimer:
 
         orig_dconv = handle.pv2_dconv3_forward
         self._orig_c["pv2_dconv3_forward"] = orig_dconv
-        fam_by_mode = {0: "dconv_kernel (dense 3x3x3 conv: fwd + grad-input)",
-                       1: "dconvT_kernel (dense transposed conv k3 s2: fwd)",
+        fam_by_mode = {0: ("dconv_split_kernel" if SPLIT_ON else "dconv_kernel") +
+                          " (dense 3x3x3 conv: fwd + grad-input)",
+                       1: ("dconvT_split_kernel" if SPLIT_ON else "dconvT_kernel") +
+                          " (dense transposed conv k3 s2: fwd)",
                        2: "dconv_kernel (strided k3 s2: grad-input of the transposed conv)"}
 
         def timed_dconv(*a):
@@ -646,7 +662,7 @@ class KernelTimer:
                             alg_gbs=nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                             alg_flops_per_launch=flops / max(len(recs), 1),
                             alg_bytes_per_launch=nbytes / max(len(recs), 1),
-                            mfma_peak_tflops=self.peaks.get(fam, F32_MFMA_PEAK_TFLOPS)))
+                            mfma_peak_tflops=mfma_peak_of(fam, self.peaks.get(fam, F32_MFMA_PEAK_TFLOPS))))
             out[-1]["frac_of_mfma_peak"] = out[-1]["tflops"] / out[-1]["mfma_peak_tflops"]
             out[-1]["frac_of_hbm_peak"] = out[-1]["alg_gbs"] / HBM_PEAK_GBS
             if fam in getattr(self, "survey", {}):
@@ -1008,6 +1024,14 @@ def main():
                 result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma",
                                       "achieved": dom["tflops"], "peak": dom["mfma_peak_tflops"],
                                       "unit": "TFLOP/s", "frac": dom["tflops"] / dom["mfma_peak_tflops"],
+                                      "peak_note": (
+                                          "algorithmic (fp32-equivalent) TFLOP/s; this kernel computes every fp32 "
+                                          "product as six v_mfma_f32_32x32x16_bf16 over three exact bf16 pieces per "
+                                          "operand (csrc/mfma_split.h): peak = dense bf16 MFMA peak / 6; against the "
+                                          "fp32 MFMA peak (%.1f) the same rate is %.3f" % (
+                                              F32_MFMA_PEAK_TFLOPS, dom["tflops"] / F32_MFMA_PEAK_TFLOPS)
+                                          if dom["mfma_peak_tflops"] == SPLIT_MFMA_PEAK_TFLOPS else
+                                          "dense MFMA peak of the kernel's operand type"),
                                       "hbm_frac_of_alg_bytes": dom.get("frac_of_hbm_peak"),
                                       "traffic": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[0],
                                       "traffic_source": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[1],

@@ -777,6 +777,145 @@ __global__ __launch_bounds__(256, 2) void dconvT_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// dconvT_kernel on the bf16 matrix cores (mfma_split.h): the coarse box in three bf16 pieces per cell
+// (28-dword rows, as dconv_split_kernel), weights pre-cut (dconv_pack_split_kernel, out = C_out of the
+// transposed conv); per tap ONE class accumulator takes six MFMAs; the neighbour's cells come from LDS
+// one tap ahead, the weight fragments two taps ahead.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
+    const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
+    int n_groups, const float* __restrict__ bias, const float* __restrict__ addend,
+    float* __restrict__ Y) {
+  constexpr int CK = 16, QPR = 4;
+  extern __shared__ __attribute__((aligned(16))) float sX[];
+  unsigned* sU = reinterpret_cast<unsigned*>(sX);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int grp = blockIdx.x % n_groups;
+  int tile = blockIdx.x / n_groups;
+  const int tx = tile % g.nTX;
+  tile /= g.nTX;
+  const int ty = tile % g.nTY;
+  tile /= g.nTY;
+  const int tz = tile % g.nTZ;
+  const int b = tile / g.nTZ;
+  const int z0 = tz * g.eTZ, y0 = ty * g.TY, x0 = tx * g.TX;
+  const int HX = g.HX, HY = g.HY;
+
+  int rowbase;
+  {
+    const int q = wave * 32 + i;
+    const int cx = q & (g.TX - 1), cy = (q >> g.lTX) & (g.TY - 1), cz = q >> (g.lTX + g.lTY);
+    rowbase = cz < g.eTZ ? (cz * HY + cy) * HX + cx : 0;
+  }
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int nchunks = c_in / CK;
+  const int nbtot = c_out >> 5;
+  const pv2::bf16x8* __restrict__ Wl = Wq + grp * 3 * 64 + lane;
+  const int64_t wc16 = (int64_t)nbtot * 3 * 64;
+  const int64_t wtap = (int64_t)nchunks * wc16;
+  const int total = g.HZ * HY * HX * QPR;
+  const int quad = tid & 3;
+
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck) __syncthreads();
+    // the chunk's box -> three bf16 pieces per cell (four loads in flight per thread)
+    for (int base = tid; base < total; base += 256 * 4) {
+      float4 v[4];
+      int row[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * 256;
+        row[u] = idx < total ? idx / QPR : -1;
+        int hx, hy, hz;
+        decode_row(idx / QPR, HX, HY, g.rHX, g.rHY, hz, hy, hx);
+        const int iz = z0 + hz, iy = y0 + hy, ix = x0 + hx;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < total && iz < g.Zi && iy < g.Yi && ix < g.Xi)
+          v[u] = ld4g(X + ((((int64_t)b * g.Zi + iz) * g.Yi + iy) * g.Xi + ix) * c_in + ck * CK + quad * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (row[u] < 0) continue;
+        const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        float r1[4], r2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
+        unsigned* d = sU + row[u] * kRowW + 2 * quad;
+        *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+        *reinterpret_cast<uint2*>(d + 8) = make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
+      }
+    }
+    __syncthreads();
+    const pv2::bf16x8* __restrict__ wck = Wl + (int64_t)ck * wc16;
+    auto cells_of = [&](int t, pv2::bf16x8 (&a)[3]) __attribute__((always_inline)) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int delta = ((kz == 0) * HY + (ky == 0)) * HX + (kx == 0);   // coarse neighbour j + (k == 0)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        a[pc] = *reinterpret_cast<const pv2::bf16x8*>(&sU[(rowbase + delta) * kRowW + 8 * pc + 4 * h]);
+    };
+    pv2::bf16x8 wq[3][3], aq[2][3];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) wq[T][pc] = wck[T * wtap + pc * 64];
+    cells_of(0, aq[0]);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int cls = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
+      if (t + 2 < 27) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wq[(t + 2) % 3][pc] = wck[(t + 2) * wtap + pc * 64];
+      }
+      if (t + 1 < 27) cells_of(t + 1, aq[(t + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // (the requests stay in front of the MFMAs)
+#define PV2_TERM(ta, tb) acc[cls] = pv2::mfma_bf16(aq[t & 1][ta], wq[t % 3][tb], acc[cls]);
+      PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  __syncthreads();
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+  const int n = grp * 32 + 4 * c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias != nullptr) bv = ld4g(bias + n);
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    acc_to_stage(stage, acc[cls], i, h);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = r8 + 8 * j;
+      const int q = wave * 32 + m;
+      const int cz = q >> (g.lTX + g.lTY);
+      const int jz = z0 + cz, jy = y0 + ((q >> g.lTX) & (g.TY - 1)), jx = x0 + (q & (g.TX - 1));
+      float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+      if (cz >= g.eTZ || jz >= g.Zt || jy >= g.Yt || jx >= g.Xt) continue;
+      const int64_t off =
+          ((((int64_t)b * g.Zo + 2 * jz + pz) * g.Yo + 2 * jy + py) * g.Xo + 2 * jx + px) * c_out + n;
+      v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+      if (addend != nullptr) {
+        const float4 a = ld4g(addend + off);
+        v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+      }
+      *reinterpret_cast<float4*>(Y + off) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[n][c][t] = sum over iteration cells q of G[cellG(q, t)][n] * X[cellX(q, t)][c]
 //   conv k3 s1 p1:        G = dy at q,            X = input at q + t - 1
 //   transposed k3 s2 p1:  G = dy at 2q + (t != 1), X = input at q + (t == 0)       (per axis)
@@ -1112,10 +1251,11 @@ int env_int(const char* name, int fallback) {
   return e ? atoi(e) : fallback;
 }
 
-// the conv k3 s1 p1 runs on the bf16 matrix cores (dconv_split_kernel) unless PV2_FP32_MFMA=1
+// the conv k3 s1 p1 and the transposed conv run on the bf16 matrix cores (dconv_split_kernel,
+// dconvT_split_kernel) unless PV2_FP32_MFMA=1
 bool split_conv(int mode) {
   static const bool on = env_int("PV2_FP32_MFMA", 0) != 1;
-  return on && mode == 0;
+  return on && (mode == 0 || mode == 1);
 }
 
 }  // namespace
@@ -1217,6 +1357,13 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   if (lds < epilogue) lds = epilogue;
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
   const int n_groups = nbtot / nb;
+  if (mode == 1 && split) {
+    if (int e = set_lds(dconvT_split_kernel, lds)) return e;
+    hipLaunchKernelGGL(dconvT_split_kernel, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g,
+                       c_in, reinterpret_cast<const pv2::bf16x8*>(packed_w), c_out, n_groups, bias, addend,
+                       out);
+    return pv2::check_launch("dconv3_forward(transposed, split)");
+  }
   if (mode == 1) {
     if (int e = set_lds(dconvT_kernel, lds)) return e;
     hipLaunchKernelGGL(dconvT_kernel, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g, c_in,
