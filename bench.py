@@ -39,7 +39,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 
 SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 SPLIT_ON = os.environ.get("PV2_FP32_MFMA") != "1"
 SPLIT_FAMILIES = ("spconv_fwd_lds_kernel", "spconv_wgrad_split_kernel", "dconv_split_kernel",
-                  "dconvT_split_kernel")
+                  "dconvT_split_kernel", "dconv_strided_split_kernel")
 
 
 def mfma_peak_of(family, default):
@@ -610,7 +610,8 @@ class KernelTimer:
                           " (dense 3x3x3 conv: fwd + grad-input)",
                        1: ("dconvT_split_kernel" if SPLIT_ON else "dconvT_kernel") +
                           " (dense transposed conv k3 s2: fwd)",
-                       2: "dconv_kernel (strided k3 s2: grad-input of the transposed conv)"}
+                       2: ("dconv_strided_split_kernel" if SPLIT_ON else "dconv_kernel") +
+                          " (strided k3 s2: grad-input of the transposed conv)"}
 
         def timed_dconv(*a):
             s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

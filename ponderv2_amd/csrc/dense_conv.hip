@@ -777,6 +777,211 @@ __global__ __launch_bounds__(256, 2) void dconvT_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// The strided conv k3 s2 p1 (grad-input of the transposed conv) on the bf16 matrix cores.  Its halo
+// box is 8 x the tile, so only 8 channels are staged per chunk - half a 16-step MFMA.  The other half
+// is a second TAP: lanes h = 0 / 1 of v_mfma_f32_32x32x16_bf16 own reduction steps 0..7 / 8..15, here
+// (tap 2 tp, channels 0..7) / (tap 2 tp + 1, channels 0..7) - each half reads its own box row, the
+// weights are packed by tap pair (dconv_pack_split2_kernel; tap 27 = zeros).  A cell row is three
+// pieces x 8 bf16 = 12 dwords: 16 consecutive rows hit 64 distinct banks without padding.  The box's
+// x axis is stored odd / even de-interleaved as in dconv_kernel.
+//   Wq[tp][c8][nb][piece][lane]: lane (i, h) holds W[out = nb*32 + i][red = c8*8 .. + 7][tap 2 tp + h]
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowS = 12;
+
+template <int NB, int PFN, bool MASKED>
+__global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
+    const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
+    int n_groups, int tiles_per_wg, const float* __restrict__ mask_src,
+    const float* __restrict__ out_mask_src, float* __restrict__ Y) {
+  constexpr int CK = 8, QPR = 2, NPAIR = 14;
+  extern __shared__ __attribute__((aligned(16))) float sX[];
+  unsigned* sU = reinterpret_cast<unsigned*>(sX);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int grp = blockIdx.x % n_groups;
+  const int n_tiles = g.B * g.nTZ * g.nTY * g.nTX;
+  const int tile_first = (blockIdx.x / n_groups) * tiles_per_wg;
+  const int tile_count = min(tiles_per_wg, n_tiles - tile_first);
+  const int nchunks = c_in / CK;
+  const int n_items = tile_count * nchunks;
+  const int Zi = g.Zi, Yi = g.Yi, Xi = g.Xi, HX = g.HX, HY = g.HY, HXr = g.HXr, HXh = g.HXh;
+  const int nTX = g.nTX, nTY = g.nTY, nTZ = g.nTZ, eTZ = g.eTZ, TYs = g.TY, TXs = g.TX;
+  const int TXm = g.TX - 1, TYm = g.TY - 1, lTX = g.lTX, lTXY = g.lTX + g.lTY;
+  const float rHX = g.rHX, rHY = g.rHY;
+  const int total = g.HZ * HY * HX * QPR;
+  const int quad = tid & (QPR - 1);
+
+  int rowbase;
+  {
+    const int q = wave * 32 + i;
+    const int cx = q & TXm, cy = (q >> lTX) & TYm, cz = q >> lTXY;
+    rowbase = ((cz * 2) * HY + cy * 2) * HXr + cx;   // even box column 2 cx -> row cx of the even half
+    if (cz >= eTZ) rowbase = 0;
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const int nbtot = c_out >> 5;
+  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane;
+  const int64_t wc8 = (int64_t)nbtot * 3 * 64;        // fragments per 8-channel chunk
+  const int64_t wpair = (int64_t)nchunks * wc8;       // fragments per tap pair
+
+  auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % nTX;
+    tile /= nTX;
+    const int ty = tile % nTY;
+    tile /= nTY;
+    b = tile / nTZ;
+    z0 = (tile % nTZ) * eTZ, y0 = ty * TYs, x0 = tx * TXs;
+  };
+  // box row of tap t relative to the cell's row (taps past 26: any row, their weights are zero)
+  auto tap_delta = [&](int t) __attribute__((always_inline)) {
+    t = t < 27 ? t : 26;
+    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+    return (kz * HY + ky) * HXr + (kx & 1) * HXh + (kx >> 1);
+  };
+
+  float4 pf[PFN], pm[MASKED ? PFN : 1];
+  unsigned okbits = 0;
+  auto fetch = [&](int tl, int ck) __attribute__((always_inline)) {
+    int b, z0, y0, x0;
+    tile_origin(tile_first + tl, b, z0, y0, x0);
+    const int hz0 = 2 * z0 - 1, hy0 = 2 * y0 - 1, hx0 = 2 * x0 - 1;
+    const int c0 = ck * CK + quad * 4;
+    okbits = 0;
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      int hx, hy, hz;
+      decode_row(idx / QPR, HX, HY, rHX, rHY, hz, hy, hx);
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      const bool ok = idx < total && iz >= 0 && iz < Zi && iy >= 0 && iy < Yi && ix >= 0 && ix < Xi;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MASKED) pm[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (ok) {
+        const int64_t off = ((((int64_t)b * Zi + iz) * Yi + iy) * Xi + ix) * c_in + c0;
+        pf[u] = ld4g(X + off);
+        if (MASKED) pm[u] = ld4g(mask_src + off);
+        okbits |= 1u << u;
+      }
+    }
+  };
+  auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int idx = tid + u * 256;
+      if (idx >= total) continue;
+      int hx, hy, hz;
+      decode_row(idx / QPR, HX, HY, rHX, rHY, hz, hy, hx);
+      const int xr = (hx & 1) * HXh + (hx >> 1);
+      float4 v = pf[u];
+      if (MASKED && ((okbits >> u) & 1u)) keep_positive(v, pm[u]);
+      const float x[4] = {v.x, v.y, v.z, v.w};
+      float r1[4], r2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
+      unsigned* d = sU + ((hz * HY + hy) * HXr + xr) * kRowS + 2 * quad;
+      *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+      *reinterpret_cast<uint2*>(d + 4) = make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
+      *reinterpret_cast<uint2*>(d + 8) = make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
+    }
+  };
+
+  float* stage = sX + wave * (32 * kStagePad);
+  const int c4 = lane & 7, r8 = lane >> 3;
+
+  pv2::bf16x8 bq[2][NB][3], aq[2][3];
+  fetch(0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bq[0][nb][pc] = Wl[(nb * 3 + pc) * 64];   // item 0, pair 0
+  int tl = 0, ck = 0;
+  for (int item = 0; item < n_items; ++item) {
+    __syncthreads();
+    deposit();
+    __syncthreads();
+    const pv2::bf16x8* __restrict__ wck = Wl + (int64_t)ck * wc8;
+    const int ntl = ck + 1 < nchunks ? tl : tl + 1, nck = ck + 1 < nchunks ? ck + 1 : 0;
+    const pv2::bf16x8* __restrict__ wnext = Wl + (int64_t)nck * wc8;
+    {
+      const int row = rowbase + (h ? tap_delta(1) : tap_delta(0));
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        aq[0][pc] = *reinterpret_cast<const pv2::bf16x8*>(&sU[row * kRowS + 4 * pc]);
+    }
+    if (item + 1 < n_items) fetch(ntl, nck);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // tap pair tp on sets `cur`; requests for pair tp + 1 (past the last: the next item's first weights)
+    auto pair = [&](int tp1, auto cur_tag) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+      constexpr int kOther = 0x002 | 0x004 | 0x020 | 0x100;
+      if (tp1 < NPAIR) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wck[tp1 * wpair + (nb * 3 + pc) * 64];
+        const int row = rowbase + (h ? tap_delta(2 * tp1 + 1) : tap_delta(2 * tp1));
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          aq[nxt][pc] = *reinterpret_cast<const pv2::bf16x8*>(&sU[row * kRowS + 4 * pc]);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[nxt][nb][pc] = wnext[(nb * 3 + pc) * 64];
+      }
+#define PV2_TERM(ta, tb) \
+  _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = pv2::mfma_bf16(aq[cur][ta], bq[cur][nb][tb], acc[nb]);
+      PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+#pragma unroll
+      for (int k = 0; k < 6 * NB; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kOther, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int tp = 0; tp < NPAIR; tp += 2) {
+      pair(tp + 1, std::integral_constant<int, 0>());
+      pair(tp + 2, std::integral_constant<int, 1>());   // (tp + 2 == 14: the next item's first weights into set 0)
+    }
+
+    if (ck + 1 == nchunks) {
+      __syncthreads();
+      int b, z0, y0, x0;
+      tile_origin(tile_first + tl, b, z0, y0, x0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc_to_stage(stage, acc[nb], i, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const int n = (grp * NB + nb) * 32 + 4 * c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = r8 + 8 * j;
+          const int q = wave * 32 + m;
+          const int cz = q >> lTXY;
+          const int oz = z0 + cz, oy = y0 + ((q >> lTX) & TYm), ox = x0 + (q & TXm);
+          float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
+          if (cz >= eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
+          const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+          if (out_mask_src != nullptr) keep_positive(v, ld4g(out_mask_src + off));
+          *reinterpret_cast<float4*>(Y + off) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    tl = ntl, ck = nck;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dconvT_kernel on the bf16 matrix cores (mfma_split.h): the coarse box in three bf16 pieces per cell
 // (28-dword rows, as dconv_split_kernel), weights pre-cut (dconv_pack_split_kernel, out = C_out of the
 // transposed conv); per tap ONE class accumulator takes six MFMAs; the neighbour's cells come from LDS
@@ -1202,6 +1407,38 @@ __global__ __launch_bounds__(256) void dconv_pack_split_kernel(
   dst[2 * 64 * 4] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
 }
 
+// Wq[tp][c8][nb][piece][lane][d]: the pieces of W[out = nb*32 + (lane & 31)][red = c8*8 + 2d (+1)][tap],
+// tap = 2 tp + (lane >> 5); zeros for tap 27 (dconv_strided_split_kernel).
+__global__ __launch_bounds__(256) void dconv_pack_split2_kernel(
+    const float* __restrict__ W, int n_out, int n_red, int64_t s_out, int64_t s_red, int64_t s_z,
+    int64_t s_y, int64_t s_x, int flip, unsigned* __restrict__ packed) {
+  const int nbtot = n_out >> 5, nc8 = n_red >> 3;
+  const int64_t total = (int64_t)14 * nc8 * nbtot * 256;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int d = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  int64_t rest = e >> 8;
+  const int nb = (int)(rest % nbtot);
+  rest /= nbtot;
+  const int c8 = (int)(rest % nc8);
+  const int tp = (int)(rest / nc8);
+  const int t = 2 * tp + (lane >> 5);
+  float a = 0.f, b = 0.f;
+  if (t < 27) {
+    const int tap = flip ? 26 - t : t;
+    const int out = nb * 32 + (lane & 31);
+    const int red = c8 * 8 + 2 * d;
+    const float* src = W + out * s_out + red * s_red + (tap / 9) * s_z + ((tap / 3) % 3) * s_y + (tap % 3) * s_x;
+    a = src[0], b = src[s_red];
+  }
+  const float a1 = pv2::bf16_rest(a), b1 = pv2::bf16_rest(b);
+  unsigned* dst = packed + ((((int64_t)tp * nc8 + c8) * nbtot + nb) * 3 * 64 + lane) * 4 + d;
+  dst[0] = pv2::pack_hi(a, b);
+  dst[64 * 4] = pv2::pack_hi(a1, b1);
+  dst[2 * 64 * 4] = pv2::pack_hi(pv2::bf16_rest(a1), pv2::bf16_rest(b1));
+}
+
 int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -1251,11 +1488,11 @@ int env_int(const char* name, int fallback) {
   return e ? atoi(e) : fallback;
 }
 
-// the conv k3 s1 p1 and the transposed conv run on the bf16 matrix cores (dconv_split_kernel,
-// dconvT_split_kernel) unless PV2_FP32_MFMA=1
+// every dense convolution runs on the bf16 matrix cores (dconv_split_kernel, dconvT_split_kernel,
+// dconv_strided_split_kernel) unless PV2_FP32_MFMA=1
 bool split_conv(int mode) {
   static const bool on = env_int("PV2_FP32_MFMA", 0) != 1;
-  return on && (mode == 0 || mode == 1);
+  return on && mode >= 0 && mode <= 2;
 }
 
 }  // namespace
@@ -1265,7 +1502,8 @@ extern "C" {
 // (mode: the pv2_dconv3_forward mode the packed weight is for - the formats differ)
 int64_t pv2_dconv3_packed_floats(int c_out, int c_in, int mode) {
   const int64_t n = (int64_t)27 * c_out * c_in;
-  return split_conv(mode) ? n * 3 / 2 : n;   // three bf16 pieces per weight
+  if (split_conv(mode)) return (mode == 2 ? (int64_t)28 * c_out * c_in : n) * 3 / 2;   // three bf16 pieces
+  return n;                                                       // per weight; mode 2: 14 tap pairs
 }
 
 int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
@@ -1275,6 +1513,13 @@ int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out,
   PV2_REQUIRE(n_out > 0 && n_out % 32 == 0 && n_red > 0 && n_red % 16 == 0,
               "dconv3_pack_weights: output channels must be a multiple of 32, reduction channels of 16");
   PV2_REQUIRE(mode >= 0 && mode <= 2, "dconv3_pack_weights: mode must be 0, 1 or 2");
+  if (split_conv(mode) && mode == 2) {
+    const int64_t items = (int64_t)14 * (n_red / 8) * (n_out / 32) * 256;
+    hipLaunchKernelGGL(dconv_pack_split2_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, n_out, n_red, s_out, s_red, s_z, s_y, s_x, flip,
+                       reinterpret_cast<unsigned*>(packed));
+    return pv2::check_launch("dconv3_pack_weights(split, tap pairs)");
+  }
   if (split_conv(mode)) {
     const int64_t items = (int64_t)27 * n_out * n_red / 2;
     hipLaunchKernelGGL(dconv_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
@@ -1352,7 +1597,7 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   }
   g.HXr = g.xsplit ? 2 * g.HXh : g.HX;
   g.rHX = 1.0f / (float)g.HX, g.rHY = 1.0f / (float)g.HY;
-  size_t lds = (size_t)g.HZ * g.HY * g.HXr * (split ? kRowW : ck + 4) * sizeof(float);
+  size_t lds = (size_t)g.HZ * g.HY * g.HXr * (!split ? ck + 4 : mode == 2 ? kRowS : kRowW) * sizeof(float);
   const size_t epilogue = (size_t)4 * 32 * kStagePad * sizeof(float);
   if (lds < epilogue) lds = epilogue;
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
@@ -1392,6 +1637,26 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     else PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, false);         \
   } while (0)
   PV2_REQUIRE(pfn <= 13, "dconv3_forward: halo box larger than the register prefetch");
+  if (split && mode == 2) {
+    PV2_REQUIRE(in_scale == nullptr && bias == nullptr && addend == nullptr && relu == 0,
+                "dconv3_forward: mode 2 takes the masks only");
+    const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
+#define PV2_DSTRIDE_LAUNCH(NB_, MASKED_)                                                                \
+  do {                                                                                                  \
+    if (int e = set_lds(dconv_strided_split_kernel<NB_, 13, MASKED_>, lds)) return e;                   \
+    hipLaunchKernelGGL((dconv_strided_split_kernel<NB_, 13, MASKED_>), grid, dim3(256), lds, s, x, g,   \
+                       c_in, wq, c_out, n_groups, tpw, in_mask_src, out_mask_src, out);                 \
+  } while (0)
+    if (nb == 2) {
+      if (masked) PV2_DSTRIDE_LAUNCH(2, true);
+      else PV2_DSTRIDE_LAUNCH(2, false);
+    } else {
+      if (masked) PV2_DSTRIDE_LAUNCH(1, true);
+      else PV2_DSTRIDE_LAUNCH(1, false);
+    }
+#undef PV2_DSTRIDE_LAUNCH
+    return pv2::check_launch("dconv3_forward(strided, split)");
+  }
   if (split) {
     const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
 #define PV2_DSPLIT_LAUNCH_MT(NB_, MT_, PFN_, MASKED_)                                                     \
