@@ -39,7 +39,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 
 SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 SPLIT_ON = os.environ.get("PV2_FP32_MFMA") != "1"
 SPLIT_FAMILIES = ("spconv_fwd_lds_kernel", "spconv_wgrad_split_kernel", "dconv_split_kernel",
-                  "dconvT_split_kernel", "dconv_strided_split_kernel")
+                  "dconvT_split_kernel", "dconv_strided_split_kernel", "dconv_wgrad_split_kernel")
 
 
 def mfma_peak_of(family, default):
@@ -625,8 +625,23 @@ class KernelTimer:
             return rc
 
         handle.pv2_dconv3_forward = timed_dconv
-        wrap_c("pv2_dconv3_backward_weight", "dconv_wgrad_kernel + dconv_wgrad_reduce_kernel (dense conv weight "
-               "gradient, two-stage, deterministic)", dconv_wgrad_cost)
+        orig_dwgrad = handle.pv2_dconv3_backward_weight
+        self._orig_c["pv2_dconv3_backward_weight"] = orig_dwgrad
+        wfam_by_mode = {0: ("dconv_wgrad_split_kernel" if SPLIT_ON else "dconv_wgrad_kernel") +
+                           " + dconv_wgrad_reduce_kernel (dense conv weight gradient, two-stage, deterministic)",
+                        1: "dconv_wgrad_kernel + dconv_wgrad_reduce_kernel (transposed conv weight gradient, "
+                           "two-stage, deterministic)"}
+
+        def timed_dwgrad(*a):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            rc = orig_dwgrad(*a)
+            e_.record()
+            c = dconv_wgrad_cost(*a)
+            timer._add(wfam_by_mode[a[11]], s_, e_, c[0], c[1], None)
+            return rc
+
+        handle.pv2_dconv3_backward_weight = timed_dwgrad
         wrap("spconv_forward", "spconv_fwd_kernel (fwd+dgrad)", conv_cost)
         wrap("spconv_grad_input", "spconv_fwd_kernel (fwd+dgrad)", dgrad_cost)
         wrap("spconv_backward_weight", "spconv_wgrad_kernel", wgrad_cost)

@@ -1334,6 +1334,198 @@ __global__ __launch_bounds__(kWgThreads) void dconv_wgrad_kernel(
   else run(std::integral_constant<int, 2>());
 }
 
+// ---------------------------------------------------------------------------------------------
+// The weight gradient on the bf16 matrix cores.  The reduction runs over CELLS, and a lane of
+// v_mfma_f32_32x32x16_bf16 owns eight consecutive reduction steps of one channel - a column of the
+// [cell][channel] boxes.  The boxes are stored as bf16 pieces, [cell][piece][32 channels] (192 bytes
+// per cell), and a fragment is gathered with eight 2-byte LDS reads (lanes = channels: 64 contiguous
+// bytes per cell, no bank conflicts; immediate offsets - the eight cells are consecutive along x)
+// and four v_lshl_or: any tap shift costs nothing, nothing is transposed on the way in.  Per 16-cell
+// step and tap: six MFMAs against 24 + 24 narrow reads - the matrix pipe stays the bound (1536
+// against ~960 cycles per step and CU for the eight waves).  Same tiling, partial slabs and ordered
+// reduction as dconv_wgrad_kernel; tiles are half as large (the pieces take 1.5 x the LDS).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCellU16 = 96;   // ushorts per cell row: 3 pieces x 32 channels
+
+template <int XI, int GI, bool SHARED_A>
+__global__ __launch_bounds__(kWgThreads) void dconv_wgrad_split_kernel(
+    const float* __restrict__ X, int c_x, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, const float* __restrict__ G, int c_g,
+    const float* __restrict__ mask_src, WGeom geom, int n_tiles, int n_nblk, int n_cblk,
+    float* __restrict__ part) {
+  constexpr int GMUL = SHARED_A ? 1 : 2;   // G rows per iteration cell along each axis
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Zx = geom.Zx, Yx = geom.Yx, Xx = geom.Xx, Zg = geom.Zg, Yg = geom.Yg, Xg = geom.Xg;
+  const int TXm = geom.TX - 1, TYm = geom.TY - 1, lTX = geom.lTX, lTXY = geom.lTX + geom.lTY;
+  const int TYs = geom.TY, TXs = geom.TX, eTZ = geom.eTZ;
+  const int nTX = geom.nTX, nTY = geom.nTY, nTZ = geom.nTZ;
+  const int HY = geom.HY, HX = geom.HX, GY = geom.GY, GX = geom.GX;
+  const int x_mul = geom.x_mul, x_off = geom.x_off;
+  const int xrows = geom.HZ * HY * HX, grows = geom.GZ * GY * GX;
+  const int ncell = geom.TZ * geom.TY * geom.TX;
+  const bool transposed = geom.transposed != 0;
+  unsigned short* sXw = reinterpret_cast<unsigned short*>(smem);   // [xrows][3][32]
+  unsigned short* sG = sXw + xrows * kCellU16;                      // [grows][3][32]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int t0 = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 * wave : 16 + 3 * (wave - 4));
+  const int cnt = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 : (wave < 7 ? 3 : 2));
+  const int per_slot = n_nblk * n_cblk;
+  const int slot = blockIdx.x / per_slot, sub = blockIdx.x % per_slot;
+  const int n_slots = gridDim.x / per_slot;
+  const int nblk = sub / n_cblk, cblk = sub % n_cblk;
+  const int n0 = nblk * 32, c0 = cblk * 32;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+  int dXu[4], dGu[4];   // row deltas of this wave's taps, in ushorts
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = t0 + u < 27 ? t0 + u : 26;
+    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+    if (transposed) {
+      dXu[u] = (((kz == 0) * HY + (ky == 0)) * HX + (kx == 0)) * kCellU16;
+      dGu[u] = (((kz != 1) * GY + (ky != 1)) * GX + (kx != 1)) * kCellU16;
+    } else {
+      dXu[u] = ((kz * HY + ky) * HX + kx) * kCellU16;
+      dGu[u] = 0;
+    }
+  }
+
+  const int oct = tid & 7;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in_scale != nullptr) {
+    sc = ld4g(in_scale + c0 + oct * 4);
+    sh = ld4g(in_shift + c0 + oct * 4);
+  }
+
+  float4 px[XI], pg[GI], pm[GI];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int tt = tile;
+    const int tx = tt % nTX;
+    tt /= nTX;
+    const int ty = tt % nTY;
+    tt /= nTY;
+    const int tz = tt % nTZ;
+    const int b = tt / nTZ;
+    const int z0 = tz * eTZ, y0 = ty * TYs, x0 = tx * TXs;
+    const int hz0 = z0 * x_mul + x_off, hy0 = y0 * x_mul + x_off, hx0 = x0 * x_mul + x_off;
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      const int row = idx >> 3;
+      const int hx = row % HX;
+      const int t2 = row / HX;
+      const int hy = t2 % HY, hz = t2 / HY;
+      const int iz = hz0 + hz, iy = hy0 + hy, ix = hx0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < xrows && iz >= 0 && iz < Zx && iy >= 0 && iy < Yx && ix >= 0 && ix < Xx) {
+        v = ld4g(X + ((((int64_t)b * Zx + iz) * Yx + iy) * Xx + ix) * c_x + c0 + oct * 4);
+        if (in_scale != nullptr) affine4(v, sc, sh);
+      }
+      px[u] = v;
+    }
+    const int gz0 = z0 * GMUL, gy0 = y0 * GMUL, gx0 = x0 * GMUL;
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      const int row = idx >> 3;
+      const int hx = row % GX;
+      const int t2 = row / GX;
+      const int hy = t2 % GY, hz = t2 / GY;
+      const int iz = gz0 + hz, iy = gy0 + hy, ix = gx0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (row < grows && iz < Zg && iy < Yg && ix < Xg) {
+        const int64_t off = ((((int64_t)b * Zg + iz) * Yg + iy) * Xg + ix) * c_g + n0 + oct * 4;
+        v = ld4g(G + off);
+        if (mask_src != nullptr) m = ld4g(mask_src + off);
+      }
+      pg[u] = v;
+      pm[u] = m;
+    }
+  };
+  auto put = [&](unsigned short* box, int idx, const float4& v) __attribute__((always_inline)) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float r1[4], r2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r1[j] = pv2::bf16_rest(x[j]), r2[j] = pv2::bf16_rest(r1[j]);
+    unsigned* d = reinterpret_cast<unsigned*>(box + (idx >> 3) * kCellU16) + 2 * (idx & 7);
+    *reinterpret_cast<uint2*>(d) = make_uint2(pv2::pack_hi(x[0], x[1]), pv2::pack_hi(x[2], x[3]));
+    *reinterpret_cast<uint2*>(d + 16) = make_uint2(pv2::pack_hi(r1[0], r1[1]), pv2::pack_hi(r1[2], r1[3]));
+    *reinterpret_cast<uint2*>(d + 32) = make_uint2(pv2::pack_hi(r2[0], r2[1]), pv2::pack_hi(r2[2], r2[3]));
+  };
+  auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      if ((idx >> 3) < xrows) put(sXw, idx, px[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+      const int idx = tid + u * kWgThreads;
+      if ((idx >> 3) < grows) {
+        float4 v = pg[u];
+        keep_positive(v, pm[u]);
+        put(sG, idx, v);
+      }
+    }
+  };
+  // eight cells of one piece: cells along x are STEP rows apart
+  auto frag = [&](const unsigned short* p, int step_u16) __attribute__((always_inline)) {
+    pv2::u32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      a[j] = (unsigned)p[(2 * j) * step_u16] | ((unsigned)p[(2 * j + 1) * step_u16] << 16);
+    return __builtin_bit_cast(pv2::bf16x8, a);
+  };
+
+  auto run = [&](auto cnt_tag) __attribute__((always_inline)) {
+    constexpr int CNT = decltype(cnt_tag)::value;
+    if (slot < n_tiles) fetch(slot);
+    const int nstep = ncell >> 4;   // 16-cell reduction steps (TX is a multiple of 16)
+    for (int tile = slot; tile < n_tiles; tile += n_slots) {
+      __syncthreads();
+      deposit();
+      __syncthreads();
+      if (tile + n_slots < n_tiles) fetch(tile + n_slots);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+      for (int sidx = 0; sidx < nstep; ++sidx) {
+        const int q0 = 16 * sidx;
+        const int cx = q0 & TXm, cy = (q0 >> lTX) & TYm, cz = q0 >> lTXY;
+        if (cz >= eTZ) break;   // (tiles of grids smaller than a full tile: wave-uniform)
+        const unsigned short* xr = sXw + ((cz * HY + cy) * HX + cx + 8 * h) * kCellU16 + i;
+        const unsigned short* gr = sG + (((cz * GMUL) * GY + cy * GMUL) * GX + (cx + 8 * h) * GMUL) * kCellU16 + i;
+        pv2::bf16x8 fa[SHARED_A ? 1 : CNT][3], fb[CNT][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          if (SHARED_A) fa[0][pc] = frag(gr + pc * 32, GMUL * kCellU16);
+#pragma unroll
+          for (int u = 0; u < CNT; ++u) {
+            if (!SHARED_A) fa[u][pc] = frag(gr + dGu[u] + pc * 32, GMUL * kCellU16);
+            fb[u][pc] = frag(xr + dXu[u] + pc * 32, kCellU16);
+          }
+        }
+#define PV2_TERM(ta, tb) \
+  _Pragma("unroll") for (int u = 0; u < CNT; ++u) acc[u] = pv2::mfma_bf16(fa[SHARED_A ? 0 : u][ta], fb[u][tb], acc[u]);
+        PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+      }
+    }
+    float* dst = part + ((int64_t)blockIdx.x * 28 + t0) * 1024;
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dst[u * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[u][r];
+  };
+  if (cnt == 4) run(std::integral_constant<int, 4>());
+  else if (cnt == 3) run(std::integral_constant<int, 3>());
+  else run(std::integral_constant<int, 2>());
+}
+
 // dW[n, c, t] = sum over the slots' partial slabs, in ascending order; written with the
 // strides of the caller's weight tensor (Conv3d [n, c, kz, ky, kx] or ConvTranspose3d [c, n, ...],
 // either memory format).
@@ -1711,9 +1903,10 @@ static int wgrad_geometry(int b, int z, int y, int xx, int c_x, int c_g, int mod
   g->B = b;
   g->Zx = z, g->Yx = y, g->Xx = xx;
   g->Zt = z, g->Yt = y, g->Xt = xx;
+  const bool split = split_conv(mode);
   if (mode == 0) {
     g->Zg = z, g->Yg = y, g->Xg = xx;
-    pick_tile(256, z, y, xx, &g->TZ, &g->eTZ, &g->TY, &g->TX);
+    pick_tile(split ? 128 : 256, z, y, xx, &g->TZ, &g->eTZ, &g->TY, &g->TX);
     g->HZ = g->eTZ + 2, g->HY = g->TY + 2, g->HX = g->TX + 2;
     g->x_mul = 1, g->x_off = -1;
     g->GZ = g->eTZ, g->GY = g->TY, g->GX = g->TX;
@@ -1766,10 +1959,34 @@ int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int 
   wgrad_geometry(b, z, y, xx, c_x, c_g, mode, &g, &n_tiles, &n_slots);
   const int n_nblk = c_g / 32, n_cblk = c_x / 32;
   const int xrows = g.HZ * g.HY * g.HX, grows = g.GZ * g.GY * g.GX;
-  const size_t lds = ((size_t)xrows + grows) * 32 * sizeof(float);
+  // (mode 0 only: the transposed conv's taps each read their own gradient rows - 48 narrow LDS reads per
+  // six MFMAs is more than the LDS issues; measured 1.3 x slower than the fp32 kernel)
+  const bool split = split_conv(mode) && mode == 0 && g.TX % 16 == 0;
+  const size_t lds = ((size_t)xrows + grows) * (split ? kCellU16 * sizeof(unsigned short) : 32 * sizeof(float));
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_backward_weight: tiles do not fit the LDS");
   const int xi = (xrows * 8 + kWgThreads - 1) / kWgThreads, gi = (grows * 8 + kWgThreads - 1) / kWgThreads;
   const dim3 grid((unsigned)(n_slots * n_nblk * n_cblk));
+  if (split) {
+#define PV2_WSPLIT_LAUNCH(XI_, GI_, SA_)                                                                   \
+  do {                                                                                                     \
+    if (int e = set_lds(dconv_wgrad_split_kernel<XI_, GI_, SA_>, lds)) return e;                           \
+    hipLaunchKernelGGL((dconv_wgrad_split_kernel<XI_, GI_, SA_>), grid, dim3(kWgThreads), lds, s, x, c_x,  \
+                       in_scale, in_shift, gy, c_g, gy_mask_src, g, n_tiles, n_nblk, n_cblk, partial_ws);  \
+  } while (0)
+    bool launched = true;
+    if (xi <= 9 && gi <= 2) PV2_WSPLIT_LAUNCH(9, 2, true);
+    else if (xi <= 13 && gi <= 4) PV2_WSPLIT_LAUNCH(13, 4, true);
+    else launched = false;
+#undef PV2_WSPLIT_LAUNCH
+    if (launched) {
+      const int64_t total = (int64_t)27 * c_g * c_x;
+      hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                         partial_ws, n_slots, n_nblk, n_cblk, c_g, c_x, s_n, s_c, s_z, s_y, s_x, dw);
+      return pv2::check_launch("dconv3_backward_weight(split)");
+    }
+    pv2::set_error("dconv3_backward_weight: no split kernel variant for this tile geometry");
+    return PV2_E_UNSUPPORTED;
+  }
 #define PV2_WGRAD_LAUNCH(XI_, GI_, SA_)                                                              \
   do {                                                                                               \
     if (int e = set_lds(dconv_wgrad_kernel<XI_, GI_, SA_>, lds)) return e;                           \
