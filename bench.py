@@ -1048,6 +1048,7 @@ def main():
                                               F32_MFMA_PEAK_TFLOPS, dom["tflops"] / F32_MFMA_PEAK_TFLOPS)
                                           if dom["mfma_peak_tflops"] == SPLIT_MFMA_PEAK_TFLOPS else
                                           "dense MFMA peak of the kernel's operand type"),
+                                      "frac_vs_f32_mfma_peak": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
                                       "hbm_frac_of_alg_bytes": dom.get("frac_of_hbm_peak"),
                                       "traffic": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[0],
                                       "traffic_source": pmc_traffic(dom["kernel"].split(" (")[0].rstrip(">"))[1],
