@@ -38,6 +38,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 
 # the matrix roofline of those kernels, in fp32-equivalent (= algorithmic) TFLOP/s
 SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 SPLIT_ON = os.environ.get("PV2_FP32_MFMA") != "1"
+SKIP_SYNC = os.environ.get("PV2_BENCH_SKIP_SYNC") == "1"   # (diagnosis: process group present, no reduction)
 SPLIT_FAMILIES = ("spconv_fwd_lds_kernel", "spconv_wgrad_split_kernel", "dconv_split_kernel",
                   "dconvT_split_kernel", "dconv_strided_split_kernel", "dconv_wgrad_split_kernel")
 
@@ -912,7 +913,7 @@ def main():
             scaler.update()
         else:
             out["loss"].backward()
-            if gsync is not None:
+            if gsync is not None and not SKIP_SYNC:
                 gsync.sync()
             opt.step()
         sched.step()

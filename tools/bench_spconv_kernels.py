@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Micro-benchmark + ablations of the sparse-conv kernels on the bench scene (2 scenes)."""
+"""Micro-benchmark of the sparse-conv kernels on the bench scene (2 scenes): scatter-add forward, the
+product-row route and the weight gradient per layer shape (PV2_FP32_MFMA=1: the fp32-MFMA kernels)."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,11 +38,9 @@ for lvl, cin, cout in cases:
     out = torch.zeros(rb.n_out, cout, device=dev)
     g = torch.randn(rb.n_out, cout, device=dev)
     fl = 2.0 * rb.n_pairs * cin * cout
-    row = []
-    for ab in (0, 1, 2, 3):
-        L.pv2_debug_set_ablate(ab)
-        t = timeit(lambda: K.spconv_forward(x, w, rb, out=out))
-        row.append("abl%d %.1fus %.1fTF" % (ab, t, fl / t / 1e6))
-    L.pv2_debug_set_ablate(0)
+    t = timeit(lambda: K.spconv_forward(x, w, rb, out=out))
+    row = ["%.1fus %.1fTF" % (t, fl / t / 1e6)]
+    tp = timeit(lambda: K.spconv_forward(x, w, rb))          # product rows + ordered reduce (default route)
+    row.append("pr %.1fus %.1fTF" % (tp, fl / tp / 1e6))
     tw = timeit(lambda: K.spconv_backward_weight(x, g, rb, cout))
     print("L%d %3d->%3d pairs %6d | fwd: %s | wgrad %.1fus %.1fTF" % (lvl, cin, cout, rb.n_pairs, " | ".join(row), tw, fl / tw / 1e6))
