@@ -313,6 +313,9 @@ def _mask_order(tbl: torch.Tensor, K: int, n_cols: int, stride: int) -> Optional
     return torch.argsort(mask, stable=True).to(torch.int32)
 
 
+_RAMPS = {}
+
+
 def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     """coords int32 [N,4] (b,x,y,z) -> rulebook of a submanifold conv with an odd cubic kernel."""
     _require_device(coords)
@@ -322,10 +325,14 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
     dev = coords.device
     K = ksize ** 3
     if ksize == 1:
-        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        # (rows 0..n-1 of one cached ramp per device, and [0, n] as ramp[:2] * n: one launch per
+        # identity rulebook instead of three - four of them per forward pass)
+        ramp = _RAMPS.get(dev)
+        if ramp is None or ramp.numel() < max(n, 2):
+            ramp = _RAMPS[dev] = torch.arange(max(2 * n, 1 << 16), dtype=torch.int32, device=dev)
+        ar = ramp[:n]
         kh = np.array([0, n], dtype=np.int64)
-        kstart = torch.zeros(2, dtype=torch.int32, device=dev)
-        kstart[1:] = n  # (a fill kernel, not a host->device copy)
+        kstart = ramp[:2] * n
         rb = Rulebook(1, n, n, ar, ar, kstart, kh, center_k=0)
         rb.nbr, rb.nbr_stride = ar, n
         rb._transposed_os = (ar, n, None, 0)
