@@ -486,12 +486,39 @@ def field_render(vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_
 # --------------------------------------------------------------------------------------------
 # model glue
 # --------------------------------------------------------------------------------------------
+class _ZeroOf(torch.autograd.Function):
+    """``sum_i (p_i.sum() * 0.0)`` - the reference's ``fc_p(points) * 0.0`` terms (decoders.py:27,64,99): an
+    exact zero whose graph hands every ``p_i`` a gradient of zeros (so the optimiser treats the
+    parameter exactly as the reference's does: weight decay included).  No forward launch; one fill
+    per parameter backward - the torch expression cost four launches per decoder each way."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.like = [(p.shape, p.dtype, p.device) for p in params]
+        return _zero_scalar(params[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(torch.zeros(shape, dtype=dtype, device=dev) for shape, dtype, dev in ctx.like)
+
+
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(like):
+    """A fresh 0-dim view of a cached zero (never written to: the callers only add it)."""
+    key = (like.device, like.dtype)
+    z = _ZERO_SCALARS.get(key)
+    if z is None:
+        z = _ZERO_SCALARS[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+    return z.view(())
+
+
 def collapse(field):
     """Collapsed parameters of the SDF and colour heads (differentiable torch ops)."""
     sd, rd = field.sdf_decoder, field.rgb_decoder
-    zero = 0.0
-    for dec in (sd, rd):  # fc_p(points) * 0.0 of the reference: an exact zero with a graph
-        zero = zero + (dec.fc_p.weight.sum() + dec.fc_p.bias.sum()) * 0.0
+    # fc_p(points) * 0.0 of the reference: an exact zero with a graph
+    zero = _ZeroOf.apply(sd.fc_p.weight, sd.fc_p.bias, rd.fc_p.weight, rd.fc_p.bias)
     W0, b0 = sd.lin0.weight, sd.lin0.bias
     Wc0, bc0 = sd.fc_c[0].weight, sd.fc_c[0].bias
     Wc1, bc1 = sd.fc_c[1].weight, sd.fc_c[1].bias
@@ -550,26 +577,26 @@ def _render_outputs(model, ray_bundle, volume_feature):
         sdf, grad, weights, comp = field_render_folded(vol5, wfp, *head)
     else:
         sdf, grad, weights, comp = field_render(vol5, *head)
-    wsum = comp[:, COL_ONE:COL_ONE + 1]
+    # ONE split of the composite row (its backward is one cat - six slices cost a zero-fill, a copy and
+    # an add each): columns f'(64) geo(64) grad(3) normal(3) rgb(3) t 1 pad
+    f2c, geoc, g3c, nrm, rgbc, tcol, wsum, _ = comp.split([F2, G, 3, 3, 3, 1, 1, NV - COL_ONE - 1], dim=1)
     out = {}
-    rgb = comp[:, COL_RGB:COL_RGB + 3]
-    bg = device_constant(model.rgb_renderer.background_color, dev, rgb.dtype)
-    rgb = rgb + bg * (1.0 - wsum)
+    bg = device_constant(model.rgb_renderer.background_color, dev, comp.dtype)
+    rgb = torch.addcmul(rgbc + bg, wsum, bg, value=-1.0)      # rgb + bg * (1 - wsum)
     out["rgb"] = rgb if model.training else rgb.clamp(0.0, 1.0)
     md = field.semantic_decoder
     if md is not None:
-        xbar = torch.cat([comp[:, COL_G:COL_G + 3], comp[:, COL_F2:COL_F2 + F2],
-                          comp[:, COL_GEO:COL_GEO + G]], dim=1)
-        zero = (md.fc_p.weight.sum() + md.fc_p.bias.sum()) * 0.0
+        xbar = torch.cat([g3c, f2c, geoc], dim=1)
+        zero = _ZeroOf.apply(md.fc_p.weight, md.fc_p.bias)
         hidden = F.linear(xbar, md.fc_c[0].weight) + (md.fc_c[0].bias + zero) * wsum
         lin = md.last_linear
         out["semantic"] = F.linear(hidden, lin.weight) + lin.bias * wsum
-    depth = comp[:, COL_T:COL_T + 1] / (wsum + 1e-10)
-    per_scene = starts.reshape(B, -1)
-    lo = per_scene.amin(1).repeat_interleave(R // B).reshape(-1, 1)
-    hi = per_scene.amax(1).repeat_interleave(R // B).reshape(-1, 1)
-    out["depth"] = torch.maximum(torch.minimum(depth, hi), lo)
-    out["normal"] = comp[:, COL_N:COL_N + 3]
+    depth = tcol / (wsum + 1e-10)
+    lo, hi = torch.aminmax(starts.reshape(B, -1), dim=1)          # per scene: nearest / farthest sample
+    lo = lo[:, None].expand(B, R // B).reshape(-1, 1)
+    hi = hi[:, None].expand(B, R // B).reshape(-1, 1)
+    out["depth"] = torch.clamp(depth, lo, hi)
+    out["normal"] = nrm
     out.update(weights=weights.unsqueeze(-1), sdf=sdf.unsqueeze(-1), gradients=grad,
                z_vals=starts.unsqueeze(-1))
     if not model.training:
