@@ -140,7 +140,10 @@ class _CellsLevel(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[3]:
             if sidestream.active(g) and sidestream.safe_leaf(w):
-                dw = sidestream.fork(weight_gradient, (x, g, gu, stats, w, packs))
+                # (what the side stream reads must outlive this node: operands AND the rulebook's pair lists /
+                # tile prefixes - they are released with ctx as soon as backward() returns, and the
+                # allocator would hand their memory to the next request on the main stream)
+                dw = sidestream.fork(weight_gradient, (x, g, gu, stats, w, packs, cells, rb))
             else:
                 dw = weight_gradient()
         return dx, dgamma, dbeta, dw, dbias, None, None, None
