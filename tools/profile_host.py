@@ -125,6 +125,40 @@ torch.cuda.synchronize(); sec.clear()
 for _ in range(10): step()
 torch.cuda.synchronize()
 print("steady state, forward sections (host ms per step): " + " | ".join("%s %.2f" % (k.strip(), v * 100) for k, v in sec.items()), flush=True)
+# ... and the DEVICE clock of the training stream at the same boundaries (events; backward phases through
+# tensor hooks): per section, the time the stream spent = its kernels + whatever it waited for
+for nm in ("extract_feature", "prepare_ray", "prepare_volume", "render_func", "render_loss"):
+    pass
+evs = []
+def ev(name):
+    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append((name, e))
+def step_events():
+    evs.clear(); ev("start")
+    cur = staged.pop(); staged.append(stage())
+    model._ambient_amp = AMP
+    d = model.extract_feature(cur); ev("backbone_fwd")
+    ray, d = model.prepare_ray(d); ev("prepare_ray")
+    vol = model.prepare_volume(d); ev("prepare_volume")
+    out = model.render_func(ray, vol); ev("render")
+    res = model.render_loss(out, ray); ev("losses")
+    def mark(name, x):
+        x = getattr(x, "pre", x)
+        if torch.is_tensor(x) and x.requires_grad:
+            x.register_hook(lambda g, name=name: ev("bwd:" + name))
+    mark("render+losses", out["rgb"]); mark("field_render", vol[0]); mark("dense_unet+cells", d["sparse_backbone_feat"])
+    opt.zero_grad(set_to_none=True); res[0].backward(); ev("bwd:backbone")
+    opt.step(); ev("optimizer")
+for _ in range(3): step_events()
+tot = {}
+for _ in range(8):
+    step_events(); torch.cuda.synchronize()
+    seen = set()
+    for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
+        key = n1 if n1 not in seen else n1 + "'"
+        seen.add(n1)
+        tot[key] = tot.get(key, 0.0) + e0.elapsed_time(e1)
+print("device time of the training stream per section (ms per step, 8 steps, each step drained): "
+      + " | ".join("%s %.2f" % (k, v / 8) for k, v in tot.items()) + " | sum %.2f" % (sum(tot.values()) / 8), flush=True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
