@@ -893,8 +893,9 @@ def main():
             b = clone_batch(batches[i % len(batches)])
             if args.raw_points and "grid_coord" not in b:
                 b = device_grid_sample(b, grid_size=0.02, hash_type="fnv")
-            b = pipe.adopt(b)
-            return raw_model.prefetch(b) if lookahead else b
+            if lookahead:
+                b = raw_model.prefetch(b)
+            return pipe.adopt(b)
 
     staged = [stage(0)]
 

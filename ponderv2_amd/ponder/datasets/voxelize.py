@@ -228,9 +228,18 @@ class input_stream:
         import torch
 
         if self.on:
-            for v in batch.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(self.cur)
+            def mark(v):
+                if torch.is_tensor(v):
+                    if v.is_cuda:
+                        v.record_stream(self.cur)
+                elif isinstance(v, dict):       # (what a model's prefetch hook added: ray set-up, ...)
+                    for w in v.values():
+                        mark(w)
+                elif isinstance(v, (list, tuple)):
+                    for w in v:
+                        mark(w)
+
+            mark(batch)
         return batch
 
 

@@ -199,9 +199,9 @@ class Trainer(TrainerBase):
                          for k, v in batch.items()}
                 if self.cfg.get("device_voxelize"):
                     batch = device_grid_sample(batch, **self.cfg.device_voxelize)
-                batch = pipe.adopt(batch)
                 if hasattr(model, "prefetch"):
                     batch = model.prefetch(batch)
+                batch = pipe.adopt(batch)     # (after the hook: what it adds lives on this stream too)
         else:
             batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
                      for k, v in batch.items()}

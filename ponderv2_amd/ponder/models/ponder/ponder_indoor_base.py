@@ -36,6 +36,11 @@ from .masking import mask_blocks
 from .render_utils import RayBundle, build_renderer
 from .render_utils.rays import device_constant
 
+import os
+
+# the ray set-up rides with the batch's staging (PonderIndoor.prefetch); PV2_PREFETCH_RAYS=0: inside the step
+PREFETCH_RAYS = os.environ.get("PV2_PREFETCH_RAYS", "1") != "0"
+
 
 def stub_text_embeddings(num_classes, dim=512, seed=0):
     """Deterministic stand-in for CLIP text embeddings (no network / weights in this environment):
@@ -489,10 +494,19 @@ class PonderIndoor(nn.Module):
         return getattr(self, "_ambient_amp", None)
 
     def prefetch(self, data_dict):
-        """Input-pipeline hook: launch the sparse backbone's geometry for this (device-resident)
-        batch on the side stream (SpUNet.prefetch_geometry); trainers call it one batch ahead."""
+        """Input-pipeline hook, called one batch ahead on the input stream: launch the sparse backbone's
+        geometry for this (device-resident) batch on the geometry stream (SpUNet.prefetch_geometry) and,
+        in training, do the ray set-up (``prepare_ray``: scene normalisation, pixel choice, ray
+        generation - a function of the batch, constant tables and the random generator only; the
+        outdoor reference has it in its dataset transforms) so that it is off the training stream."""
         fn = getattr(self.backbone, "prefetch_geometry", None)
-        return fn(data_dict) if fn is not None else data_dict
+        if fn is not None:
+            data_dict = fn(data_dict)
+        if (PREFETCH_RAYS and self.training and "_ray_dict" not in data_dict
+                and ray_setup.usable(self, data_dict)):
+            ray_dict, data_dict = ray_setup.prepare_ray(self, data_dict)
+            data_dict["_ray_dict"] = ray_dict
+        return data_dict
 
     def forward(self, data_dict):
         """Under an ambient autocast region (the reference's ``enable_amp=True``) the reduced
@@ -508,7 +522,9 @@ class PonderIndoor(nn.Module):
 
     def _forward(self, data_dict):
         data_dict = self.extract_feature(data_dict)
-        ray_dict, data_dict = self.prepare_ray(data_dict)
+        ray_dict = data_dict.pop("_ray_dict", None)     # set up with the batch, one step ahead (prefetch)
+        if ray_dict is None:
+            ray_dict, data_dict = self.prepare_ray(data_dict)
         volume_feature = self.prepare_volume(data_dict)
         render_out = self.render_func(ray_dict, volume_feature)
         loss, loss_dict = self.render_loss(render_out, ray_dict)

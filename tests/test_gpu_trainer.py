@@ -82,3 +82,35 @@ def test_trainer_repeatable_on_device(tmp_path):
         err = (p.detach() - pa[n]).abs().max().item()
         assert err <= 1e-3 * pa[n].abs().max().item() + 1e-6, (n, err)
     print(f"{len(diff)} parameter tensors differ in the last bits between two seeded runs")
+
+
+def test_prefetched_ray_setup_equals_inline(device):
+    """``PonderIndoor.prefetch`` does the ray set-up with the batch (one step ahead, on the input stream);
+    the step must see the same rays and targets as when ``prepare_ray`` runs inside it."""
+    from ponderv2_amd.ponder.datasets import collate_fn
+    from ponderv2_amd.ponder.datasets.voxelize import input_stream
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.manual_seed(0)
+    model = build_model(ConfigDict(ddp_worker.tiny_model_cfg())).to(device).train()
+    batch = collate_fn([ddp_worker.tiny_scene(60), ddp_worker.tiny_scene(61)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    n = model.ray_nsample
+    B, V, H, W = batch["depth"].shape
+    g = torch.Generator().manual_seed(5)
+    batch["ray_pixels"] = torch.stack([torch.randint(0, H, (B, V, n), generator=g),
+                                       torch.randint(0, W, (B, V, n), generator=g)], -1).to(device)
+
+    def clone():
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    torch.manual_seed(1)
+    inline = model(clone())
+    with input_stream(device) as pipe:
+        staged = pipe.adopt(model.prefetch(clone()))
+    assert "_ray_dict" in staged
+    torch.manual_seed(1)
+    ahead = model(staged)
+    for k in inline:
+        torch.testing.assert_close(ahead[k], inline[k], rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")

@@ -26,7 +26,9 @@ def step(tag=False):
     with rf("phase:extract_feature(backbone fwd)"):
         d = model.extract_feature(cur)
     with rf("phase:prepare_ray"):
-        ray, d = model.prepare_ray(d)
+        ray = d.pop("_ray_dict", None)      # (set up with the batch when prefetched)
+        if ray is None:
+            ray, d = model.prepare_ray(d)
     with rf("phase:prepare_volume(to_dense + UNet3D)"):
         vol = model.prepare_volume(d)
     with rf("phase:render"):

@@ -24,8 +24,10 @@ PREFETCH = "--prefetch" in sys.argv
 from ponderv2_amd.ponder.datasets.voxelize import input_stream
 def stage():   # as bench.py / engines/train.py: on the input stream
     with input_stream(dev) as pipe:
-        b = pipe.adopt(bench.clone_batch(batch))
-        return model.prefetch(b) if PREFETCH else b
+        b = bench.clone_batch(batch)
+        if PREFETCH:
+            b = model.prefetch(b)
+        return pipe.adopt(b)
 staged = [stage()]
 def step():
     cur = staged.pop()
@@ -137,7 +139,10 @@ def step_events():
     cur = staged.pop(); staged.append(stage())
     model._ambient_amp = AMP
     d = model.extract_feature(cur); ev("backbone_fwd")
-    ray, d = model.prepare_ray(d); ev("prepare_ray")
+    ray = d.pop("_ray_dict", None)      # (set up with the batch when prefetched)
+    if ray is None:
+        ray, d = model.prepare_ray(d)
+    ev("prepare_ray")
     vol = model.prepare_volume(d); ev("prepare_volume")
     out = model.render_func(ray, vol); ev("render")
     res = model.render_loss(out, ray); ev("losses")
