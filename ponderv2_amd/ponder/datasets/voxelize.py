@@ -228,18 +228,10 @@ class input_stream:
         import torch
 
         if self.on:
-            def mark(v):
-                if torch.is_tensor(v):
-                    if v.is_cuda:
-                        v.record_stream(self.cur)
-                elif isinstance(v, dict):       # (what a model's prefetch hook added: ray set-up, ...)
-                    for w in v.values():
-                        mark(w)
-                elif isinstance(v, (list, tuple)):
-                    for w in v:
-                        mark(w)
+            # (tensors, and what a model's prefetch hook added: nested dicts / tuples / rulebooks)
+            from ponderv2_amd.kernels import _record_stream
 
-            mark(batch)
+            _record_stream(batch, self.cur)
         return batch
 
 

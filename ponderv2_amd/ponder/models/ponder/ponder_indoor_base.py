@@ -422,13 +422,16 @@ class PonderIndoor(nn.Module):
                 and getattr(self.proj_net, "cells_supported", lambda: True)())
 
     def prepare_volume(self, data_dict):
-        data_dict = self.grid_sample(data_dict)
+        if not data_dict.pop("_grid_sampled", False):   # (done with the batch's staging: prefetch)
+            data_dict = self.grid_sample(data_dict)
         if self._use_cells() and not self._small_scenes(data_dict):
             from .sparse_input import cells_from_voxels
 
             G0, G1, G2 = self.grid_shape
-            dense = cells_from_voxels(data_dict["sparse_backbone_feat"], self._dense_rows(data_dict),
-                                      data_dict["offset"].numel(), (G2, G1, G0))
+            geo = data_dict.pop("_cells_geometry", None)
+            lin = None if geo is not None else self._dense_rows(data_dict)
+            dense = cells_from_voxels(data_dict["sparse_backbone_feat"], lin,
+                                      data_dict["offset"].numel(), (G2, G1, G0), geometry=geo)
             project = self.proj_net.forward_cells
         else:
             dense = self.to_dense(data_dict)
@@ -506,6 +509,19 @@ class PonderIndoor(nn.Module):
                 and ray_setup.usable(self, data_dict)):
             ray_dict, data_dict = ray_setup.prepare_ray(self, data_dict)
             data_dict["_ray_dict"] = ray_dict
+            if self._use_cells():
+                # ... and the geometry of the projection network's first level (which cells are
+                # occupied, the cell -> grid-row pairs of its convolution): coordinates only
+                from .sparse_input import cells_geometry
+
+                with torch.no_grad():
+                    data_dict = self.grid_sample(data_dict)
+                    data_dict["_grid_sampled"] = True
+                    if not self._small_scenes(data_dict):
+                        G0, G1, G2 = self.grid_shape
+                        data_dict["_cells_geometry"] = cells_geometry(
+                            self._dense_rows(data_dict), data_dict["offset"].numel(), (G2, G1, G0),
+                            build_rulebook=True)
         return data_dict
 
     def forward(self, data_dict):

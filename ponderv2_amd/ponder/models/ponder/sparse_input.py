@@ -53,23 +53,37 @@ class DenseCells:
         return self._rulebook
 
 
-def cells_from_voxels(feat, lin, batch, dims, reduce="mean"):
-    """Pool per-voxel rows into their dense cells WITHOUT building the dense grid: a flag grid and
-    its prefix sum number the occupied cells.  No device->host read: the cell arrays are sized for
-    the worst case (one cell per voxel); rows past the true cell count are padding (``lin`` -1,
-    zero features), which every consumer skips."""
+def cells_geometry(lin, batch, dims, build_rulebook=False):
+    """The half of ``cells_from_voxels`` that only needs the voxels' dense rows: a flag grid and its
+    prefix sum number the occupied cells.  No device->host read: the cell arrays are sized for the
+    worst case (one cell per voxel); rows past the true cell count are padding (``lin`` -1), which
+    every consumer skips.  ``build_rulebook``: also the (cell, tap) pair lists of the first
+    convolution - all of it a function of the batch's coordinates, so a model's input-pipeline hook
+    can run it a step ahead (PonderIndoor.prefetch)."""
     z, y, x = dims
     total = batch * z * y * x
     cap = lin.shape[0]
-    flags = torch.zeros(total, dtype=torch.int32, device=feat.device)
+    flags = torch.zeros(total, dtype=torch.int32, device=lin.device)
     flags.index_fill_(0, lin, 1)
     cell_id = torch.cumsum(flags, 0, dtype=torch.int32)
     cell_of_voxel = cell_id[lin].long() - 1
-    cell_lin = torch.full((cap,), -1, dtype=torch.int64, device=feat.device)
+    cell_lin = torch.full((cap,), -1, dtype=torch.int64, device=lin.device)
     cell_lin[cell_of_voxel] = lin  # duplicates write the same value
-    pooled = scatter(feat, cell_of_voxel[:, None], dim=0, reduce=reduce,
+    geo = dict(cell_of_voxel=cell_of_voxel, cell_lin=cell_lin, batch=batch, dims=(z, y, x), rulebook=None)
+    if build_rulebook:
+        geo["rulebook"] = DenseCells(None, cell_lin, batch, (z, y, x)).rulebook()
+    return geo
+
+
+def cells_from_voxels(feat, lin, batch, dims, reduce="mean", geometry=None):
+    """Pool per-voxel rows into their dense cells WITHOUT building the dense grid (``cells_geometry``
+    - or its result from a step ahead - then one scatter-mean of the features; padding cells keep
+    zero features)."""
+    geo = geometry if geometry is not None else cells_geometry(lin, batch, dims)
+    cap = geo["cell_lin"].shape[0]
+    pooled = scatter(feat, geo["cell_of_voxel"][:, None], dim=0, reduce=reduce,
                      out=feat.new_zeros((cap, feat.shape[1])))
-    return DenseCells(pooled, cell_lin, batch, (z, y, x))
+    return DenseCells(pooled, geo["cell_lin"], batch, tuple(dims), _rulebook=geo.get("rulebook"))
 
 
 def _tap_table(cells):

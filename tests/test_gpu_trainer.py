@@ -109,7 +109,7 @@ def test_prefetched_ray_setup_equals_inline(device):
     inline = model(clone())
     with input_stream(device) as pipe:
         staged = pipe.adopt(model.prefetch(clone()))
-    assert "_ray_dict" in staged
+    assert "_ray_dict" in staged and "_cells_geometry" in staged
     torch.manual_seed(1)
     ahead = model(staged)
     for k in inline:
