@@ -711,3 +711,27 @@ def test_arena_views_split_matches_per_piece_views():
     assert len(got) == len(specs)
     for (off, n), v in zip(specs, got):
         assert torch.equal(v, a.view(off, n)) and v.data_ptr() == a.view(off, n).data_ptr()
+
+
+def test_cells_geometry_ahead_of_time_equals_inline():
+    """``cells_from_voxels`` with the geometry computed beforehand (what PonderIndoor.prefetch does a step
+    ahead) returns the same cells, rows and rulebook as computing everything in place."""
+    import torch
+
+    from ponderv2_amd.ponder.models.ponder import sparse_input as si
+    from oracle import cpu_backend
+
+    g = torch.Generator().manual_seed(3)
+    B, dims = 2, (3, 5, 4)
+    total = B * dims[0] * dims[1] * dims[2]
+    lin = torch.randint(0, total, (40,), generator=g)
+    feat = torch.randn(40, 8, generator=g)
+    with cpu_backend.installed():
+        a = si.cells_from_voxels(feat, lin, B, dims)
+        geo = si.cells_geometry(lin, B, dims, build_rulebook=True)
+        b = si.cells_from_voxels(feat, None, B, dims, geometry=geo)
+        assert torch.equal(a.lin, b.lin) and torch.equal(a.feat, b.feat) and a.dims == b.dims
+        ra, rb = a.rulebook(), b.rulebook()
+    assert rb is geo["rulebook"]
+    assert torch.equal(ra.pair_in[:ra.n_pairs], rb.pair_in[:rb.n_pairs])
+    assert torch.equal(ra.pair_out[:ra.n_pairs], rb.pair_out[:rb.n_pairs])
