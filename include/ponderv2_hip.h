@@ -231,6 +231,55 @@ int pv2_spconv_reduce_rows(const float* prod, const int32_t* pos, int64_t pos_st
                            int64_t n_rows, const float* bias, const float* addend, float* out,
                            float* bn_partial, int* bn_blocks, pv2_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Output-stationary form over MASK-GROUPED rows (csrc/sparse_conv_osm.hip, round 5; same reference
+ * call sites: spconv_unet_v1m1_base.py:47-83,112-121,135-146,171-181): ONE launch per conv and
+ * direction - no product rows, no row reduce, no atomics, no zero-fill; every output element is
+ * written once, offsets summed in ascending table order inside the MFMA accumulators (bitwise
+ * reproducible).  The rows of a 32-row tile are chosen to share their kernel offsets:
+ *
+ *   pv2_osm_plan: from a gather table tbl[k*stride + o] (input row feeding output row o under
+ *       offset k, or -1; K <= 31; rows >= *n_cols_dev - when given - are padding) build
+ *         perm  [n_cols]      rows sorted stably by the bit mask of their present offsets
+ *                             (padding rows last),
+ *         tblp  [K, n_pad]    tblp[k*n_pad + r] = tbl[k*stride + perm[r]] (-1 past the valid rows),
+ *         tmask [n_pad / 32]  OR of the masks of sorted rows 32 t .. 32 t + 31.
+ *       n_pad: a multiple of 256, >= n_cols.  workspace: pv2_osm_plan_workspace_bytes(n_cols).
+ *   pv2_spconv_osm: out[perm[r], :] = (addend[perm[r], :]) + sum_k W[kw(k)] . in[tblp[k][r], :] for
+ *       r < n_out, kw(k) = plan->kflip ? K-1-k : k.  weight [c_out, K, c_in], or - with
+ *       weight_reduction_major != 0 - [c_in, K, c_out] (grad-input reads the forward weight in
+ *       place).  c_in % 32 == 0, c_out % 4 == 0.  addend may be NULL or alias out.  zero_row: at least
+ *       c_in zero floats.  bn_partial != NULL: the BatchNorm statistics of `out` per block of
+ *       *bn_rows_per_block sorted rows - partial[b][0..c) = column sums, [c..2c) = sums of squares
+ *       about the BLOCK mean (combined by pv2_bn_forward's second stage in double precision);
+ *       *bn_blocks <= PV2_BN_MAX_PARTIAL_BLOCKS.
+ *   Arithmetic: fp32 products as six bf16 MFMAs over three exact bf16 pieces per operand
+ *   (csrc/mfma_split.h), fp32 accumulation.  Rows without a neighbour under an offset contribute
+ *   0 * w: with a non-finite WEIGHT the whole 32-row tile turns NaN (the pair-major forms confine it
+ *   to the rows that have the neighbour); non-finite FEATURES stay in their own rows.
+ * ------------------------------------------------------------------------------------------ */
+#define PV2_BN_MAX_PARTIAL_BLOCKS 8192
+typedef struct pv2_osm_plan_t {
+  const int32_t* tblp;
+  const int32_t* perm;
+  const uint32_t* tmask;
+  int64_t n_pad;
+  int32_t kflip;
+  int32_t reserved;
+} pv2_osm_plan_t;
+/* tuning / test knob: mode 0 / 1 / 2 = PV2_CONV_OSM off / on / auto for pv2_convbn_*; nb (1..4, 0 = automatic)
+ * and wr (2 | 4, 0 = automatic) force the tile of pv2_spconv_osm; min_wgs the workgroup target of the
+ * automatic choice.  Negative (min_wgs: <= 0) arguments leave a setting as it is. */
+int pv2_debug_set_osm(int mode, int nb, int wr, int min_wgs);
+size_t pv2_osm_plan_workspace_bytes(int64_t n_cols);
+int pv2_osm_plan(const int32_t* tbl, int K, int64_t n_cols, int64_t stride, const int32_t* n_cols_dev,
+                 int32_t* perm, int32_t* tblp, uint32_t* tmask, int64_t n_pad, void* workspace,
+                 size_t workspace_bytes, pv2_stream_t stream);
+int pv2_spconv_osm(const float* in_feat, int c_in, const float* weight, int K, int c_out,
+                   int weight_reduction_major, const pv2_osm_plan_t* plan, int64_t n_out,
+                   const float* zero_row, const float* addend, float* out, float* bn_partial,
+                   int* bn_blocks, int* bn_rows_per_block, pv2_stream_t stream);
+
 /* One conv -> BatchNorm1d -> (+ shortcut) -> ReLU unit of the backbone as ONE call per direction
  * (BasicBlock.forward, spconv_unet_v1m1_base.py:70-83; the conv + norm_fn + ReLU stages :108,
  * 120-121,143-145): the product-row conv, the statistics in its reduce epilogue, combine + apply.
@@ -259,6 +308,11 @@ typedef struct pv2_conv_geom {
   const int32_t* tile_start_w;
   const int32_t* pos_out;
   const int32_t* pos_in;
+  /* round 5: the mask-grouped output-stationary route (pv2_spconv_osm below).  osm_fwd walks the OUTPUT
+   * rows of the conv (forward pass), osm_bwd its INPUT rows (grad-input); tblp == NULL: not planned, the
+   * unit takes the product-row route.  zero_row: >= 4096 zero floats (what absent neighbours read). */
+  pv2_osm_plan_t osm_fwd, osm_bwd;
+  const float* zero_row;
 } pv2_conv_geom;
 int pv2_convbn_forward(const pv2_conv_geom* g, const float* x, int c_in, const float* weight,
                        int c_out, const float* bn_weight, const float* bn_bias,

@@ -20,13 +20,20 @@ class VolumeDesc(Structure):
     _fields_ = [(k, c_int64) for k in ("n", "c", "d", "h", "w", "sn", "sc", "sd", "sh", "sw")]
 
 
+class OsmPlan(Structure):
+    """pv2_osm_plan_t: the mask-grouped row order of one gather table (csrc/sparse_conv_osm.hip)."""
+    _fields_ = [("tblp", c_void_p), ("perm", c_void_p), ("tmask", c_void_p), ("n_pad", c_int64),
+                ("kflip", c_int32), ("reserved", c_int32)]
+
+
 class ConvGeom(Structure):
     """pv2_conv_geom: one rulebook as the fused conv + BatchNorm entry points take it."""
     _fields_ = ([("K", c_int32), ("tile_pairs_w", c_int32)]
                 + [(k, c_int64) for k in ("n_in", "n_out", "n_tiles", "n_tiles_w", "pos_out_stride",
                                           "pos_in_stride")]
                 + [(k, c_void_p) for k in ("pair_in", "pair_out", "kstart", "tile_start",
-                                           "tile_start_w", "pos_out", "pos_in")])
+                                           "tile_start_w", "pos_out", "pos_in")]
+                + [("osm_fwd", OsmPlan), ("osm_bwd", OsmPlan), ("zero_row", c_void_p)])
 
 
 class UnetOp(Structure):
@@ -52,7 +59,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -99,6 +106,12 @@ SIGNATURES = {
     "pv2_spconv_products": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int64, _P, _P]),
     "pv2_spconv_reduce_rows": (
         c_int, [_P, _P, c_int64, c_int, c_int, c_int64, _P, _P, _P, _P, POINTER(c_int), _P]),
+    "pv2_debug_set_osm": (c_int, [c_int, c_int, c_int, c_int]),
+    "pv2_osm_plan_workspace_bytes": (c_size_t, [c_int64]),
+    "pv2_osm_plan": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
+    "pv2_spconv_osm": (
+        c_int, [_P, c_int, _P, c_int, c_int, c_int, POINTER(OsmPlan), c_int64, _P, _P, _P, _P,
+                POINTER(c_int), POINTER(c_int), _P]),
     "pv2_convbn_forward": (
         c_int, [POINTER(ConvGeom), _P, c_int, _P, c_int, _P, _P, _P, c_int, c_float, c_float, _P, _P,
                 _P, _P, _P, _P, _P, _P]),

@@ -68,6 +68,19 @@ int bn_forward_from_partials(const float* x, int64_t n, int c, const float* part
                              int relu, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean_invstd, float* y, hipStream_t s);
 
+int bn_forward_from_block_stats(const float* x, int64_t n, int c, const float* partial, int blocks,
+                                int64_t rows_per_block, const float* weight, const float* bias,
+                                const float* residual, int relu, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean_invstd, float* y,
+                                hipStream_t s);
+// sparse_conv_osm.hip: the mask-grouped output-stationary conv (pv2_spconv_osm)
+int spconv_osm(bool trans, const float* in_feat, int c_in, const float* weight, int K, int c_out,
+               const pv2_osm_plan_t* plan, int64_t n_out, const float* zero_row, const float* addend,
+               float* out, float* bn_partial, int* bn_blocks, int* bn_rows_per_block, hipStream_t s);
+// whether a conv of this shape takes that route (PV2_CONV_OSM = 0 / 1 / auto)
+bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n_rows, int c_red,
+             int c_cols);
+
 }  // namespace pv2
 
 #define PV2_REQUIRE(cond, msg)   \

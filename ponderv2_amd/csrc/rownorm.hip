@@ -96,7 +96,7 @@ template <> __device__ __forceinline__ void st8<H16>(unsigned short* p, int64_t 
 // MODE 0: f0 = x - s, f1 = (x - s)^2 with the shift s = x[0, c] (forward statistics: the shifted form
 //         keeps E[x^2] - mean^2 accurate for columns whose mean is far larger than their spread)
 // MODE 1: g = dy * (y > 0 if y else 1);  f0 = g, f1 = g * xhat       (backward reductions)
-constexpr int kMaxPartialBlocks = 2048;  // (the row reduce of sparse_conv_pr.hip writes up to this many)
+constexpr int kMaxPartialBlocks = PV2_BN_MAX_PARTIAL_BLOCKS;  // (the conv epilogues write up to this many)
 constexpr int kMaxChannels = 1024;
 
 // EA: element type of `a` (the input x in MODE 0, dy in MODE 1); EX / EY: of x and y in MODE 1.
@@ -312,6 +312,59 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
   }
 }
 
+// The forward statistics from PER-BLOCK moments (the epilogue of spconv_osm_kernel): block b of
+// `rows_per_block` rows (the last one shorter) wrote partial[b][0..C) = sum_r x and partial[b][C..2C) =
+// sum_r (x - mean_b)^2.  Chan's pairwise update, all blocks against the grand mean, in double and in a
+// fixed order:  M2 = sum_b [ M2_b + n_b (mean_b - mean)^2 ].  No shift needed: every block is centred
+// on its own mean.  Publishes what col_combine_kernel<0> publishes.
+__global__ __launch_bounds__(kCombineThreads) void col_combine_blocks_kernel(
+    const float* __restrict__ partial, int nb, int c, int64_t n, int64_t rows_per_block, float eps,
+    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ out) {
+  __shared__ double r0[kCombineThreads];
+  __shared__ double s_mean[32];
+  const int tid = threadIdx.x, q = tid >> 5, cc = tid & 31;
+  const int ch = blockIdx.x * 32 + cc;
+  double a0 = 0.0;
+  if (ch < c) {
+#pragma unroll 8
+    for (int b = q; b < nb; b += kCombineSubs) a0 += (double)partial[(int64_t)b * 2 * c + ch];
+  }
+  r0[tid] = a0;
+  __syncthreads();
+  if (q == 0) {
+    double t0 = 0.0;
+    for (int k = 0; k < kCombineSubs; ++k) t0 += r0[k * 32 + cc];
+    s_mean[cc] = t0 / (double)n;
+  }
+  __syncthreads();
+  const double mean = s_mean[cc];
+  double a1 = 0.0;
+  if (ch < c) {
+#pragma unroll 4
+    for (int b = q; b < nb; b += kCombineSubs) {
+      const int64_t left = n - (int64_t)b * rows_per_block;
+      const double nbk = (double)(left < rows_per_block ? left : rows_per_block);
+      const double d = (double)partial[(int64_t)b * 2 * c + ch] / nbk - mean;
+      a1 += (double)partial[(int64_t)b * 2 * c + c + ch] + nbk * d * d;
+    }
+  }
+  r0[tid] = a1;
+  __syncthreads();
+  if (q != 0 || ch >= c) return;
+  double t1 = 0.0;
+  for (int k = 0; k < kCombineSubs; ++k) t1 += r0[k * 32 + cc];
+  double var = t1 / (double)n;
+  if (var < 0.0) var = 0.0;
+  out[ch] = (float)mean;
+  out[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+  }
+}
+
 // y = [relu]( (x - mean) * invstd * w + b [+ residual] )
 template <typename EX, typename EY>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(
@@ -501,6 +554,25 @@ int bn_forward_from_partials(const float* x, int64_t n, int c, const float* part
                        dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
                        y);
   return pv2::check_launch("bn_forward_from_partials");
+}
+
+// the same from per-block moments (spconv_osm_kernel's epilogue): combine + apply
+int bn_forward_from_block_stats(const float* x, int64_t n, int c, const float* partial, int blocks,
+                                int64_t rows_per_block, const float* weight, const float* bias,
+                                const float* residual, int relu, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean_invstd, float* y,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(col_combine_blocks_kernel, dim3((c + 31) / 32), dim3(kCombineThreads), 0, s, partial,
+                     blocks, c, n, rows_per_block, eps, momentum, running_mean, running_var, mean_invstd);
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((bn_apply_vec_kernel<F32, F32>), dim3(pv2::grid_for(n * c / 8, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<F32, F32>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  return pv2::check_launch("bn_forward_from_block_stats");
 }
 
 }  // namespace pv2

@@ -60,6 +60,65 @@ def _use_os(rb) -> bool:
     if rb.nbr is None or USE_OS is False:
         return False
     return True
+# MASK-GROUPED OUTPUT-STATIONARY route (round 5, csrc/sparse_conv_osm.hip): one launch per conv and
+# direction, sums kept in the MFMA accumulators - no product rows, no row reduce.  The plans (row order,
+# permuted gather table, tile masks) are built with the rulebooks; the C side decides per shape
+# (pv2::use_osm) unless PV2_CONV_OSM forces it:
+#   "auto" (default)  plans for the 27-offset submanifold rulebooks, used where measured faster;
+#   "1"               plans for every rulebook with at most 31 offsets, every planned conv takes the route;
+#   "0"               no plans: the product-row route everywhere.
+OSM_MODE = os.environ.get("PV2_CONV_OSM", "auto")
+if OSM_MODE not in ("0", "1"):
+    OSM_MODE = "auto"
+OSM_MAX_K = 31
+
+
+def _want_osm(K: int) -> bool:
+    if OSM_MODE == "0" or USE_PR is False or K > OSM_MAX_K or K < 2:
+        return False
+    return OSM_MODE == "1" or K == 27
+
+
+_ZERO_ROWS = {}
+
+
+def zero_row(device) -> torch.Tensor:
+    """4096 zero floats per device: what rows without a neighbour read in the output-stationary conv."""
+    z = _ZERO_ROWS.get(device.index)
+    if z is None:
+        z = _ZERO_ROWS[device.index] = torch.zeros(4096, dtype=torch.float32, device=device)
+    return z
+
+
+class OsmPlanData:
+    """Device arrays of one pv2_osm_plan (kept alive by the rulebook) + the struct the C side reads."""
+
+    def __init__(self, perm, tblp, tmask, n_pad, kflip):
+        self.perm, self.tblp, self.tmask, self.n_pad, self.kflip = perm, tblp, tmask, n_pad, kflip
+        self.struct = _lib.OsmPlan(tblp.data_ptr(), perm.data_ptr(), tmask.data_ptr(), n_pad, kflip, 0)
+
+    def flipped(self):
+        """The same table read with mirrored weight offsets (grad-input of a submanifold conv)."""
+        return OsmPlanData(self.perm, self.tblp, self.tmask, self.n_pad, 1 - self.kflip)
+
+
+def build_osm_plan(tbl: torch.Tensor, K: int, n_cols: int, stride: int,
+                   n_cols_dev: Optional[torch.Tensor] = None, kflip: int = 0) -> OsmPlanData:
+    """pv2_osm_plan on the current stream: rows of the gather table ``tbl`` [K, stride] sorted by their
+    offset mask, the table in that order and the per-tile masks."""
+    L = _lib.lib()
+    dev = tbl.device
+    n_pad = (max(n_cols, 1) + 255) // 256 * 256
+    perm = torch.empty(max(n_cols, 1), dtype=torch.int32, device=dev)
+    tblp = torch.empty(K * n_pad, dtype=torch.int32, device=dev)
+    tmask = torch.empty(n_pad // 32, dtype=torch.int32, device=dev)
+    ws_bytes = int(L.pv2_osm_plan_workspace_bytes(n_cols))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.pv2_osm_plan(_ptr(tbl), K, n_cols, stride, _ptr(n_cols_dev), _ptr(perm), _ptr(tblp),
+                              _ptr(tmask), n_pad, _ptr(ws), ws_bytes, _stream(tbl)), "pv2_osm_plan")
+    return OsmPlanData(perm, tblp, tmask, n_pad, kflip)
+
+
 # Run the centre offset of submanifold convs as a separate plain-store pass (no zero-fill, fewer
 # atomics) on the scatter-add path.  Measured neutral on MI355X at the ScanNet batch (the second
 # launch and its smaller grids cost what the saved fill and atomics gain): off.
@@ -183,6 +242,10 @@ class Rulebook:
     _tiles_dev: Optional[torch.Tensor] = None
     bounded: bool = False                    # host-side pair counts are upper bounds (no read-back)
     _geoms: dict = field(default_factory=dict)
+    # plans of the mask-grouped output-stationary route: over this rulebook's OUTPUT rows / over its
+    # INPUT rows (= the transposed rulebook's outputs: grad-input); None: not planned
+    osm: Optional["OsmPlanData"] = None
+    osm_t: Optional["OsmPlanData"] = None
 
     @property
     def n_pairs(self) -> int:
@@ -223,6 +286,7 @@ class Rulebook:
         if self._transposed_os is not None:
             rb.nbr, rb.nbr_stride, rb.perm, rb.kflip = self._transposed_os
             rb._transposed_os = (self.nbr, self.nbr_stride, self.perm, self.kflip)
+        rb.osm, rb.osm_t = self.osm_t, self.osm
         if self._pos is not None:
             po, so, pi, si = self._pos
             rb._pos = (pi, si, po, so)
@@ -262,11 +326,15 @@ class Rulebook:
             pos_out, so, pos_in, si = self.positions() if positions else (None, 0, None, 0)
             ts, n_tiles, _ = self.tiles(FWD_LDS_TILE)
             tsw, n_tiles_w, _ = self.tiles(tile_w)
+            none = _lib.OsmPlan(None, None, None, 0, 0, 0)
             g = _lib.ConvGeom(self.K, tile_w, self.n_in, self.n_out, n_tiles, n_tiles_w, so, si,
                               self.pair_in.data_ptr(), self.pair_out.data_ptr(),
                               self.kstart.data_ptr(), ts.data_ptr(), tsw.data_ptr(),
                               pos_out.data_ptr() if positions else None,
-                              pos_in.data_ptr() if positions else None)
+                              pos_in.data_ptr() if positions else None,
+                              self.osm.struct if (self.osm is not None and positions) else none,
+                              self.osm_t.struct if (self.osm_t is not None and positions) else none,
+                              zero_row(self.kstart.device).data_ptr())
             self._geoms[key] = g
         return g
 
@@ -355,6 +423,9 @@ def build_subm_rulebook(coords: torch.Tensor, ksize: int) -> Rulebook:
         rb.nbr, rb.nbr_stride = nbr, n
         rb.perm = _mask_order(nbr, K, n, n) if USE_OS is True else None
         rb._transposed_os = (nbr, n, rb.perm, 1)
+        if _want_osm(K):
+            rb.osm = build_osm_plan(nbr, K, n, n)
+            rb.osm_t = rb.osm.flipped()
     return rb
 
 
@@ -426,6 +497,9 @@ def build_downsample_rulebook(coords: torch.Tensor, stride: int, out_shape: List
                    "pv2_table_invert")
         rb.nbr, rb.nbr_stride, rb.perm = tbl, n, _mask_order(tbl, K, n_out, n)
         rb._transposed_os = (parent, n, _mask_order(parent, K, n, n), 0)
+        if _want_osm(K):
+            rb.osm = build_osm_plan(tbl, K, n_out, n)
+            rb.osm_t = build_osm_plan(parent, K, n, n)
     return rb, out_coords[:n_out]
 
 
@@ -481,6 +555,8 @@ def _record_stream(obj, stream, _seen=None):
             _record_stream(v, stream, seen)
     elif isinstance(obj, Rulebook):
         _record_stream(list(vars(obj).values()), stream, seen)
+    elif isinstance(obj, OsmPlanData):
+        _record_stream([obj.perm, obj.tblp, obj.tmask], stream, seen)
 
 
 _GEOMETRY_STREAMS = {}
@@ -598,7 +674,9 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
                    "pv2_table_invert")
         downs.append(dict(pair_in=pair_in, pair_out=pair_out, kstart=kstart, tbl=tbl, parent=parent,
                           perm=order(tbl, 8, n_out_dev), perm_t=order(parent, 8, n_dev[-1]),
-                          out_shape=out_shape, pos=positions(pair_in, pair_out, kstart, 8, cap)))
+                          out_shape=out_shape, pos=positions(pair_in, pair_out, kstart, 8, cap),
+                          osm=build_osm_plan(tbl, 8, cap, cap, n_out_dev) if _want_osm(8) else None,
+                          osm_t=build_osm_plan(parent, 8, cap, cap, n_dev[-1]) if _want_osm(8) else None))
         coords.append(out_coords)
         n_dev.append(n_out_dev)
         shapes.append(out_shape)
@@ -622,7 +700,8 @@ def _launch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 
                               pair_out=pair_out, kstart=kstart,
                               pos=positions(pair_in, pair_out, kstart, K,
                                             K * cap if level == 0 else 27 * cap),
-                              perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None))
+                              perm=order(nbr, K, n_dev[level]) if (USE_OS is True and K <= 63) else None,
+                              osm=build_osm_plan(nbr, K, cap, cap, n_dev[level]) if _want_osm(K) else None))
     for d in downs + subms:
         d["tiles_dev"] = tiles_dev[id(d["kstart"])]
     state = dict(cap=cap, n_levels=n_levels, coords=coords, shapes=shapes, downs=downs, subms=subms,
@@ -654,6 +733,7 @@ def _finish_unet_geometry(state, host) -> dict:
             rb._transposed_os = (d["parent"], cap, d["perm_t"], 0)
             if d.get("pos") is not None:
                 rb._pos = d["pos"]
+            rb.osm, rb.osm_t = d.get("osm"), d.get("osm_t")
         out[f"spconv{l}"] = dict(kind="down", ksize=2, rulebook=rb, in_indices=coords[l - 1][:n_lvl[l - 1]],
                                  in_spatial_shape=shapes[l - 1], out_indices=coords[l][:n_lvl[l]],
                                  out_shape=d["out_shape"], prebuilt=True)
@@ -667,6 +747,9 @@ def _finish_unet_geometry(state, host) -> dict:
             rb._transposed_os = (d["nbr"], cap, d["perm"], 1)
             if d.get("pos") is not None:
                 rb._pos = d["pos"]
+            if d.get("osm") is not None:
+                rb.osm = d["osm"]
+                rb.osm_t = rb.osm.flipped()
         out[d["key"]] = dict(kind="subm", ksize=d["ksize"], n=n, rulebook=rb)
     return out
 
@@ -702,6 +785,32 @@ def _pr_conv(feats, weight, rb, c_in, c_out, reduction_major, pair_in, pos, pos_
                                         _ptr(bias), _ptr(addend), _ptr(out), _ptr(bn_partial),
                                         ctypes.byref(blocks), st), "pv2_spconv_reduce_rows")
     return out, blocks.value
+
+
+def spconv_osm(feats: torch.Tensor, weight: torch.Tensor, rb: Rulebook, transposed: bool = False,
+               addend: Optional[torch.Tensor] = None, stats: bool = False):
+    """The mask-grouped output-stationary conv (pv2_spconv_osm) of ``feats`` over ``rb``'s plan.
+    ``transposed``: grad-input - ``feats`` is grad_out [n_out, c_out], ``weight`` the FORWARD weight
+    [c_out, K, c_in] read in place, the result [n_in, c_in].  ``stats``: also (partial, blocks,
+    rows_per_block), the per-block BatchNorm moments."""
+    _require_device(feats, weight)
+    plan = rb.osm_t if transposed else rb.osm
+    assert plan is not None, "rulebook carries no output-stationary plan"
+    feats, weight = feats.contiguous(), weight.contiguous()
+    c_out, Kw, c_in = weight.shape
+    c_red, c_cols, n_rows = (c_out, c_in, rb.n_in) if transposed else (c_in, c_out, rb.n_out)
+    assert feats.shape[1] == c_red and Kw == rb.K
+    out = torch.empty((n_rows, c_cols), dtype=torch.float32, device=feats.device)
+    partial = torch.empty(int(_lib.lib().pv2_bn_workspace_floats(c_cols)), dtype=torch.float32,
+                          device=feats.device) if stats else None
+    blocks, rpb = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().pv2_spconv_osm(
+        _ptr(feats), c_red, _ptr(weight), rb.K, c_cols, int(transposed), ctypes.byref(plan.struct),
+        n_rows, _ptr(zero_row(feats.device)), _ptr(addend), _ptr(out), _ptr(partial),
+        ctypes.byref(blocks), ctypes.byref(rpb), _stream(feats)), "pv2_spconv_osm")
+    if stats:
+        return out, partial, blocks.value, rpb.value
+    return out
 
 
 def spconv_forward(feats: torch.Tensor, weight_okc: torch.Tensor, rb: Rulebook,
