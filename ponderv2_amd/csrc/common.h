@@ -78,8 +78,8 @@ int spconv_osm(bool trans, const float* in_feat, int c_in, const float* weight, 
                const pv2_osm_plan_t* plan, int64_t n_out, const float* zero_row, const float* addend,
                float* out, float* bn_partial, int* bn_blocks, int* bn_rows_per_block, hipStream_t s);
 // whether a conv of this shape takes that route (PV2_CONV_OSM = 0 / 1 / auto)
-bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n_rows, int c_red,
-             int c_cols);
+bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n_rows, int64_t n_other,
+             int c_red, int c_cols);
 
 }  // namespace pv2
 

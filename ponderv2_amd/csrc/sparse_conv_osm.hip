@@ -129,9 +129,22 @@ __global__ __launch_bounds__(64 * WR) void spconv_osm_kernel(
   const int64_t rpos = r0 + wave * 32 + i;
   const int orow = rpos < n_out ? perm[rpos] : -1;
 
-  for (int e = tid; e < K * ROWS; e += THREADS) {
-    const int k = e / ROWS, r = e - k * ROWS;
-    s_idx[e] = tblp[(int64_t)k * n_pad + r0 + r];
+  {
+    // the tile's slice of the gather table -> LDS: ALL of a thread's entries are requested before the first
+    // is stored (a load-store loop paid one memory round trip per trip: 5 - 10 us of prologue per launch)
+    constexpr int NE = kMaxK * ROWS / THREADS;
+    int v[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + THREADS * j;
+      const int k = e / ROWS, r = e - k * ROWS;
+      v[j] = e < K * ROWS ? tblp[(int64_t)k * n_pad + r0 + r] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + THREADS * j;
+      if (e < K * ROWS) s_idx[e] = v[j];
+    }
   }
 
   f32x16 acc[NB];
@@ -448,8 +461,8 @@ int osm_rows_per_block(int64_t n_out, int c_out) {
 // measured faster than the product-row route on MI355X (profiles/r05_spconv_ab.txt).
 // PV2_FP32_MFMA=1 (every product on the fp32 MFMA) keeps the product-row route: this kernel has the
 // bf16-piece form only.
-bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n_rows, int c_red,
-             int c_cols) {
+bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n_rows, int64_t n_other,
+             int c_red, int c_cols) {
   if (g_mode < 0) {
     const char* f = getenv("PV2_FP32_MFMA");
     const char* e = getenv("PV2_CONV_OSM");
@@ -461,7 +474,13 @@ bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n
   if (K < 1 || K >= kMaxK || c_red < kKC || (c_red % kKC) != 0 || (c_cols % 4) != 0) return false;
   if (n_rows < 1 || n_rows > plan->n_pad || (n_rows + 63) / 64 > PV2_BN_MAX_PARTIAL_BLOCKS) return false;
   if (mode == 1) return true;
-  return K == 27;
+  // auto, from the A/B on the bench geometry (profiles/r05_spconv_ab.txt): the strided / inverse convs
+  // whose walked rows are the FINE side (every row has exactly one offset: the mask order makes every tile
+  // a dense single-offset GEMM - grad-input of a strided conv, forward of an inverse conv) and the narrow
+  // strided forward passes; the 27-offset submanifold convs stay on the product-row route (their
+  // workgroups walk 10 - 17 offsets x c_in / 32 slabs serially: 1.2 - 4x slower, section 3.2c of DESIGN.md).
+  if (K > 8) return false;
+  return n_rows >= n_other || c_red <= 64;
 }
 
 int spconv_osm(bool trans, const float* in_feat, int c_in, const float* weight, int K, int c_out,

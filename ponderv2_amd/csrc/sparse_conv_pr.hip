@@ -346,7 +346,7 @@ int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* 
                                   g->n_tiles_w, dweight_or_null, part_ws, side))
       return e;
   }
-  if (dx_or_null && pv2::use_osm(&g->osm_bwd, g->zero_row, g->K, g->n_in, c_out, c_in)) {
+  if (dx_or_null && pv2::use_osm(&g->osm_bwd, g->zero_row, g->K, g->n_in, g->n_out, c_out, c_in)) {
     // grad-input, output-stationary over the INPUT rows (sparse_conv_osm.hip): one launch, the other
     // consumers' gradient added in its epilogue, forward weight read in place
     if (int e = pv2::spconv_osm(true, dy, c_out, weight, g->K, c_in, &g->osm_bwd, g->n_in, g->zero_row,
@@ -409,7 +409,7 @@ int pv2_convbn_forward(const pv2_conv_geom* g, const float* x, int c_in, const f
                        float* y_conv, float* mean_invstd, float* out, pv2_stream_t stream) {
   PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_forward: needs at least two output rows");
   hipStream_t s = (hipStream_t)stream;
-  if (pv2::use_osm(&g->osm_fwd, g->zero_row, g->K, g->n_out, c_in, c_out)) {
+  if (pv2::use_osm(&g->osm_fwd, g->zero_row, g->K, g->n_out, g->n_in, c_in, c_out)) {
     // one launch: output-stationary conv with the block statistics in its epilogue
     int blocks = 0, rpb = 0;
     if (int e = pv2::spconv_osm(false, x, c_in, weight, g->K, c_out, &g->osm_fwd, g->n_out, g->zero_row,

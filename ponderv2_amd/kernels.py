@@ -64,7 +64,8 @@ def _use_os(rb) -> bool:
 # direction, sums kept in the MFMA accumulators - no product rows, no row reduce.  The plans (row order,
 # permuted gather table, tile masks) are built with the rulebooks; the C side decides per shape
 # (pv2::use_osm) unless PV2_CONV_OSM forces it:
-#   "auto" (default)  plans for the 27-offset submanifold rulebooks, used where measured faster;
+#   "auto" (default)  plans for the 8-offset strided / inverse rulebooks, used where measured faster
+#                     (profiles/r05_spconv_ab.txt: the 27-offset submanifold convs lose on this route);
 #   "1"               plans for every rulebook with at most 31 offsets, every planned conv takes the route;
 #   "0"               no plans: the product-row route everywhere.
 OSM_MODE = os.environ.get("PV2_CONV_OSM", "auto")
@@ -76,7 +77,7 @@ OSM_MAX_K = 31
 def _want_osm(K: int) -> bool:
     if OSM_MODE == "0" or USE_PR is False or K > OSM_MAX_K or K < 2:
         return False
-    return OSM_MODE == "1" or K == 27
+    return OSM_MODE == "1" or K == 8
 
 
 _ZERO_ROWS = {}

@@ -65,10 +65,12 @@ def test_osm_plans_match_their_definition(device, seed, batch, n, monkeypatch):
 
 @pytest.mark.parametrize("nb,wr", [(0, 0), (1, 2), (1, 4), (2, 2), (2, 4), (3, 2), (3, 4), (4, 2), (4, 4)])
 @pytest.mark.parametrize("c_in,c_out", [(32, 32), (64, 128), (96, 96), (256, 192)])
-def test_osm_conv_vs_oracle_every_configuration(device, c_in, c_out, nb, wr):
+def test_osm_conv_vs_oracle_every_configuration(device, c_in, c_out, nb, wr, monkeypatch):
     """Forward, grad-input (+ addend, also in place) and the block statistics of a submanifold conv for
     every (column group, row tiles) shape of the kernel; (0, 0) is the dispatcher's own choice."""
-    from ponderv2_amd import _lib
+    from ponderv2_amd import _lib, kernels as K
+
+    monkeypatch.setattr(K, "OSM_MODE", "1")
 
     if nb and ((c_out // 32) % nb or (c_in // 32) % nb):
         pytest.skip("column group does not divide the channel blocks")
