@@ -833,7 +833,11 @@ def main():
         # one flat all-reduce after backward instead of DDP's per-parameter hooks (utils/grad_sync.py)
         from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
 
-        gsync = FlatGradSync(model.parameters(), uniform_usage=not ppt)
+        # overlap: the sparse executor's parameter-gradient arena is all-reduced IN PLACE, slab by slab,
+        # behind the events its backward records - while the units below still run (PV2_GSYNC_OVERLAP=0:
+        # the round-4 form, everything after backward)
+        gsync = FlatGradSync(model.parameters(), uniform_usage=not ppt,
+                             overlap=os.environ.get("PV2_GSYNC_OVERLAP", "1") != "0").attach()
     elif dist_on:
         # find_unused_parameters: the ppt head is reported, never trained (quirk Q10), and the
         # multi-dataset model trains a different condition's BatchNorms per step.  static_graph

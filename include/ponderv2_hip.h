@@ -426,6 +426,17 @@ int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* s
                      pv2_stream_t stream);
 int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
                       float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream);
+/* The same with CHECKPOINTS for a gradient reduction that overlaps the backward pass (what the
+ * reference gets from DistributedDataParallel's bucketed all-reduce, ponder/engines/defaults.py:22-43):
+ * the executor walks the units last to first, so the parameter gradients of units >= ckpt_unit[j] are
+ * complete once unit ckpt_unit[j] has been processed.  At that point ckpt_event_main[j] (a hipEvent_t,
+ * host array of handles) is recorded on `stream` (BatchNorm gradients) and ckpt_event_side[j] on the side
+ * stream (weight gradients; on `stream` when side_stream is NULL).  ckpt_unit: host array, strictly
+ * descending.  n_ckpt == 0: exactly pv2_unet_backward. */
+int pv2_unet_backward_ev(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                         float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream, int n_ckpt,
+                         const int32_t* ckpt_unit, void* const* ckpt_event_main,
+                         void* const* ckpt_event_side);
 
 /* ------------------------------------------------------------------------------------------
  * 2 x 2 x 2 max-pooling of a channels-last dense grid x[B, Z, Y, X, C] -> y[B, Z/2, Y/2, X/2, C]

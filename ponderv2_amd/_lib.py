@@ -120,6 +120,8 @@ SIGNATURES = {
                 _P, _P, _P, _P]),
     "pv2_unet_forward": (c_int, [POINTER(UnetOp), c_int, _P, _P, _P]),
     "pv2_unet_backward": (c_int, [POINTER(UnetOp), c_int, _P, _P, _P, _P, _P]),
+    "pv2_unet_backward_ev": (c_int, [POINTER(UnetOp), c_int, _P, _P, _P, _P, _P, c_int, POINTER(c_int32),
+                                     POINTER(c_void_p), POINTER(c_void_p)]),
     "pv2_gemm_nt": (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P, _P]),
     "pv2_gemm_tn": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pv2_bn_workspace_floats": (c_int64, [c_int]),

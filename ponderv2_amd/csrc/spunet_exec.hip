@@ -102,8 +102,22 @@ int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* s
 
 int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
                       float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream) {
+  return pv2_unet_backward_ev(ops, n_ops, prod_ws, stats_ws, part_ws, stream, side_stream, 0, nullptr,
+                              nullptr, nullptr);
+}
+
+int pv2_unet_backward_ev(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
+                         float* part_ws, pv2_stream_t stream, pv2_stream_t side_stream, int n_ckpt,
+                         const int32_t* ckpt_unit, void* const* ckpt_event_main,
+                         void* const* ckpt_event_side) {
   PV2_REQUIRE(ops != nullptr && n_ops >= 0, "pv2_unet_backward: bad plan");
+  PV2_REQUIRE(n_ckpt == 0 || (ckpt_unit != nullptr && ckpt_event_main != nullptr && ckpt_event_side != nullptr),
+              "pv2_unet_backward_ev: checkpoint arrays missing");
+  for (int j = 0; j < n_ckpt; ++j)
+    PV2_REQUIRE(ckpt_unit[j] >= 0 && ckpt_unit[j] < n_ops && (j == 0 || ckpt_unit[j] < ckpt_unit[j - 1]),
+                "pv2_unet_backward_ev: checkpoints must be unit indices in descending order");
   hipStream_t s = (hipStream_t)stream;
+  int next_ckpt = 0;   // checkpoints are listed in the order the units finish: descending unit index
   for (int i = n_ops - 1; i >= 0; --i) {
     const pv2_unet_op& u = ops[i];
     int e = PV2_OK;
@@ -146,6 +160,15 @@ int pv2_unet_backward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* 
         return PV2_E_BADARG;
     }
     if (e != PV2_OK) return e;
+    while (next_ckpt < n_ckpt && ckpt_unit[next_ckpt] >= i) {
+      // every parameter gradient of units >= i is now queued: BatchNorm gradients on `stream`, weight
+      // gradients on the side stream.  Whoever waits for both events may read them (the gradient
+      // reduction of a data-parallel step starts on this slab while the units below still run).
+      if (int err = pv2::hip_status(hipEventRecord((hipEvent_t)ckpt_event_main[next_ckpt], s))) return err;
+      hipStream_t side = side_stream ? (hipStream_t)side_stream : s;
+      if (int err = pv2::hip_status(hipEventRecord((hipEvent_t)ckpt_event_side[next_ckpt], side))) return err;
+      ++next_ckpt;
+    }
   }
   return PV2_OK;
 }

@@ -156,8 +156,11 @@ class Trainer(TrainerBase):
 
             for t in list(model.parameters()) + list(model.buffers()):
                 torch.distributed.broadcast(t.data, src=0)
+            # (overlap: in-place reduction of the sparse executor's gradient arena behind per-slab
+            # events of its backward - only with uniform usage, see utils/grad_sync.py)
             self.grad_sync = FlatGradSync(model.parameters(),
-                                          uniform_usage=not self.cfg.find_unused_parameters)
+                                          uniform_usage=not self.cfg.find_unused_parameters,
+                                          overlap=bool(self.cfg.get("grad_sync_overlap", True))).attach()
             return model
         return create_ddp_model(model, broadcast_buffers=False,
                                 find_unused_parameters=self.cfg.find_unused_parameters)

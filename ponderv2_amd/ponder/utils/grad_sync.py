@@ -26,6 +26,19 @@ run on the flat buffer, whose layout is fixed after the first step and agreed be
 (one all-reduce of a layout signature, once): a step - or a rank - whose gradients do not sit at the
 recorded offsets simply falls back to per-tensor copies into the same places, so the ranks can
 never disagree about what they reduce.
+
+Overlap with the backward pass (round 5; what the reference gets from DDP's buckets,
+ponder/engines/defaults.py:22-43).  With ``overlap=True`` the sparse executor reports its
+parameter-gradient arena from INSIDE the backward node (``spunet_native.GRAD_SLAB_HOOK``): it walks
+the units last to first, so the arena is final from its END towards its beginning, and it records
+an event pair (training stream / weight-gradient side stream) per finished slab of ~``slab_mb``
+(pv2_unet_backward_ev).  Each slab is all-reduced IN PLACE on the arena, behind its events, through a
+communication stream - while the units below are still running - and the parameters' ``.grad``
+(views of the arena) hold the averages when ``sync()`` has waited for the handles: no copy into the
+flat buffer and none back for 150 of the step's 160 MB.  Everything else (the dense U-Net's arena,
+the heads, the stem) travels through the flat buffer as before.  The collectives are issued in the
+same order on every rank (slabs in completion order, then the flat slices); a step whose backward
+did not run natively on this rank reduces the same slabs from a staging buffer inside ``sync()``.
 """
 import torch
 import torch.distributed as dist
@@ -33,8 +46,18 @@ import torch.distributed as dist
 
 class FlatGradSync:
     def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
-                 use_blocks: bool = True):
+                 use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0):
         self.params = [p for p in params if p.requires_grad]
+        # in-place reduction of the sparse executor's arena behind per-slab events (see the module
+        # docstring); needs every rank to take the same code path: uniform usage only
+        self.overlap = bool(overlap) and uniform_usage
+        self.slab_elems = max(int(slab_mb * 2 ** 20 // 4), 1)
+        self._index_of = {id(p): i for i, p in enumerate(self.params)}
+        self._arena_layout = None     # (arena numel, ((lo, hi), ...), ((param index, offset, numel), ...))
+        self._covered = frozenset()   # parameter indices whose gradients live in the in-place arena
+        self._inflight = None         # this step's (arena, [(work, view)])
+        self._stage = None
+        self._comm = {}
         self.group = process_group
         self.numel = sum(p.numel() for p in self.params)
         self.slice_elems = max(int(slice_mb * 2 ** 20 // 4), 1)
@@ -54,7 +77,7 @@ class FlatGradSync:
         by_storage = {}
         for i, p in enumerate(self.params):
             g = p.grad
-            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32 or i in self._covered:
                 continue
             st = g.untyped_storage()
             by_storage.setdefault(st.data_ptr(), []).append((i, (g.data_ptr() - st.data_ptr()) // 4, g.numel()))
@@ -62,11 +85,24 @@ class FlatGradSync:
         for ptr, members in by_storage.items():
             if len(members) < 8:
                 continue
-            lo = min(o for _, o, _ in members)
-            hi = max(o + n for _, o, n in members)
-            payload = sum(n for _, _, n in members)
-            if payload * 4 >= min_bytes and payload >= 0.9 * (hi - lo):
-                fams.append((ptr, lo, hi - lo, [(i, o - lo) for i, o, _ in members]))
+            members.sort(key=lambda m: m[1])
+            # a block is written back as ONE span: it may hold nothing but its members and the
+            # allocator's alignment padding between them (< 64 floats, spunet_native._ALIGN).  A larger
+            # gap could hide another tensor (a frozen parameter's gradient, another group's, the padded
+            # stem weight's) - the family is cut there; overlapping members end it too
+            runs, run = [], [members[0]]
+            for m in members[1:]:
+                gap = m[1] - (run[-1][1] + run[-1][2])
+                if 0 <= gap < 64:
+                    run.append(m)
+                else:
+                    runs.append(run)
+                    run = [m]
+            runs.append(run)
+            for run in runs:
+                lo, hi = run[0][1], run[-1][1] + run[-1][2]
+                if len(run) >= 8 and sum(n for _, _, n in run) * 4 >= min_bytes:
+                    fams.append((ptr, lo, hi - lo, [(i, o - lo) for i, o, _ in run]))
         fams.sort(key=lambda f: -f[2])
         return fams
 
@@ -76,10 +112,19 @@ class FlatGradSync:
             # layout: arena blocks (with their gaps) first, then the remaining parameters, then one
             # usage flag per parameter.  ``self.numel`` = everything in front of the flags.
             fams = self._arena_families() if (self.use_blocks and self.uniform_usage) else []
-            sig = float(sum((k + 1) * (span % 1000003) + len(m) for k, (_, _, span, m) in enumerate(fams)))
-            if fams and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-                # the ranks must agree on the layout: one small reduction, once
-                t = torch.tensor([sig, -sig], dtype=torch.float64, device=ref.device)
+            if (self.use_blocks and self.uniform_usage and dist.is_initialized()
+                    and dist.get_world_size(self.group) > 1):
+                # the ranks must agree on the layout: one small reduction, once - issued by EVERY rank
+                # whether or not it found a family itself (a rank without one contributes signature 0:
+                # skipping the collective there would pair this reduce with the other ranks' first
+                # gradient slice - ADVICE round 4).  The signature covers every member's (parameter
+                # index, offset) and every span, so two different layouts of equal size do not pass.
+                sig = 0
+                for k, (_, _, span, m) in enumerate(fams):
+                    sig = (sig * 1000003 + (k + 1) * 7919 + span) % 2147483629
+                    for i, o in m:
+                        sig = (sig * 1000003 + i * 31 + o) % 2147483629
+                t = torch.tensor([float(sig), -float(sig)], dtype=torch.float64, device=ref.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 hi, lo = t.tolist()
                 if hi != -lo:
@@ -94,14 +139,117 @@ class FlatGradSync:
             for i, p in enumerate(self.params):
                 if i in in_block:
                     offsets.append(in_block[i])
+                elif i in self._covered:   # reduced in place on the executor's arena: no room here
+                    offsets.append(None)
                 else:
                     offsets.append(off)
                     off += p.numel()
             self.numel = off
             self._blocks = blocks
             self._flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=ref.device)
-            self._views = [self._flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, self.params)]
+            self._views = [None if o is None else self._flat[o:o + p.numel()].view_as(p)
+                           for o, p in zip(offsets, self.params)]
         return self._flat, self._views
+
+    # ------------------------------------------------------------------ overlap with the backward
+    def attach(self):
+        """Register with the sparse executor (``overlap=True``): from now on its backward node reports
+        the parameter-gradient arena and the per-slab events to ``_on_arena``."""
+        if self.overlap:
+            from ponderv2_amd import spunet_native
+
+            spunet_native.GRAD_SLAB_HOOK = self
+        return self
+
+    def detach(self):
+        from ponderv2_amd import spunet_native
+
+        if spunet_native.GRAD_SLAB_HOOK is self:
+            spunet_native.GRAD_SLAB_HOOK = None
+
+    def wants(self, tensors) -> bool:
+        """Called by the executor before it lays out the slabs: True when every gradient of ``tensors``
+        becomes the ``.grad`` of one of this object's parameters (leaves; no accumulation pending)."""
+        if not (self.overlap and dist.is_available() and dist.is_initialized()):
+            return False
+        return all(id(t) in self._index_of and t.is_leaf and t.grad is None for t in tensors)
+
+    def _reduce_slabs(self, arena, slabs, events=None):
+        """all-reduce ``arena[lo:hi]`` for every slab, in order, asynchronously; on a device behind the
+        slab's events on the communication stream."""
+        avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        works = []
+        if arena.is_cuda:
+            dev = arena.device
+            comm = self._comm.get(dev.index)
+            if comm is None:
+                comm = self._comm[dev.index] = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(comm):
+                if events is None:
+                    comm.wait_stream(cur)
+                arena.record_stream(comm)
+                for j, (lo, hi) in enumerate(slabs):
+                    if events is not None:
+                        for ev in events[j]:
+                            comm.wait_event(ev)
+                    view = arena[lo:hi]
+                    works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+        else:
+            for lo, hi in slabs:
+                view = arena[lo:hi]
+                works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+        return works, avg
+
+    def _on_arena(self, arena, members, slabs, events):
+        """From inside the executor's backward: ``arena`` the flat parameter-gradient buffer,
+        ``members`` [(parameter, offset, numel)], ``slabs`` [(lo, hi)] in completion order, ``events``
+        [(main, side)] per slab (None on the host)."""
+        layout = (arena.numel(), tuple(slabs),
+                  tuple((self._index_of[id(t)], off, n) for t, off, n in members))
+        if self._arena_layout is None:
+            if self._flat is not None:
+                raise RuntimeError("FlatGradSync(overlap=True): the executor's arena appeared after the "
+                                   "flat layout was fixed; attach() before the first step")
+            self._arena_layout = layout
+            self._covered = frozenset(i for i, _, _ in layout[2])
+        elif layout != self._arena_layout:
+            raise RuntimeError("FlatGradSync(overlap=True): the executor's gradient arena changed its "
+                               "layout between steps; use overlap=False for this model")
+        works, avg = self._reduce_slabs(arena, slabs, events)
+        self._inflight = (arena, works, avg)
+
+    def _finish_inplace(self, world):
+        """Wait for the slab reductions of this step - issuing them from a staging buffer first when the
+        backward did not run natively on this rank - and leave the averages in the gradients."""
+        if self._arena_layout is None:
+            return
+        numel, slabs, members = self._arena_layout
+        staged = None
+        if self._inflight is None:
+            ref = self.params[0]
+            if self._stage is None or self._stage.device != ref.device:
+                self._stage = torch.empty(numel, dtype=torch.float32, device=ref.device)
+            staged = self._stage
+            staged.zero_()
+            live = [(i, off, n) for i, off, n in members if self.params[i].grad is not None]
+            if live:
+                torch._foreach_copy_([staged[off:off + n].view_as(self.params[i]) for i, off, n in live],
+                                     [self.params[i].grad for i, _, _ in live])
+            works, avg = self._reduce_slabs(staged, list(slabs))
+        else:
+            _, works, avg = self._inflight
+        for work, view in works:
+            work.wait()
+            if not avg:
+                view.div_(world)
+        if staged is not None:
+            live = [(i, off, n) for i, off, n in members if self.params[i].grad is not None]
+            if live:
+                torch._foreach_copy_([self.params[i].grad for i, _, _ in live],
+                                     [staged[off:off + n].view_as(self.params[i]) for i, off, n in live])
+        self._inflight = None
 
     def _block_sources(self):
         """For every arena block: the live gradient storage span as one tensor when this step's
@@ -133,8 +281,13 @@ class FlatGradSync:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(self.group)
+        if self.overlap and self._arena_layout is None and self._inflight is None and self._flat is None:
+            raise RuntimeError("FlatGradSync(overlap=True): the first step's backward did not report the "
+                               "sparse executor's arena (attach() missing, or the model ran module by "
+                               "module); use overlap=False")
+        self._finish_inplace(world)   # (same position in every rank's sequence of collectives)
         flat, views = self._buffers()
-        used = [i for i, p in enumerate(self.params) if p.grad is not None]
+        used = [i for i, p in enumerate(self.params) if p.grad is not None and i not in self._covered]
         if not self.uniform_usage:
             flat.zero_()
         else:
@@ -190,7 +343,7 @@ class FlatGradSync:
                         "uniform_usage=False for such models")
             self._steps += 1
         if self.uniform_usage or len(used) == len(self.params):
-            anywhere = [p.grad is not None for p in self.params]
+            anywhere = [p.grad is not None and i not in self._covered for i, p in enumerate(self.params)]
         else:  # somebody else's parameters: one small read, only when this rank skipped some
             anywhere = (flat[self.numel:] > 0).tolist()
         if not avg:

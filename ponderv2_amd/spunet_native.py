@@ -27,6 +27,11 @@ from . import _lib, kernels as K, precision, rownorm, sidestream
 from ._lib import UNET_CONCAT, UNET_CONV_BN, UNET_STEM, UnetOp
 
 ENABLED = os.environ.get("PV2_NATIVE_UNET", "1") != "0"
+# A gradient reducer that wants the parameter-gradient arena from INSIDE the backward node
+# (ponder/utils/grad_sync.py FlatGradSync(overlap=True).attach()): an object with ``wants(tensors)``,
+# ``slab_elems`` and ``_on_arena(arena, members, slabs, events)``.
+GRAD_SLAB_HOOK = None
+_EVENT_POOL = {}
 CALLS = 0     # forward passes that ran natively (tests assert the path is the one being measured)
 _ALIGN = 64   # floats: every carved buffer starts on a 256-byte boundary
 
@@ -333,6 +338,48 @@ def _fill_forward(plan, feats, tensors):
     return ops
 
 
+def _gradient_slabs(plan, tensors, hook, parena):
+    """Slabs of the parameter-gradient arena in the order the backward completes them (the executor walks
+    the units last to first, the arena is laid out first to last): ([(parameter, offset, numel)],
+    [(lo, hi)], [unit index whose completion finishes the slab]) - or None when the reducer does not want
+    this plan.  The stem (unit 0; its weight travels zero-padded, so its gradient is not a parameter's
+    ``.grad``) stays outside the slabs."""
+    convs = [(i, u) for i, u in enumerate(plan.units) if u.kind == UNET_CONV_BN]
+    if len(convs) < 2:
+        return None
+    wanted = []
+    for _, u in convs:
+        wanted += list(tensors[u.w_index:u.w_index + 3])
+    if not hook.wants(wanted):
+        return None
+    members = []
+    for _, u in convs:
+        w, bw, bb = tensors[u.w_index:u.w_index + 3]
+        members += [(bb, u.gsum_off, u.c_out), (bw, u.gsum_off + u.c_out, u.c_out), (w, u.dw_off, w.numel())]
+    end = parena.size
+    spans, units = [], []
+    hi = end
+    for pos in range(len(convs) - 1, -1, -1):
+        i, u = convs[pos]
+        if hi - u.gsum_off >= hook.slab_elems or pos == 0:
+            spans.append((u.gsum_off, hi))
+            units.append(i)
+            hi = u.gsum_off
+    return members, spans, units
+
+
+def _slab_events(dev, n):
+    """n reusable (training stream, side stream) event pairs of this device, created once (a torch event
+    has no handle before its first record)."""
+    pool = _EVENT_POOL.setdefault(dev.index, [])
+    while len(pool) < n:
+        pair = (torch.cuda.Event(), torch.cuda.Event())
+        for e in pair:
+            e.record(torch.cuda.current_stream(dev))
+        pool.append(pair)
+    return pool[:n]
+
+
 class SpUNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, plan, *tensors):
@@ -404,9 +451,24 @@ class SpUNetFunction(torch.autograd.Function):
             part = K.workspace("wgrad", dev, part_floats)
         prod = K.workspace("prod", dev, plan.max_prod)
         stats = rownorm._workspace(dev, plan.max_c)
-        _lib.check(_lib.lib().pv2_unet_backward(
-            ops, len(ops), K._ptr(prod), K._ptr(stats), K._ptr(part), K._stream(grad_out),
-            ctypes.c_void_p(side.cuda_stream) if side is not None else None), "pv2_unet_backward")
+        hook, slabs = GRAD_SLAB_HOOK, None
+        if hook is not None:
+            slabs = _gradient_slabs(plan, tensors, hook, parena)
+        if slabs is None:
+            _lib.check(_lib.lib().pv2_unet_backward(
+                ops, len(ops), K._ptr(prod), K._ptr(stats), K._ptr(part), K._stream(grad_out),
+                ctypes.c_void_p(side.cuda_stream) if side is not None else None), "pv2_unet_backward")
+        else:
+            members, spans, units = slabs
+            events = _slab_events(dev, len(spans))
+            unit_arr = (ctypes.c_int32 * len(units))(*units)
+            ev_main = (ctypes.c_void_p * len(units))(*[e[0].cuda_event for e in events])
+            ev_side = (ctypes.c_void_p * len(units))(*[e[1].cuda_event for e in events])
+            _lib.check(_lib.lib().pv2_unet_backward_ev(
+                ops, len(ops), K._ptr(prod), K._ptr(stats), K._ptr(part), K._stream(grad_out),
+                ctypes.c_void_p(side.cuda_stream) if side is not None else None, len(units), unit_arr,
+                ev_main, ev_side), "pv2_unet_backward_ev")
+            hook._on_arena(parena.tensor, members, spans, events)
         grads = [None] * len(tensors)
         convs = [u for u in plan.units if u.kind != UNET_CONCAT]
         specs = []

@@ -148,6 +148,101 @@ def arena_sync_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def overlap_sync_worker(rank, world, port, out_dir):
+    """FlatGradSync(overlap=True): slabs of an executor-style arena reduced in place from the hook give,
+    BIT FOR BIT, the averages of the flat (everything after backward) form - in steps where the hook
+    fired on both ranks, on one rank only (the other stages the same slabs inside sync()), on neither;
+    and a rank that finds no arena family on its first step still issues the layout-agreement reduce
+    (ADVICE round 4)."""
+    from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(30)], torch.nn.Linear(96, 3))
+
+    model_a, model_b = make(), make()
+    pa, pb = list(model_a.parameters()), list(model_b.parameters())
+    over = FlatGradSync(pa, slice_mb=0.02, overlap=True, slab_mb=0.1)
+    flat = FlatGradSync(pb, slice_mb=0.02, overlap=False)
+    # the "executor" owns all but the first and the last layer (stem-like / head-like parameters stay
+    # ordinary tensors); arena laid out first to last, 64-float aligned
+    owned = list(range(2, len(pa) - 2))
+    offs, off = {}, 0
+    for i in owned:
+        offs[i] = off
+        off += (pa[i].numel() + 63) // 64 * 64
+    arena_numel = off
+    spans, hi = [], arena_numel
+    for i in reversed(owned):
+        if hi - offs[i] >= over.slab_elems or i == owned[0]:
+            spans.append((offs[i], hi))
+            hi = offs[i]
+    assert len(spans) >= 3
+
+    def local(step):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        return [torch.randn(p.shape, generator=g) for p in pa]
+
+    ok = True
+    for step, fired in enumerate([True, True, rank == 0, False, True]):
+        grads = local(step)
+        for p, gr in zip(pb, grads):
+            p.grad = gr.clone()
+        assert over.wants([pa[i] for i in owned]) or step > 0
+        if fired:
+            arena = torch.full((arena_numel,), float("nan"))
+            for i in owned:
+                arena[offs[i]:offs[i] + pa[i].numel()].copy_(grads[i].reshape(-1))
+            over._on_arena(arena, [(pa[i], offs[i], pa[i].numel()) for i in owned], spans, None)
+            for i in owned:   # what AccumulateGrad does with the executor's views
+                pa[i].grad = arena[offs[i]:offs[i] + pa[i].numel()].view_as(pa[i])
+        else:
+            for i in owned:
+                pa[i].grad = grads[i].clone()
+        for i in set(range(len(pa))) - set(owned):
+            pa[i].grad = grads[i].clone()
+        over.sync()
+        flat.sync()
+        ok = ok and all(torch.equal(a.grad, b.grad) for a, b in zip(pa, pb))
+        want = []
+        for gr in grads:
+            t = gr.clone()
+            dist.all_reduce(t)
+            want.append(t / world)
+        ok = ok and all(torch.allclose(a.grad, w, atol=1e-6) for a, w in zip(pa, want))
+    # ADVICE r4: rank 1 has NO arena family on the first synchronised step, rank 0 has one
+    model_c = make()
+    pc = list(model_c.parameters())
+    third = FlatGradSync(pc, slice_mb=0.02)
+    grads = local(77)
+    if rank == 0:
+        sizes = [(p.numel() + 63) // 64 * 64 for p in pc]
+        arena = torch.zeros(sum(sizes))
+        o = 0
+        for p, gr, n in zip(pc, grads, sizes):
+            v = arena[o:o + p.numel()].view_as(p)
+            v.copy_(gr)
+            p.grad = v
+            o += n
+    else:
+        for p, gr in zip(pc, grads):
+            p.grad = gr.clone()
+    third.sync()
+    for gr, p in zip(grads, pc):
+        t = gr.clone()
+        dist.all_reduce(t)
+        ok = ok and torch.allclose(p.grad, t / world, atol=1e-6)
+    torch.save(dict(rank=rank, ok=bool(ok), slabs=len(spans), covered=len(over._covered),
+                    blocks_third=len(third._blocks)),
+               os.path.join(out_dir, f"overlap{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def trainer_main(cfg):
     """main_func for engines.launch(): two optimisation steps of the hook-driven Trainer."""
     from oracle import cpu_backend

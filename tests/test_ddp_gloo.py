@@ -46,6 +46,20 @@ def test_flat_grad_sync_moves_arena_gradients_as_blocks(tmp_path):
         assert res["blocks"] == 1 and res["block_members"] == 60, res
 
 
+@pytest.mark.timeout(900)
+def test_overlapped_slab_reduction_equals_the_flat_reduction_bit_for_bit(tmp_path):
+    """FlatGradSync(overlap=True) - slabs of the executor's gradient arena all-reduced in place from the
+    backward hook - against the flat form on the same gradients: identical bits on both ranks in every
+    mix of hook / staged steps; and the layout-agreement reduce is issued by a rank without an arena."""
+    world = 2
+    mp.spawn(ddp_worker.overlap_sync_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f"overlap{r}.pt")
+        assert res["ok"], res
+        assert res["slabs"] >= 3 and res["covered"] == 58 and res["blocks_third"] == 0, res
+
+
 def test_trainer_two_ranks_via_launch(tmp_path):
     """engines.launch spawns one process per 'GPU', DistributedSampler shards the scenes, hooks
     log and checkpoint on rank 0."""
