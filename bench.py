@@ -730,12 +730,17 @@ def clone_batch(batch):
 
 
 def cpu_baseline(args):
-    """the same model code on the host cores through the oracle's CPU kernels
-    (kind "port"; spconv itself is absent, so there is no runnable reference CPU backbone),
-    BASELINE configs[0]: one scene of 20 000 voxels, 2 views x 64 = 128 rays, fp32.  One warm-up
-    step, then the MEDIAN of three timed training steps (forward + backward + SGD); the SparseUNet
-    forward alone (the north star's CPU baseline item) and the rulebook build are timed separately,
-    median of three each.  ~30 s of host work on the GPU box's 128 cores."""
+    """SURVEY 8(d) / BASELINE.md section 3: the same model code on the host cores through the oracle's
+    CPU kernels (kind "port"; spconv itself is absent, so there is no runnable reference CPU backbone,
+    and the GPU box has no reference checkout).  Round 5:
+      * THREAD SWEEP {8, 16, 32, 64, all}: the per-offset GEMMs of the oracle are tiny, and
+        ``set_num_threads(cpu_count)`` on a 128-core box oversubscribes them (11.0 s for a forward that
+        takes 3.4 s on 8 cores); the SparseUNet forward is timed per thread count (1 warm-up + 2 timed)
+        and everything below runs at the best one, which is what ``cores`` reports;
+      * 2 warm-up + 5 timed iterations, median, as BASELINE.md section 3 says;
+      * the train step of configs[0] (1 scene, 20 000 voxels, 128 rays: the reference's own
+        CPU-runnable case) = ``value``; the SparseUNet forward ALSO on the benched 46 842-voxel batch of
+        configs[1] (``sparse_unet_forward_bench_s``), next to the GPU's number for the same batch."""
     import statistics
 
     from oracle import cpu_backend, rulebook as orb
@@ -743,48 +748,71 @@ def cpu_baseline(args):
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    torch.manual_seed(0)
-    with cpu_backend.installed():
-        model = build_model(ConfigDict(model_cfg(64))).train()
-        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True,
-                              weight_decay=1e-4)
-        batch = collate_fn([make_scene(0, num_views=2, image_hw=(480, 640), n_voxels=20000)])
-
-        def step():
+    def timed(fn, warm, n):
+        for _ in range(warm):
+            fn()
+        out = []
+        for _ in range(n):
             t0 = time.perf_counter()
-            out = model(clone_batch(batch))
-            t1 = time.perf_counter()
-            opt.zero_grad()
-            out["loss"].backward()
-            opt.step()
-            return t1 - t0, time.perf_counter() - t0
+            fn()
+            out.append(time.perf_counter() - t0)
+        return statistics.median(out)
 
-        step()  # warm-up (allocator, thread pools, oneDNN primitive caches)
-        timed = [step() for _ in range(3)]
-        t_fwd = statistics.median(t[0] for t in timed)
-        t_step = statistics.median(t[1] for t in timed)
-        backbone = []
-        with torch.no_grad():
-            for _ in range(3):
-                tb = time.perf_counter()
-                model.backbone(clone_batch(batch))
-                backbone.append(time.perf_counter() - tb)
-        t_backbone = statistics.median(backbone)
-    coords = torch.cat([torch.zeros(len(batch["grid_coord"]), 1, dtype=torch.long),
-                        batch["grid_coord"]], 1).int().numpy()
-    rb = []
-    for _ in range(3):
-        tr = time.perf_counter()
-        orb.subm_rulebook(coords, 3)
-        rb.append(time.perf_counter() - tr)
-    return dict(value=1.0 / t_step, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
+    ncpu = os.cpu_count() or 1
+    threads_before = torch.get_num_threads()
+    torch.manual_seed(0)
+    try:
+        with cpu_backend.installed():
+            model = build_model(ConfigDict(model_cfg(64))).train()
+            opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True,
+                                  weight_decay=1e-4)
+            batch = collate_fn([make_scene(0, num_views=2, image_hw=(480, 640), n_voxels=20000)])
+
+            def backbone_fwd(b=batch):
+                with torch.no_grad():
+                    model.backbone(clone_batch(b))
+
+            sweep = {}
+            for nt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+                torch.set_num_threads(nt)
+                sweep[nt] = timed(backbone_fwd, 1, 2)
+            best = min(sweep, key=sweep.get)
+            torch.set_num_threads(best)
+            t_backbone = timed(backbone_fwd, 2, 5)
+            fwd_times = []
+
+            def step():
+                t0 = time.perf_counter()
+                out = model(clone_batch(batch))
+                fwd_times.append(time.perf_counter() - t0)
+                opt.zero_grad()
+                out["loss"].backward()
+                opt.step()
+
+            t_step = timed(step, 2, 5)
+            t_fwd = statistics.median(fwd_times[2:])
+            # the benched batch (configs[1]: 2 scenes, 46 842 voxels) through the same backbone
+            bench_batch = collate_fn([make_scene(1000 * 0 + i, num_views=2, image_hw=(480, 640))
+                                      for i in range(2)])
+            n_bench = int(bench_batch["offset"][-1])
+            t_backbone_bench = timed(lambda: backbone_fwd(bench_batch), 2, 5)
+        coords = torch.cat([torch.zeros(len(batch["grid_coord"]), 1, dtype=torch.long),
+                            batch["grid_coord"]], 1).int().numpy()
+        t_rb = timed(lambda: orb.subm_rulebook(coords, 3), 0, 3)
+    finally:
+        torch.set_num_threads(threads_before)
+    return dict(value=1.0 / t_step, unit="scenes/s", cores=best, kind="port",
                 sample="configs[0]: 1 scene (20000 voxels, 2 views x 64 = 128 rays), train step "
-                       "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels; 1 warm-up + "
-                       f"median of 3 (SparseUNet forward alone {t_backbone:.2f} s, model forward "
-                       f"{t_fwd:.2f} s, step {t_step:.2f} s, level-0 k3 rulebook build "
-                       f"{statistics.median(rb):.2f} s)",
-                rays_per_s=128.0 / t_step, sparse_unet_forward_s=t_backbone, forward_s=t_fwd,
-                step_s=t_step, rulebook_build_s=statistics.median(rb))
+                       "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels; thread sweep "
+                       f"{ {k: round(v, 2) for k, v in sweep.items()} } s per SparseUNet forward -> {best} "
+                       f"threads of {ncpu}; 2 warm-up + median of 5 (SparseUNet forward alone "
+                       f"{t_backbone:.2f} s, on the benched {n_bench}-voxel batch {t_backbone_bench:.2f} s; "
+                       f"model forward {t_fwd:.2f} s, step {t_step:.2f} s, level-0 k3 rulebook build "
+                       f"{t_rb:.2f} s)",
+                rays_per_s=128.0 / t_step, sparse_unet_forward_s=t_backbone,
+                sparse_unet_forward_bench_s=t_backbone_bench, bench_batch_voxels=n_bench,
+                thread_sweep_s={str(k): v for k, v in sweep.items()}, host_cores=ncpu,
+                forward_s=t_fwd, step_s=t_step, rulebook_build_s=t_rb)
 
 
 def main():
@@ -915,13 +943,18 @@ def main():
             if gsync is not None:
                 gsync.sync()
             scaler.step(opt)
+            # the scheduler advances only when the optimizer step was not skipped - the reference's
+            # get_scale() comparison (ponder/engines/train.py:191-195; one device read, as there)
+            before = scaler.get_scale()
             scaler.update()
+            if before <= scaler.get_scale():
+                sched.step()
         else:
             out["loss"].backward()
             if gsync is not None and not SKIP_SYNC:
                 gsync.sync()
             opt.step()
-        sched.step()
+            sched.step()
         if args.print_losses and rank == 0:
             print("loss", {k: round(float(v.detach()), 5) for k, v in out.items()}, flush=True)
         return out

@@ -767,8 +767,11 @@ __global__ __launch_bounds__(256) void spconv_wgrad_split_kernel(
   };
   auto put = [&](unsigned* row, const float4& v0, const float4& v1, float z0, float z1, int q)
       __attribute__((always_inline)) {
-    const float x0[4] = {v0.x * z0, v0.y * z0, v0.z * z0, v0.w * z0};
-    const float x1[4] = {v1.x * z1, v1.y * z1, v1.z * z1, v1.w * z1};
+    // (a SELECT, not a product with 0 / 1: the padding pairs read row 0, and 0 * inf = NaN would carry
+    // a non-finite entry of row 0 into every tile's tail - round 5 range tests)
+    const bool k0 = z0 != 0.f, k1 = z1 != 0.f;
+    const float x0[4] = {k0 ? v0.x : 0.f, k0 ? v0.y : 0.f, k0 ? v0.z : 0.f, k0 ? v0.w : 0.f};
+    const float x1[4] = {k1 ? v1.x : 0.f, k1 ? v1.y : 0.f, k1 ? v1.z : 0.f, k1 ? v1.w : 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float a1 = pv2::bf16_rest(x0[j]), b1 = pv2::bf16_rest(x1[j]);

@@ -213,7 +213,7 @@ def run_ponder_indoor_cfg1(device, with_float64=True):
                                   name="ponder_indoor_cfg1", with_float64=with_float64)
 
 
-def run_ponder_ppt_full(device, condition_index, with_float64=True):
+def run_ponder_ppt_full(device, condition_index, with_float64=True, real_init=False):
     """BASELINE.json configs[3] at FULL size, one batch of one condition: the shipped multi-dataset
     model (SpUNet-v1m3 PDNorm at full width and depth, 128x128x32 grid, UNet3D-v1m2, NeuS head, 512
     rays per scene) against the reference's own step (oracle/make_golden.py::ponder_ppt_full_case)."""
@@ -227,7 +227,9 @@ def run_ponder_ppt_full(device, condition_index, with_float64=True):
                valid_index=PPT_VALID, template=("a", "b"))
     kw = dict(num_views=2, image_hw=(480, 640), condition=cond, num_classes=len(PPT_VALID[condition_index]))
     batch = collate_fn([make_scene(700 + 10 * condition_index + i, **kw) for i in range(2)])
-    return _run_indoor_full(device, cfg, batch, "ponder_ppt_full_" + cond.lower(), with_float64)
+    return _run_indoor_full(device, cfg, batch,
+                            "ponder_ppt_full_" + cond.lower() + ("_real_init" if real_init else ""),
+                            with_float64, real_init=real_init)
 
 
 def run_ponder_indoor_cfg0(device, scenes=1, rays_per_view=64, n_voxels=20000,
@@ -296,6 +298,10 @@ def _run_indoor_full(device, cfg, batch, name, with_float64=True, real_init=Fals
         errs[str(name)] = abs(float(out[str(name)].detach()) - val) / (abs(val) + 1e-12)
     for key in ("rgb", "depth", "normal"):
         errs["render_" + key] = rel_err(torch.cat(rendered[key]), g["render_" + key])
+    for key in ("rgb", "depth"):
+        if "render64_" + key in g.files:   # the reference's FLOAT64 render: ours / the reference's fp32 one
+            errs["render64_" + key] = rel_err(torch.cat(rendered[key]), g["render64_" + key])
+            errs["ref32_render64_" + key] = rel_err(torch.from_numpy(g["render_" + key]), g["render64_" + key])
     params = dict(model.named_parameters())
     for i, name in enumerate(g["grad_names"]):
         errs["grad_" + str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
@@ -366,7 +372,7 @@ def check_float64_gradients_tight(f64):
     assert f64["worst_tensor_rel"] <= max(3.0 * f64["worst_tensor_ref32_rel"], 5e-3), f64
 
 
-def check_float64_gradients(f64):
+def check_float64_gradients(f64, closed_form=True):
     """The GPU's fp32 gradients are as close to the reference's float64 gradients as fp32 arithmetic
     lets ANY implementation be on these fixtures.  The yardstick is the reference's own fp32 pass
     against its own float64 pass, recorded in the fixtures: global relative error 1.2e-3 ... 1.1e-1
@@ -376,6 +382,10 @@ def check_float64_gradients(f64):
     of the gradient, on either side, so the size of the error is a property of the batch, not of the
     implementation.  Hence: within 3x of the reference's own fp32 error, or below 15 % where the
     reference happened to land close (measured on MI355X: 7.8e-3 ... 1.1e-1)."""
+    # (closed_form=False - any fixture made with the reference's REAL initialisation - has no business
+    # here: those are held by check_float64_gradients_tight; the 15 % floor exists for the closed-form
+    # weights only, VERDICT r4 item 2b)
+    assert closed_form, "real-initialisation fixtures use check_float64_gradients_tight"
     assert f64["tensors"] > 200, f64
     for key in ("global_rel", "backbone_rel"):
         ref = f64["ref32_" + key]
@@ -448,7 +458,7 @@ def run_ponder_outdoor(device):
     return errs
 
 
-def run_ponder_outdoor_full(device, with_float64=True):
+def run_ponder_outdoor_full(device, with_float64=True, real_init=False):
     """BASELINE.json configs[4] at FULL size, one sweep: the reference's nuScenes model section
     unchanged (SpUNet-v1m1 32..256 over a 1080 x 1080 x 80 voxel range, 180 x 180 x 5 dense grid,
     SimpleConv3D, 16-wide five-block SDF MLP, 72 + 24 samples, 6 x 512 rays, mask ratio 0.8) against
@@ -457,10 +467,13 @@ def run_ponder_outdoor_full(device, with_float64=True):
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    g = np.load(os.path.join(GOLDEN, "ponder_outdoor_full.npz"))
+    g = np.load(os.path.join(GOLDEN, "ponder_outdoor_full%s.npz" % ("_real_init" if real_init else "")))
     cfg = outdoor_model_cfg(dict(FULL_BACKBONE, in_channels=4))
+    if real_init:
+        torch.manual_seed(0)     # the reference's own initialisation, drawn from the same seed
     model = build_model(ConfigDict(cfg))
-    fill_deterministic(model)
+    if not real_init:
+        fill_deterministic(model)
     model = model.to(device).train()
     replay = ReplayRand([g[f"rand_{i}"] for i in range(int(g["rands"]))], device)
     model.renderer.sampler.initial_sampler.rand = replay

@@ -80,7 +80,7 @@ def _check_full_size(errs, flips):
     f64 = errs.pop("float64", None)
     print(errs, "bin flips", flips, "float64 gradient record", f64)
     assert flips == 0
-    losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render_"))}
+    losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render", "ref32_"))}
     assert max(losses.values()) < 1e-4, errs
     assert max(errs["render_rgb"], errs["render_depth"]) < 1e-4, errs   # the north star's RGB-D
     # the composited normal sums g / |g| over samples whose gradient is ~0 outside the scene:
@@ -116,14 +116,52 @@ def test_ponder_indoor_full_size_config1_real_initialisation_tight_gradients(dev
     f64 = errs.pop("float64")
     print(errs, "bin flips", flips, "float64 gradient record", f64)
     assert flips == 0
-    losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render_"))}
+    losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render", "ref32_"))}
     assert max(losses.values()) < 1e-4, errs
     gc.check_float64_gradients_tight(f64)
-    # per-ray RGB-D: the fixture's values are the reference's FP32 render of an untrained field (SDF
-    # weights ~ N(0, 0.02): nearly flat alphas, so a ray's depth is a sum of ~132 almost equal
-    # weights and fp32 rounding of either side moves it by 1e-3 of the range; measured 1.5e-4 / 7.4e-4).
-    # The trained-looking closed-form fixtures hold the 1e-4 of the north star (tests above).
-    assert max(errs["render_rgb"], errs["render_depth"]) < 2e-3, errs
+    _check_real_init_render(errs)
+
+
+def _check_real_init_render(errs):
+    """Per-ray RGB-D of a real-initialisation fixture against the reference's FLOAT64 render (round 5,
+    VERDICT r4 item 2c): an untrained field (SDF weights ~ N(0, 0.02)) has nearly flat alphas, a ray's
+    depth is a sum of ~132 almost equal weights, and fp32 rounding moves it by ~1e-3 of the range on
+    EITHER side - the fixture records how far the reference's own fp32 render is from its float64 one.
+    Bar: the north star's 1e-4 plus that distance (as the outdoor loss is held), never above 1e-3."""
+    for key in ("rgb", "depth"):
+        slack = errs["ref32_render64_" + key]
+        assert errs["render64_" + key] < 1e-4 + slack, errs
+        assert errs["render64_" + key] < 1e-3, errs
+
+
+@pytest.mark.parametrize("condition_index", [0, 1, 2])
+def test_ponder_ppt_full_size_real_initialisation_tight_gradients(device, condition_index):
+    """BASELINE.json configs[3] at FULL size with the reference's REAL initialisation, one batch per
+    condition (oracle/make_golden.py ppt_full_real): losses to 1e-4, sampler bins bit-exact, the whole
+    chain of gradient tensors within 1e-3 of the reference's float64 gradients (or twice the
+    reference's own fp32 distance), RGB-D against the float64 render."""
+    errs, flips = gc.run_ponder_ppt_full(device, condition_index, real_init=True)
+    f64 = errs.pop("float64")
+    print(errs, "bin flips", flips, "float64 gradient record", f64)
+    assert flips == 0
+    losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render", "ref32_"))}
+    assert max(losses.values()) < 1e-4, errs
+    gc.check_float64_gradients_tight(f64)
+    _check_real_init_render(errs)
+
+
+def test_ponder_outdoor_full_size_real_initialisation_tight_gradients(device):
+    """BASELINE.json configs[4] at FULL size with the reference's REAL initialisation: loss within 1e-4
+    of the fp32 step plus that step's own distance from its float64 pass, every gradient tensor against
+    the float64 record with the tight bound."""
+    errs = gc.run_ponder_outdoor_full(device, real_init=True)
+    f64 = errs.pop("float64")
+    print(errs, "float64 gradient record", f64)
+    for name in ("loss", "depth_loss"):
+        slack = errs["ref32_f64_" + name]
+        assert errs[name] < 1e-4 + slack, errs
+        assert errs["f64_" + name] < 1e-4 + slack, errs
+    gc.check_float64_gradients_tight(f64)
 
 
 def test_ponder_indoor_full_size_config1_default_kernels_five_runs(device):
@@ -141,7 +179,7 @@ def test_ponder_indoor_full_size_config1_default_kernels_five_runs(device):
     for run in range(5):
         errs, flips = gc.run_ponder_indoor_cfg1(device, with_float64=(run == 0))
         errs.pop("float64", None)
-        terms = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render_"))}
+        terms = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render", "ref32_"))}
         assert flips == 0, (run, flips)
         assert max(terms.values()) < 1e-4, (run, errs)
         assert max(errs["render_rgb"], errs["render_depth"]) < 1e-4, (run, errs)

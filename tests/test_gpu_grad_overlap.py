@@ -1,0 +1,77 @@
+"""The overlapped gradient reduction on the device with a ONE-rank RCCL process group: the sparse
+executor's backward records its per-slab events (pv2_unet_backward_ev), FlatGradSync(overlap=True)
+all-reduces the slabs in place behind them on a communication stream, and with one rank the averages
+must be the local gradients, bit for bit (reference: DistributedDataParallel's overlapped buckets,
+ponder/engines/defaults.py:22-43).  Run with -m gpu on an MI355X."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import ddp_worker
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
+    from ponderv2_amd import spunet_native
+    from ponderv2_amd.ponder.datasets import collate_fn
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+    from ponderv2_amd.ponder.utils.grad_sync import FlatGradSync
+
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
+                                device_id=device)
+    try:
+        torch.manual_seed(5)
+        model = build_model(ConfigDict(ddp_worker.tiny_model_cfg())).to(device).train()
+        batch = collate_fn([ddp_worker.tiny_scene(60), ddp_worker.tiny_scene(61)])
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+        def step(sync):
+            torch.manual_seed(9)
+            model.zero_grad(set_to_none=True)
+            calls = spunet_native.CALLS
+            out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            out["loss"].backward()
+            assert spunet_native.CALLS == calls + 1      # the native executor ran
+            if sync is not None:
+                sync.sync()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        local = step(None)
+        # (small slabs: the tiny backbone's arena is ~3 MB; several slabs -> several event pairs)
+        sync = FlatGradSync(model.parameters(), overlap=True, slab_mb=0.5).attach()
+        try:
+            first = step(sync)
+            second = step(sync)
+        finally:
+            sync.detach()
+        assert sync._arena_layout is not None and len(sync._arena_layout[1]) >= 3
+        assert len(sync._covered) > 100
+        assert first.keys() == local.keys()
+        def close(a, b):
+            return (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-20)
+
+        for n in local:
+            # (BatchNorm running statistics moved between the passes; train-mode gradients do not see
+            # them.  Not bitwise: the float atomics left on the path - scatter-mean, the sampler's volume
+            # gradient - reorder between passes, see test_gpu_trainer.py)
+            assert close(first[n], local[n]) and close(second[n], local[n]), n
+        # the covered gradients are views of the executor's arena, reduced in place
+        covered = [model_p for i, model_p in enumerate(sync.params) if i in sync._covered]
+        assert len({p.grad.untyped_storage().data_ptr() for p in covered}) == 1
+    finally:
+        if created:
+            dist.destroy_process_group()
