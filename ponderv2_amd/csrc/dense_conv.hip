@@ -1766,7 +1766,9 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   static const int split_mt = env_int("PV2_DSPLIT_MT", 1);
   if (split && cells_t >= 262144 && in_mask_src == nullptr) mt = split_mt;
   static const int force_mt = env_int("PV2_DCONV_MT", 0), force_nb = env_int("PV2_DCONV_NB", 0);
-  if (mode == 0 && force_mt) mt = force_mt;
+  // (the forced two-tile variant has no masked form on the bf16-piece path: with a ReLU mask the knob is
+  // ignored there, as the automatic choice already does - it used to drop the mask silently)
+  if (mode == 0 && force_mt && !(split && force_mt == 2 && in_mask_src != nullptr)) mt = force_mt;
   pick_tile(128 * mt, g.Zt, g.Yt, g.Xt, &g.TZ, &g.eTZ, &g.TY, &g.TX);
   g.lTX = ilog2(g.TX), g.lTY = ilog2(g.TY);
   g.nTZ = (g.Zt + g.eTZ - 1) / g.eTZ, g.nTY = (g.Yt + g.TY - 1) / g.TY, g.nTX = (g.Xt + g.TX - 1) / g.TX;

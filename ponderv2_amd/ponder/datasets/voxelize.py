@@ -130,7 +130,10 @@ def grid_sample_torch(coord, grid_size, hash_type="fnv", pick=None):
     count = torch.diff(start, append=start.new_tensor([skey.numel()]))
     if pick is None:
         pick = torch.randint(0, int(count.max()), (count.numel(),), device=coord.device)
-    idx_unique = order[start + pick.to(start.device) % count]
+    # (draws are reduced modulo the LARGEST member count first - a no-op for the reference's own draws,
+    # ``randint(0, count.max())`` - and then modulo the voxel's: exactly what the device kernel does with
+    # caller-supplied or raw 31-bit draws, so the two paths pick the same point for ANY draw)
+    idx_unique = order[start + (pick.to(start.device) % count.max()) % count]
     return idx_unique, grid[idx_unique]
 
 

@@ -507,8 +507,15 @@ class PonderIndoor(nn.Module):
             data_dict = fn(data_dict)
         if (PREFETCH_RAYS and self.training and "_ray_dict" not in data_dict
                 and ray_setup.usable(self, data_dict)):
+            # prepare_ray rewrites coord / extrinsic / depth_scale to unit-cube values; in the reference
+            # (and without the prefetch) extract_feature runs FIRST, on the metric ones.  The metric tensors
+            # are kept and put back for the backbone / masking in _forward, so a backbone that reads
+            # ``coord`` sees the same thing on every path.  What does differ between the paths
+            # is the ORDER of the random draws (pixel choice before the masking draw here).
+            metric = {k: data_dict[k] for k in ("coord", "extrinsic", "depth_scale") if k in data_dict}
             ray_dict, data_dict = ray_setup.prepare_ray(self, data_dict)
             data_dict["_ray_dict"] = ray_dict
+            data_dict["_metric_inputs"] = metric
             if self._use_cells():
                 # ... and the geometry of the projection network's first level (which cells are
                 # occupied, the cell -> grid-row pairs of its convolution): coordinates only
@@ -537,7 +544,14 @@ class PonderIndoor(nn.Module):
             return self._forward(data_dict)
 
     def _forward(self, data_dict):
-        data_dict = self.extract_feature(data_dict)
+        metric = data_dict.pop("_metric_inputs", None)
+        if metric:   # the rays were set up ahead of time: the backbone still sees the metric inputs
+            unit = {k: data_dict[k] for k in metric}
+            data_dict.update(metric)
+            data_dict = self.extract_feature(data_dict)
+            data_dict.update(unit)
+        else:
+            data_dict = self.extract_feature(data_dict)
         ray_dict = data_dict.pop("_ray_dict", None)     # set up with the batch, one step ahead (prefetch)
         if ray_dict is None:
             ray_dict, data_dict = self.prepare_ray(data_dict)
