@@ -555,9 +555,15 @@ def _record_stream(obj, stream, _seen=None):
         for v in obj:
             _record_stream(v, stream, seen)
     elif isinstance(obj, Rulebook):
-        _record_stream(list(vars(obj).values()), stream, seen)
+        # (element by element: a TEMPORARY list here would enter `seen` by its id, be freed on return, and
+        # the next rulebook's temporary could be handed the same address - and be skipped whole, leaving
+        # its tensors unrecorded: a use-after-free on the training stream, found in round 5 as a memory
+        # fault of bench.py once the plans added more such temporaries)
+        for v in vars(obj).values():
+            _record_stream(v, stream, seen)
     elif isinstance(obj, OsmPlanData):
-        _record_stream([obj.perm, obj.tblp, obj.tmask], stream, seen)
+        for v in (obj.perm, obj.tblp, obj.tmask):
+            _record_stream(v, stream, seen)
 
 
 _GEOMETRY_STREAMS = {}

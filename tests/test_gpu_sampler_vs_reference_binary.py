@@ -38,6 +38,11 @@ def test_three_entry_points_equal_the_reference_binary(device, ref, dtype, tol, 
                                                        align_corners, smooth):
     from ponderv2_amd import kernels as K
 
+    if dtype == torch.float64 and smooth:
+        # the reference evaluates its smoothstep in SINGLE precision whatever the tensor type
+        # (smooth_sampler_kernel.cu:27-37 ``float smoothstep(float)``): in float64 it is only float-exact,
+        # the product's double path is (measured 1.1e-7 apart on MI355X, everything else 1e-15)
+        tol = 1e-6
     torch.manual_seed(17)
     B, C, D, H, W, R, S = 2, 12, 5, 7, 9, 33, 13
     vol = torch.randn(B, C, D, H, W, dtype=dtype)
