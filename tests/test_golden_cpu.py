@@ -109,10 +109,22 @@ def test_seeded_initialisation_equals_the_reference_model():
     cfg = gc.indoor_model_cfg(dict(gc.SMALL_BACKBONE, channels=(16, 32, 48, 64, 64, 48, 32, 96)),
                               grid_shape=(32, 32, 8), ray_nsample=20)
     cfg["template"] = ("a", "b")
-    torch.manual_seed(0)
-    ref = MODELS.build(ConfigDict(cfg)).state_dict()
-    torch.manual_seed(0)
-    mine = build_model(ConfigDict(cfg)).state_dict()
-    assert list(ref) == list(mine)
-    for k in ref:
-        assert torch.equal(ref[k], mine[k]), k
+    # round 5: the multi-dataset model (SpUNet-v1m3 PDNorm, configs[3]) and the outdoor model (configs[4])
+    # carry real-initialisation fixtures too - same check for their classes
+    ppt = gc.indoor_model_cfg(dict(gc.PDNORM_BACKBONE, context_channels=256,
+                                   channels=(16, 32, 48, 64, 64, 48, 32, 96)),
+                              grid_shape=(32, 32, 8), ray_nsample=20)
+    ppt.update(conditions=gc.PPT_CONDITIONS, class_name=tuple(f"class {i}" for i in range(36)),
+               valid_index=gc.PPT_VALID, template=("a", "b"))
+    outdoor = gc.outdoor_model_cfg(dict(gc.SMALL_BACKBONE, in_channels=4,
+                                        channels=(16, 32, 48, 64, 64, 48, 32, 96)), **gc.OUTDOOR_SMALL)
+    for name, c, classes in (("indoor", cfg, 20), ("ppt", ppt, 36), ("outdoor", outdoor, 16)):
+        ref_shims.install(num_classes=classes)
+        torch.manual_seed(0)
+        ref = MODELS.build(ConfigDict(c)).state_dict()
+        torch.manual_seed(0)
+        mine = build_model(ConfigDict(c)).state_dict()
+        assert list(ref) == list(mine), name
+        for k in ref:
+            assert torch.equal(ref[k], mine[k]), (name, k)
+    ref_shims.install()
