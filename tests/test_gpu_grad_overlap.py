@@ -66,8 +66,11 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
         assert sync._arena_layout is not None and len(sync._arena_layout[1]) >= 3
         assert len(sync._covered) > 40
         assert first.keys() == local.keys()
+        floor = 1e-6 * max(g.abs().max().item() for g in local.values())   # (parameters in front of a
+        # BatchNorm have an exactly-zero true gradient: rounding noise ~1e-9 on either side)
+
         def close(a, b):
-            return (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-20)
+            return (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + floor
 
         for n in local:
             # (BatchNorm running statistics moved between the passes; train-mode gradients do not see
