@@ -51,7 +51,7 @@ def mfma_peak_of(family, default):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-PMC_FILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
+PMC_FILE = "profiles/r05_pmc_fetch_write_per_kernel.json"
 
 
 def kernel_source_hash():

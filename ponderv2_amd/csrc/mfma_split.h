@@ -10,6 +10,15 @@
 // 2.2e-7 of sum |a b| at K = 256, the fp32 MFMA's own is 3.1e-7; 307 against 134 TFLOP/s in the inner
 // loop with its companions).  The sparse and dense convolutions use it for every fp32 product.
 //
+// Range (tests/test_gpu_split_range.py, round 5).  The split is exact for every finite float whose pieces
+// are normal bf16 numbers, i.e. down to ~2^-110; below that the smaller pieces are bf16 subnormals, which
+// the matrix pipe flushes: operands in 2^-126 .. 2^-110 lose their low bits gradually (measured 1.2e-6 of
+// sum|ab| at 2^-120 .. 2^-112), fp32 SUBNORMAL operands may vanish altogether.  Near FLT_MAX nothing
+// overflows that fp32 would not (pieces only shrink).  Non-finite operands: inf splits into (inf, NaN, NaN)
+// (inf - inf in bf16_rest) and a product with a zero piece of the other operand is inf * 0 - so an Inf
+// input surfaces as NaN where the fp32 MFMA would give Inf.  The SET of non-finite outputs is the same
+// (asserted per kernel family); an isfinite check - all a GradScaler does with it - cannot tell them apart.
+//
 // Operand layout of v_mfma_f32_32x32x16_bf16: lane (i = lane & 31, h = lane >> 5) holds the eight
 // reduction steps 8 h .. 8 h + 7 of row i (A) / column i (B); D as the fp32 32x32 MFMA.
 #pragma once

@@ -474,11 +474,13 @@ bool use_osm(const pv2_osm_plan_t* plan, const float* zero_row, int K, int64_t n
   if (K < 1 || K >= kMaxK || c_red < kKC || (c_red % kKC) != 0 || (c_cols % 4) != 0) return false;
   if (n_rows < 1 || n_rows > plan->n_pad || (n_rows + 63) / 64 > PV2_BN_MAX_PARTIAL_BLOCKS) return false;
   if (mode == 1) return true;
-  // auto, from the A/B on the bench geometry (profiles/r05_spconv_ab.txt): the strided / inverse convs
-  // whose walked rows are the FINE side (every row has exactly one offset: the mask order makes every tile
-  // a dense single-offset GEMM - grad-input of a strided conv, forward of an inverse conv) and the narrow
-  // strided forward passes; the 27-offset submanifold convs stay on the product-row route (their
-  // workgroups walk 10 - 17 offsets x c_in / 32 slabs serially: 1.2 - 4x slower, section 3.2c of DESIGN.md).
+  // auto, from the A/B on the bench geometry (profiles/r05_spconv_ab.txt).  Per launch this route wins
+  // for the strided / inverse convs whose walked rows are the FINE side (every row has exactly one
+  // offset: the mask order makes every tile a dense single-offset GEMM - grad-input of a strided conv,
+  // forward of an inverse conv) and for the narrow strided forward passes; the 27-offset submanifold convs
+  // lose (their workgroups walk 10 - 17 offsets x c_in / 32 slabs serially: 1.0 - 4x slower, DESIGN.md
+  // section 3.2c).  The host side builds plans only when asked to (PV2_CONV_OSM=1): the eight plans of
+  // the strided levels cost more on the geometry stream than the 62 us per step those launches save.
   if (K > 8) return false;
   return n_rows >= n_other || c_red <= 64;
 }

@@ -64,10 +64,13 @@ def _use_os(rb) -> bool:
 # direction, sums kept in the MFMA accumulators - no product rows, no row reduce.  The plans (row order,
 # permuted gather table, tile masks) are built with the rulebooks; the C side decides per shape
 # (pv2::use_osm) unless PV2_CONV_OSM forces it:
-#   "auto" (default)  plans for the 8-offset strided / inverse rulebooks, used where measured faster
-#                     (profiles/r05_spconv_ab.txt: the 27-offset submanifold convs lose on this route);
 #   "1"               plans for every rulebook with at most 31 offsets, every planned conv takes the route;
-#   "0"               no plans: the product-row route everywhere.
+#   "0" / "auto" (default)  no plans: the product-row route everywhere.  Measured on MI355X
+#                     (profiles/r05_spconv_ab.txt): the 27-offset submanifold convs are 1.0 - 4x SLOWER on
+#                     this route; the 8-offset strided / inverse convs are up to 1.7x faster per launch
+#                     (62 us per step in total), but building their eight plans on the geometry stream
+#                     costs more than that - 19.44 ms per step with them against 19.30 without (same box,
+#                     two alternating runs each).  The route stays available and tested; it is not the default.
 OSM_MODE = os.environ.get("PV2_CONV_OSM", "auto")
 if OSM_MODE not in ("0", "1"):
     OSM_MODE = "auto"
@@ -77,7 +80,7 @@ OSM_MAX_K = 31
 def _want_osm(K: int) -> bool:
     if OSM_MODE == "0" or USE_PR is False or K > OSM_MAX_K or K < 2:
         return False
-    return OSM_MODE == "1" or K == 8
+    return OSM_MODE == "1"
 
 
 _ZERO_ROWS = {}

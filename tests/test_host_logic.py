@@ -735,3 +735,47 @@ def test_cells_geometry_ahead_of_time_equals_inline():
     assert rb is geo["rulebook"]
     assert torch.equal(ra.pair_in[:ra.n_pairs], rb.pair_in[:rb.n_pairs])
     assert torch.equal(ra.pair_out[:ra.n_pairs], rb.pair_out[:rb.n_pairs])
+
+
+def test_spconv_shaped_state_dict_loads():
+    """A checkpoint as the reference would save it with spconv 2.x loads into the product model, strictly.
+
+    No spconv wheel and no released checkpoint exist offline, so the two things a real checkpoint would
+    pin - the weight layout ``[C_out, kD, kH, kW, C_in]`` of SubMConv3d / SparseConv3d / SparseInverseConv3d
+    (spconv 2.x, KRSC; ponder/models/sparse_unet/spconv_unet_v1m1_base.py:41-66,111-181 builds them with
+    bias=False) and their default initialisation - stay UNPINNED against spconv itself (DESIGN.md section 4,
+    INTEGRATION.md).  What this test fixes is the contract the product states: a ``state_dict`` built
+    INDEPENDENTLY of the product's parameters - key names from the reference's module tree, shapes from the
+    documented layout and the config's channel counts - loads with ``strict=True``, and a conv reads it as
+    ``[C_out, K, C_in]`` without a transpose."""
+    import golden_cases as gc
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+    from ponderv2_amd.spconv import pytorch as spconv
+
+    cfg = dict(gc.FULL_BACKBONE)
+    model = build_model(ConfigDict(cfg))
+    gen = torch.Generator().manual_seed(0)
+    synthetic, convs = {}, 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, (spconv.SubMConv3d, spconv.SparseConv3d, spconv.SparseInverseConv3d)):
+            ks = mod.kernel_size if isinstance(mod.kernel_size, (tuple, list)) else (mod.kernel_size,) * 3
+            shape = (mod.out_channels, *ks, mod.in_channels)        # spconv 2.x KRSC
+            synthetic[name + ".weight"] = torch.randn(shape, generator=gen)
+            assert mod.bias is None
+            convs += 1
+        elif isinstance(mod, torch.nn.BatchNorm1d):
+            c = mod.num_features
+            synthetic.update({name + ".weight": torch.rand(c, generator=gen), name + ".bias": torch.randn(c, generator=gen),
+                              name + ".running_mean": torch.randn(c, generator=gen),
+                              name + ".running_var": torch.rand(c, generator=gen) + 0.5,
+                              name + ".num_batches_tracked": torch.tensor(7)})
+    assert convs == 59          # BASELINE.md 2.2: 59 sparse-conv layers
+    assert sum(v.numel() for k, v in synthetic.items() if k.endswith(".weight") and v.dim() == 5) > 38e6
+    missing, unexpected = model.load_state_dict(synthetic, strict=True)
+    assert not missing and not unexpected
+    # the first residual block's conv as the kernels see it: [C_out, K, C_in], contiguous, no copy
+    conv = model.enc[0][0].conv1
+    w = conv.weight.reshape(conv.out_channels, -1, conv.in_channels)
+    assert w.data_ptr() == conv.weight.data_ptr() and w.shape[1] == 27
+    assert torch.equal(w[:, 13, :], synthetic["enc.0.block0.conv1.weight"][:, 1, 1, 1, :])

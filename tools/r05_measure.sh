@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round 5 measurement trip: full GPU suite, smoke(), default bench (live kernel timing + CPU baseline with its
+# thread sweep), rocprofv3 kernel stats (two streams / one), kernel table, breakdown, launch map, PMC passes
+# (one counter group per pass, --pmc with --kernel-trace only).  Outputs: gpurun_out/r05/
+set -u
+O=gpurun_out/r05; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --timeout 400 -s > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest_gpu.txt | tail -8 | cut -c1-300
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python bench.py --kernel-table $O/kernel_table.txt > $O/bench_f32.json 2> $O/bench_f32.err; echo "bench rc=$?"; cut -c1-420 $O/bench_f32.json; echo
+bash tools/gpu_prof.sh r05 --steps 10 --warmup 3 > /dev/null 2>&1; cp gpurun_out/prof_r05_kernel_stats.csv $O/kernel_stats_f32.csv
+PV2_WGRAD_STREAM=0 bash tools/gpu_prof.sh r05s --steps 10 --warmup 3 > /dev/null 2>&1; cp gpurun_out/prof_r05s_kernel_stats.csv $O/kernel_stats_f32_single_stream.csv
+python tools/kernel_breakdown.py $O/kernel_stats_f32_single_stream.csv 13 > $O/kernel_breakdown.txt 2>&1
+python tools/kernel_breakdown.py $O/kernel_stats_f32.csv 13 >> $O/kernel_breakdown.txt 2>&1
+head -16 $O/kernel_breakdown.txt
+timeout 300 python tools/launch_map.py > $O/launch_map.txt 2>&1; grep -n "total launches" $O/launch_map.txt
+bash tools/gpu_pmc.sh r05_fetch "FETCH_SIZE" --steps 6 --warmup 2 > /dev/null 2>&1
+bash tools/gpu_pmc.sh r05_write "WRITE_SIZE" --steps 6 --warmup 2 > /dev/null 2>&1
+PV2_WGRAD_STREAM=0 bash tools/gpu_pmc.sh r05_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 6 --warmup 2 > /dev/null 2>&1
+python tools/pmc_to_json.py gpurun_out/pmc_r05_fetch_by_kernel.csv gpurun_out/pmc_r05_write_by_kernel.csv ${PV2_COMMIT:-r05} $O/pmc_fetch_write_per_kernel.json
+cp gpurun_out/pmc_r05_*_by_kernel.csv $O/ 2>/dev/null
+head -6 gpurun_out/pmc_r05_mfma_by_kernel.csv | cut -c1-220
+# the bench line again with the fresh PMC file in place (roofline.traffic)
+cp $O/pmc_fetch_write_per_kernel.json profiles/r05_pmc_fetch_write_per_kernel.json
+timeout 300 python bench.py --no-cpu-baseline > $O/bench_f32_with_traffic.json 2>/dev/null; python - <<PY
+import json
+d=json.load(open("$O/bench_f32_with_traffic.json")); print(d["ms_per_step"], d["roofline"])
+PY
