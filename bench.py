@@ -748,15 +748,23 @@ def cpu_baseline(args):
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    def timed(fn, warm, n):
+    def timed(fn, warm, n, budget_s):
+        """median of up to ``n`` timed calls after ``warm`` warm-ups, cut short (never below one timed call)
+        when the section has used ``budget_s`` - the default bench run must stay within minutes whatever
+        the host is"""
+        start = time.perf_counter()
         for _ in range(warm):
             fn()
+            if time.perf_counter() - start > budget_s / 2:
+                break
         out = []
         for _ in range(n):
             t0 = time.perf_counter()
             fn()
             out.append(time.perf_counter() - t0)
-        return statistics.median(out)
+            if time.perf_counter() - start > budget_s:
+                break
+        return statistics.median(out), len(out)
 
     ncpu = os.cpu_count() or 1
     threads_before = torch.get_num_threads()
@@ -775,10 +783,12 @@ def cpu_baseline(args):
             sweep = {}
             for nt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
                 torch.set_num_threads(nt)
-                sweep[nt] = timed(backbone_fwd, 1, 2)
+                sweep[nt] = timed(backbone_fwd, 1, 1, 12.0)[0]
+                if sweep[nt] > 1.5 * min(sweep.values()):
+                    break      # past the knee: more threads only oversubscribe the per-offset GEMMs
             best = min(sweep, key=sweep.get)
             torch.set_num_threads(best)
-            t_backbone = timed(backbone_fwd, 2, 5)
+            t_backbone, n_backbone = timed(backbone_fwd, 2, 5, 20.0)
             fwd_times = []
 
             def step():
@@ -789,26 +799,26 @@ def cpu_baseline(args):
                 out["loss"].backward()
                 opt.step()
 
-            t_step = timed(step, 2, 5)
-            t_fwd = statistics.median(fwd_times[2:])
+            t_step, n_step = timed(step, 2, 5, 45.0)
+            t_fwd = statistics.median(fwd_times[-n_step:])
             # the benched batch (configs[1]: 2 scenes, 46 842 voxels) through the same backbone
             bench_batch = collate_fn([make_scene(1000 * 0 + i, num_views=2, image_hw=(480, 640))
                                       for i in range(2)])
             n_bench = int(bench_batch["offset"][-1])
-            t_backbone_bench = timed(lambda: backbone_fwd(bench_batch), 2, 5)
+            t_backbone_bench, n_bench_it = timed(lambda: backbone_fwd(bench_batch), 2, 5, 30.0)
         coords = torch.cat([torch.zeros(len(batch["grid_coord"]), 1, dtype=torch.long),
                             batch["grid_coord"]], 1).int().numpy()
-        t_rb = timed(lambda: orb.subm_rulebook(coords, 3), 0, 3)
+        t_rb = timed(lambda: orb.subm_rulebook(coords, 3), 0, 3, 5.0)[0]
     finally:
         torch.set_num_threads(threads_before)
     return dict(value=1.0 / t_step, unit="scenes/s", cores=best, kind="port",
                 sample="configs[0]: 1 scene (20000 voxels, 2 views x 64 = 128 rays), train step "
                        "fwd+bwd+SGD, fp32, product model code on oracle CPU kernels; thread sweep "
                        f"{ {k: round(v, 2) for k, v in sweep.items()} } s per SparseUNet forward -> {best} "
-                       f"threads of {ncpu}; 2 warm-up + median of 5 (SparseUNet forward alone "
-                       f"{t_backbone:.2f} s, on the benched {n_bench}-voxel batch {t_backbone_bench:.2f} s; "
-                       f"model forward {t_fwd:.2f} s, step {t_step:.2f} s, level-0 k3 rulebook build "
-                       f"{t_rb:.2f} s)",
+                       f"threads of {ncpu}; 2 warm-up + median of up to 5 within a time budget (SparseUNet "
+                       f"forward alone {t_backbone:.2f} s [{n_backbone} timed], on the benched {n_bench}-voxel "
+                       f"batch {t_backbone_bench:.2f} s [{n_bench_it}]; model forward {t_fwd:.2f} s, step "
+                       f"{t_step:.2f} s [{n_step}], level-0 k3 rulebook build {t_rb:.2f} s)",
                 rays_per_s=128.0 / t_step, sparse_unet_forward_s=t_backbone,
                 sparse_unet_forward_bench_s=t_backbone_bench, bench_batch_voxels=n_bench,
                 thread_sweep_s={str(k): v for k, v in sweep.items()}, host_cores=ncpu,
