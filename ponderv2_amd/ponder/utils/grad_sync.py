@@ -58,6 +58,12 @@ class FlatGradSync:
         self._inflight = None         # this step's (arena, [(work, view)])
         self._stage = None
         self._comm = {}
+        # the in-place route is ARMED by the first sync(): until every rank has confirmed that its
+        # backward reported the same arena layout, the hook issues no collective of its own (a rank
+        # whose first backward ran module by module would otherwise pair its first flat slice with the
+        # others' first slab)
+        self._armed = False
+        self._pending_first = None    # (arena, slabs) of the step that arms
         self.group = process_group
         self.numel = sum(p.numel() for p in self.params)
         self.slice_elems = max(int(slice_mb * 2 ** 20 // 4), 1)
@@ -172,6 +178,11 @@ class FlatGradSync:
         becomes the ``.grad`` of one of this object's parameters (leaves; no accumulation pending)."""
         if not (self.overlap and dist.is_available() and dist.is_initialized()):
             return False
+        if self._inflight is not None or self._pending_first is not None:
+            # a second backward before sync(): gradient accumulation would add into an arena that is
+            # being reduced in place - not supported by the overlapped route
+            raise RuntimeError("FlatGradSync(overlap=True): call sync() after every backward() "
+                               "(gradient accumulation needs overlap=False)")
         return all(id(t) in self._index_of and t.is_leaf and t.grad is None for t in tensors)
 
     def _reduce_slabs(self, arena, slabs, events=None):
@@ -217,8 +228,42 @@ class FlatGradSync:
         elif layout != self._arena_layout:
             raise RuntimeError("FlatGradSync(overlap=True): the executor's gradient arena changed its "
                                "layout between steps; use overlap=False for this model")
+        if not self._armed:           # first step: no collective before the ranks have agreed (sync())
+            self._pending_first = (arena, tuple(slabs))
+            return
         works, avg = self._reduce_slabs(arena, slabs, events)
         self._inflight = (arena, works, avg)
+
+    def _arm(self, world):
+        """First sync(): do ALL ranks hold the same arena layout?  Then the in-place route is on from now on
+        (and this step's slabs are reduced here, in place); otherwise it is off everywhere and the arena's
+        parameters travel through the flat buffer like any others."""
+        have = self._arena_layout is not None
+        agreed = have
+        if world > 1:
+            sig = 0
+            if have:
+                numel, slabs, members = self._arena_layout
+                sig = numel % 2147483629
+                for lo, hi in slabs:
+                    sig = (sig * 1000003 + lo * 31 + hi) % 2147483629
+                for i, off, n in members:
+                    sig = (sig * 1000003 + i * 131 + off * 7 + n) % 2147483629
+                sig += 1
+            ref = self.params[0]
+            t = torch.tensor([float(sig), -float(sig)], dtype=torch.float64, device=ref.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            hi, lo = t.tolist()
+            agreed = have and hi == -lo and hi > 0
+        if agreed:
+            self._armed = True
+            arena, slabs = self._pending_first
+            works, avg = self._reduce_slabs(arena, list(slabs))
+            self._inflight = (arena, works, avg)
+        else:
+            self.overlap = False
+            self._arena_layout, self._covered = None, frozenset()
+        self._pending_first = None
 
     def _finish_inplace(self, world):
         """Wait for the slab reductions of this step - issuing them from a staging buffer first when the
@@ -281,11 +326,10 @@ class FlatGradSync:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(self.group)
-        if self.overlap and self._arena_layout is None and self._inflight is None and self._flat is None:
-            raise RuntimeError("FlatGradSync(overlap=True): the first step's backward did not report the "
-                               "sparse executor's arena (attach() missing, or the model ran module by "
-                               "module); use overlap=False")
-        self._finish_inplace(world)   # (same position in every rank's sequence of collectives)
+        if self.overlap and not self._armed:
+            self._arm(world)          # (one small collective, once; may switch the in-place route off)
+        if self.overlap:
+            self._finish_inplace(world)   # (same position in every rank's sequence of collectives)
         flat, views = self._buffers()
         used = [i for i, p in enumerate(self.params) if p.grad is not None and i not in self._covered]
         if not self.uniform_usage:

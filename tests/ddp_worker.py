@@ -192,7 +192,9 @@ def overlap_sync_worker(rank, world, port, out_dir):
         grads = local(step)
         for p, gr in zip(pb, grads):
             p.grad = gr.clone()
-        assert over.wants([pa[i] for i in owned]) or step > 0
+        for p in pa:
+            p.grad = None
+        assert over.wants([pa[i] for i in owned])      # (what the executor asks before it lays out slabs)
         if fired:
             arena = torch.full((arena_numel,), float("nan"))
             for i in owned:
@@ -214,6 +216,34 @@ def overlap_sync_worker(rank, world, port, out_dir):
             dist.all_reduce(t)
             want.append(t / world)
         ok = ok and all(torch.allclose(a.grad, w, atol=1e-6) for a, w in zip(pa, want))
+    armed = over._armed and len(over._covered) == len(owned)
+    # a reducer whose FIRST backward reported an arena on rank 0 only: the in-place route must switch itself
+    # off on both ranks (no collective was issued from the hook), and everything still averages correctly
+    model_d = make()
+    pd = list(model_d.parameters())
+    lone = FlatGradSync(pd, slice_mb=0.02, overlap=True, slab_mb=0.1)
+    for step in range(2):
+        grads = local(50 + step)
+        for p in pd:
+            p.grad = None
+        if lone.wants([pd[i] for i in owned]) and rank == 0 and step == 0:
+            arena = torch.full((arena_numel,), float("nan"))
+            for i in owned:
+                arena[offs[i]:offs[i] + pd[i].numel()].copy_(grads[i].reshape(-1))
+            lone._on_arena(arena, [(pd[i], offs[i], pd[i].numel()) for i in owned], spans, None)
+            for i in owned:
+                pd[i].grad = arena[offs[i]:offs[i] + pd[i].numel()].view_as(pd[i])
+        else:
+            for i in owned:
+                pd[i].grad = grads[i].clone()
+        for i in set(range(len(pd))) - set(owned):
+            pd[i].grad = grads[i].clone()
+        lone.sync()
+        for gr, p in zip(grads, pd):
+            t = gr.clone()
+            dist.all_reduce(t)
+            ok = ok and torch.allclose(p.grad, t / world, atol=1e-6)
+    ok = ok and (not lone.overlap) and (not lone._armed) and len(lone._covered) == 0 and armed
     # rank 1 has NO arena family on the first synchronised step, rank 0 has one
     model_c = make()
     pc = list(model_c.parameters())
