@@ -543,7 +543,12 @@ class PendingGeometry:
         return self._result
 
 
+_SKIP_RECORD = os.environ.get("PV2_DEBUG_NO_RECORD_STREAM") == "1"   # timing experiments only: UNSAFE
+
+
 def _record_stream(obj, stream, _seen=None):
+    if _SKIP_RECORD:
+        return
     seen = set() if _seen is None else _seen
     if id(obj) in seen:
         return
