@@ -200,16 +200,28 @@ def test_model_folds_the_final_convolution_by_default_and_unfolded_results_agree
 
     ref_l, ref_g = step(False)
     again_l, again_g = step(False)
+    third_l, third_g = step(False)
     assert not seen
     new_l, new_g = step(True)
     assert len(seen) == 1
     for k, v in ref_l.items():
         assert abs(new_l[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, v, new_l[k])
     assert ref_g.keys() == new_g.keys()
-    bad = {}
+    # The step's own run-to-run noise (float atomics of the scatter-mean and of the sampler's volume
+    # gradient, amplified wherever they flip a ReLU) is sampled TWICE; one sample made this test fail once
+    # in ~10 runs of the whole suite in round 5 (a tensor whose single noise sample happened to be small).
+    # All tensors together are held tightly, a single tensor loosely.
+    bad, num, den, num_floor = {}, 0.0, 0.0, 0.0
     for name, g0 in ref_g.items():
         ref = g0.cpu().numpy()
-        floor, err = gc.rel_err(again_g[name], ref), gc.rel_err(new_g[name], ref)
-        if not err <= max(5e-3, 6.0 * floor):   # above the step's own noise (one sample: ``floor``)
+        floor = max(gc.rel_err(again_g[name], ref), gc.rel_err(third_g[name], ref))
+        err = gc.rel_err(new_g[name], ref)
+        if not err <= max(2e-2, 10.0 * floor):
             bad[name] = (err, floor)
+        d = g0.double()
+        num += float((new_g[name].double() - d).pow(2).sum())
+        num_floor += max(float((again_g[name].double() - d).pow(2).sum()),
+                         float((third_g[name].double() - d).pow(2).sum()))
+        den += float(d.pow(2).sum())
     assert not bad, bad
+    assert (num / den) ** 0.5 <= max(5e-3, 6.0 * (num_floor / den) ** 0.5), (num, num_floor, den)

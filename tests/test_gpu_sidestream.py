@@ -59,8 +59,9 @@ def test_side_stream_does_not_change_the_step(device, monkeypatch):
         ref = g0.cpu().numpy()
         floor = max(gc.rel_err(f[name], ref) for f in floors)
         err = gc.rel_err(new_g[name], ref)
-        # (a gradient read while still in flight on the side stream is off by factors)
-        if not err <= max(1e-4, 4.0 * floor):
+        # (a gradient read while still in flight on the side stream is off by FACTORS; the bound only has
+        # to stay clear of the step's noise - three samples of a heavy-tailed quantity - so it is generous)
+        if not err <= max(1e-3, 10.0 * floor):
             bad[name] = (err, floor)
     assert not bad, bad
 
