@@ -779,3 +779,44 @@ def test_spconv_shaped_state_dict_loads():
     w = conv.weight.reshape(conv.out_channels, -1, conv.in_channels)
     assert w.data_ptr() == conv.weight.data_ptr() and w.shape[1] == 27
     assert torch.equal(w[:, 13, :], synthetic["enc.0.block0.conv1.weight"][:, 1, 1, 1, :])
+
+
+def test_record_stream_reaches_every_tensor_of_every_rulebook():
+    """``kernels._record_stream`` (what makes the prefetched geometry safe to use on the training stream)
+    must visit EVERY tensor of EVERY rulebook in the result.  Round 5 found that it walked a rulebook's
+    fields through a temporary list whose ``id()`` went into the seen-set: the next rulebook's temporary could
+    be handed the same address and the whole rulebook was skipped - its tensors stayed unrecorded and the
+    caching allocator re-used them under the training stream's kernels (a memory fault of bench.py)."""
+    from ponderv2_amd import kernels as K
+
+    recorded = []
+
+    class FakeDeviceTensor(torch.Tensor):
+        is_cuda = property(lambda self: True)
+
+        def record_stream(self, stream):
+            recorded.append(id(self))
+
+    def t():
+        return torch.zeros(3).as_subclass(FakeDeviceTensor)
+
+    everything = []
+
+    def plan():
+        p = K.OsmPlanData.__new__(K.OsmPlanData)
+        p.perm, p.tblp, p.tmask, p.n_pad, p.kflip, p.struct = t(), t(), t(), 256, 0, None
+        everything.extend([p.perm, p.tblp, p.tmask])
+        return p
+
+    result = {}
+    for i in range(12):
+        pin, pout, ks = t(), t(), t()
+        rb = K.Rulebook(8, 1, 1, pin, pout, ks, np.zeros(9, np.int64), _tiles_dev=t())
+        rb.nbr = t()
+        rb._pos = (t(), 1, t(), 1)
+        rb.osm, rb.osm_t = plan(), plan()
+        everything.extend([pin, pout, ks, rb.nbr, rb._tiles_dev, rb._pos[0], rb._pos[2]])
+        result[f"spconv{i}"] = dict(kind="down", rulebook=rb, in_indices=t(), out_indices=t())
+        everything.extend([result[f"spconv{i}"]["in_indices"], result[f"spconv{i}"]["out_indices"]])
+    K._record_stream(result, stream=object())
+    assert sorted(recorded) == sorted(id(x) for x in everything)
