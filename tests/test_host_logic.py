@@ -820,3 +820,54 @@ def test_record_stream_reaches_every_tensor_of_every_rulebook():
         everything.extend([result[f"spconv{i}"]["in_indices"], result[f"spconv{i}"]["out_indices"]])
     K._record_stream(result, stream=object())
     assert sorted(recorded) == sorted(id(x) for x in everything)
+
+
+def test_gradient_slabs_partition_the_executor_arena_in_completion_order():
+    """``spunet_native._gradient_slabs`` (round 5: what the overlapped gradient reduction is told): the
+    parameter-gradient arena is laid out first unit to last, the backward finishes units last to first - so
+    the slabs must tile [first conv unit's offset, arena end) from the END, each at least ``slab_elems`` long
+    (the last one takes what is left), each named by the LOWEST unit it contains, the stem outside."""
+    from ponderv2_amd import spunet_native as sn
+    from ponderv2_amd._lib import UNET_CONCAT, UNET_CONV_BN, UNET_STEM
+
+    class Hook:
+        slab_elems = 5000
+
+        def __init__(self):
+            self.asked = None
+
+        def wants(self, tensors):
+            self.asked = list(tensors)
+            return True
+
+    plan, tensors, arena = sn.Plan(), [], sn._Arena()
+    kinds = [UNET_STEM] + [UNET_CONV_BN, UNET_CONV_BN, UNET_CONCAT] * 4 + [UNET_CONV_BN]
+    for i, kind in enumerate(kinds):
+        u = sn._Unit()
+        u.kind = kind
+        if kind != UNET_CONCAT:
+            c_out, k, c_in = 8 + 4 * (i % 3), 27 if kind != UNET_STEM else 125, 8
+            w = torch.nn.Parameter(torch.zeros(c_out, k, c_in))
+            bw, bb = torch.nn.Parameter(torch.zeros(c_out)), torch.nn.Parameter(torch.zeros(c_out))
+            u.c_out, u.w_index = c_out, len(tensors)
+            tensors += [w, bw, bb]
+            u.gsum_off = arena.reserve(2 * c_out)
+            u.dw_off = arena.reserve(w.numel())
+        plan.units.append(u)
+    hook = Hook()
+    members, spans, units = sn._gradient_slabs(plan, tensors, hook, arena)
+    convs = [(i, u) for i, u in enumerate(plan.units) if u.kind == UNET_CONV_BN]
+    assert len(hook.asked) == 3 * len(convs)                      # the stem's tensors are not offered
+    assert spans[0][1] == arena.size and spans[-1][0] == convs[0][1].gsum_off
+    assert all(spans[j + 1][1] == spans[j][0] for j in range(len(spans) - 1))     # contiguous, descending
+    assert all(hi - lo >= hook.slab_elems for lo, hi in spans[:-1]) and len(spans) >= 3
+    assert units == sorted(units, reverse=True) and units[-1] == convs[0][0]
+    for (lo, hi), i in zip(spans, units):
+        assert plan.units[i].gsum_off == lo                       # named by its lowest unit
+    assert len(members) == 3 * len(convs)
+    for t, off, n in members:
+        assert t.numel() == n and spans[-1][0] <= off and off + n <= arena.size
+        assert sum(lo <= off and off + n <= hi for lo, hi in spans) == 1          # inside exactly one slab
+    # too few conv units, or a reducer that declines: no slabs
+    assert sn._gradient_slabs(plan, tensors, type("No", (), {"slab_elems": 1, "wants": lambda s, t: False})(),
+                              arena) is None
