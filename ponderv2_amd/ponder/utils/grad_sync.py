@@ -44,6 +44,19 @@ import torch
 import torch.distributed as dist
 
 
+def _dense_strides(g):
+    """The strides of ``g`` when its elements occupy exactly ``numel`` consecutive storage elements in
+    SOME dimension order (contiguous, channels-last, ...), else None."""
+    if g.is_contiguous():
+        return tuple(g.stride())
+    expect = 1
+    for st, sz in sorted((st, sz) for sz, st in zip(g.shape, g.stride()) if sz > 1):
+        if st != expect:
+            return None
+        expect *= sz
+    return tuple(g.stride())
+
+
 class FlatGradSync:
     def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
                  use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0):
@@ -72,21 +85,30 @@ class FlatGradSync:
         self._blocks = []
         self.use_blocks = use_blocks
         self._flag_key, self._flags = None, None
+        self._member_strides = {}     # parameter index -> strides of its gradient inside an arena block
         self.uniform_usage = uniform_usage
         # uniform usage is an ASSUMPTION about the model; it is checked, not trusted (see sync)
         self._last_used, self._steps, self.check_every = None, 0, 64
 
     def _arena_families(self, min_bytes=1 << 20):
-        """Families of used parameters whose gradients are contiguous views of ONE storage: [(storage
-        ptr, span start (elements from the storage base), span length, [(param index, offset in the
-        span)])], largest first."""
-        by_storage = {}
+        """Families of used parameters whose gradients are DENSE views of ONE storage (contiguous, or
+        any other dimension order that fills ``numel`` consecutive elements - the dense U-Net keeps its
+        weight gradients channels-last): [(storage ptr, span start (elements from the storage base), span
+        length, [(param index, offset in the span)])], largest first.  The strides go to
+        ``_member_strides``: the flat buffer's view of such a member has the same ones, so that ONE copy
+        of the span moves every member."""
+        by_storage, strides = {}, {}
         for i, p in enumerate(self.params):
             g = p.grad
-            if g is None or not g.is_contiguous() or g.dtype != torch.float32 or i in self._covered:
+            if g is None or g.dtype != torch.float32 or i in self._covered:
                 continue
+            sd = _dense_strides(g)
+            if sd is None:
+                continue
+            strides[i] = sd
             st = g.untyped_storage()
             by_storage.setdefault(st.data_ptr(), []).append((i, (g.data_ptr() - st.data_ptr()) // 4, g.numel()))
+        self._candidate_strides = strides
         fams = []
         for ptr, members in by_storage.items():
             if len(members) < 8:
@@ -130,6 +152,8 @@ class FlatGradSync:
                     sig = (sig * 1000003 + (k + 1) * 7919 + span) % 2147483629
                     for i, o in m:
                         sig = (sig * 1000003 + i * 31 + o) % 2147483629
+                        for sd in self._candidate_strides[i]:
+                            sig = (sig * 1000003 + sd) % 2147483629
                 t = torch.tensor([float(sig), -float(sig)], dtype=torch.float64, device=ref.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 hi, lo = t.tolist()
@@ -153,8 +177,17 @@ class FlatGradSync:
             self.numel = off
             self._blocks = blocks
             self._flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=ref.device)
-            self._views = [None if o is None else self._flat[o:o + p.numel()].view_as(p)
-                           for o, p in zip(offsets, self.params)]
+            self._member_strides = {i: self._candidate_strides[i] for i in in_block}
+            self._views = []
+            for i, (o, p) in enumerate(zip(offsets, self.params)):
+                if o is None:
+                    self._views.append(None)
+                    continue
+                piece = self._flat[o:o + p.numel()]
+                sd = self._member_strides.get(i)
+                # (a block member's view mirrors its gradient's strides: the block copy is a byte copy)
+                self._views.append(piece.view_as(p) if sd is None or sd == tuple(p.stride())
+                                   else piece.as_strided(tuple(p.shape), sd))
         return self._flat, self._views
 
     # ------------------------------------------------------------------ overlap with the backward
@@ -304,14 +337,15 @@ class FlatGradSync:
             i0, o0 = members[0]
             g0 = self.params[i0].grad
             src = None
-            if g0 is not None and g0.is_contiguous():
+            if g0 is not None and tuple(g0.stride()) == self._member_strides.get(i0):
                 st = g0.untyped_storage()
                 start = (g0.data_ptr() - st.data_ptr()) // 4 - o0          # span start in the storage
                 ok = start >= 0 and (start + span) * 4 <= st.nbytes()
                 base = st.data_ptr() + 4 * start
                 for i, o in members:
                     g = self.params[i].grad
-                    if g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * o:
+                    if (g is None or tuple(g.stride()) != self._member_strides.get(i)
+                            or g.data_ptr() != base + 4 * o):
                         ok = False
                         break
                 if ok:

@@ -107,7 +107,10 @@ def arena_sync_worker(rank, world, port, out_dir):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     torch.manual_seed(0)
-    model = torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(30)], torch.nn.Linear(96, 3))
+    # (two 5-D conv weights in front: in the arena their gradients are CHANNELS-LAST views, as the dense
+    # U-Net node hands them back - dense, not contiguous; they must travel inside the block too)
+    model = torch.nn.Sequential(torch.nn.Conv3d(8, 16, 3), torch.nn.Conv3d(16, 8, 3),
+                                *[torch.nn.Linear(96, 96) for _ in range(28)], torch.nn.Linear(96, 3))
     params = list(model.parameters())
     sync = FlatGradSync(params, slice_mb=0.02)
 
@@ -119,7 +122,12 @@ def arena_sync_worker(rank, world, port, out_dir):
             arena = torch.full((sum(sizes),), float("nan"))
             off = 0
             for p, gr, n in zip(params[:-2], grads, sizes):
-                view = arena[off:off + p.numel()].view_as(p)
+                if p.dim() == 5:
+                    co, ci, k = p.shape[0], p.shape[1], p.shape[2]
+                    view = arena[off:off + p.numel()].view(co, k, k, k, ci).permute(0, 4, 1, 2, 3)
+                    assert not view.is_contiguous() and view.shape == p.shape
+                else:
+                    view = arena[off:off + p.numel()].view_as(p)
                 view.copy_(gr)
                 p.grad = view
                 off += n
