@@ -59,8 +59,12 @@ def _dense_strides(g):
 
 class FlatGradSync:
     def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
-                 use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0):
+                 use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0,
+                 alias_grads: bool = True):
         self.params = [p for p in params if p.requires_grad]
+        # after the reduction ``.grad`` of a parameter outside the arenas becomes the flat buffer's view
+        # instead of receiving a copy of it (False: copy back into the tensors autograd produced)
+        self.alias_grads = bool(alias_grads)
         # in-place reduction of the sparse executor's arena behind per-slab events (see the module
         # docstring); needs every rank to take the same code path: uniform usage only
         self.overlap = bool(overlap) and uniform_usage
@@ -177,6 +181,7 @@ class FlatGradSync:
             self.numel = off
             self._blocks = blocks
             self._flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=ref.device)
+            self._offsets = offsets
             self._member_strides = {i: self._candidate_strides[i] for i in in_block}
             self._views = []
             for i, (o, p) in enumerate(zip(offsets, self.params)):
@@ -394,7 +399,7 @@ class FlatGradSync:
                 moved.update(i for i, _ in members)
         rest = [i for i in used if i not in moved]
         if rest:
-            torch._foreach_copy_([views[i] for i in rest], [self.params[i].grad for i in rest])
+            self._gather(rest, flat, views)
         if not self.uniform_usage:
             key = tuple(used)
             if self._flag_key != key:  # the local set changes rarely: its device copy is cached
@@ -433,9 +438,45 @@ class FlatGradSync:
         for i, p in enumerate(self.params):
             if not anywhere[i] or i in moved:
                 continue
+            if self.alias_grads and p.grad is not None and views[i].stride() == p.grad.stride():
+                # the average stays where it is: ``.grad`` becomes the flat buffer's view (what
+                # DistributedDataParallel(gradient_as_bucket_view=True) does) - no copy back, no launch
+                p.grad = views[i]
+                continue
             if p.grad is None:
                 p.grad = torch.empty_like(p)
             targets.append(p.grad)
             origins.append(views[i])
         if targets:
             torch._foreach_copy_(targets, origins)
+
+    def _gather(self, rest, flat, views):
+        """The gradients of ``rest`` (ascending parameter indices) into their flat slots.  Adjacent slots
+        are filled by ONE ``torch.cat`` (a batched kernel: the per-tensor route is a hipMemcpyAsync each
+        on ROCm - 40 of them per step for the heads and norms of this model); gradients that already ARE
+        their flat views (``alias_grads`` + in-place accumulation) are left alone."""
+        runs, run = [], []
+        for i in rest:
+            g = self.params[i].grad
+            if g.data_ptr() == views[i].data_ptr() and g.stride() == views[i].stride():
+                if run:
+                    runs.append(run)
+                    run = []
+                continue
+            if run and (self._offsets[run[-1]] + self.params[run[-1]].numel() != self._offsets[i]
+                        or not g.is_contiguous()):
+                runs.append(run)
+                run = []
+            if g.is_contiguous() and views[i].is_contiguous():
+                run.append(i)
+            else:
+                views[i].copy_(g)
+        if run:
+            runs.append(run)
+        for run in runs:
+            if len(run) == 1:
+                views[run[0]].copy_(self.params[run[0]].grad)
+                continue
+            lo = self._offsets[run[0]]
+            hi = self._offsets[run[-1]] + self.params[run[-1]].numel()
+            torch.cat([self.params[i].grad.reshape(-1) for i in run], out=flat[lo:hi])
