@@ -27,6 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_cache", "db"))
 os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(ROOT, "miopen_cache", "cache"))
 
+if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1 or os.environ.get("PV2_BENCH_FORCE_DIST") == "1":
+    # six streams over ROCclr's four default hardware queues serialise once a process group is in the
+    # process: 22.5 - 23.2 ms per step against 19.9 with two queues (ponderv2_amd/__init__.py, profiles/
+    # r05_hw_queues.txt); read at HIP initialisation, hence up here
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

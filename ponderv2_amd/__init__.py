@@ -18,4 +18,21 @@ _ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 _os.environ.setdefault("MIOPEN_USER_DB_PATH", _os.path.join(_ROOT, "miopen_cache", "db"))
 _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(_ROOT, "miopen_cache", "cache"))
 
+
+
+def limit_hardware_queues_for_process_group():
+    """With an RCCL process group in the process the step runs on six HIP streams (training, input,
+    geometry, weight-gradient side stream, communication stream, RCCL's own) over ROCclr's default of FOUR
+    hardware queues - and the streams that share a queue serialise: measured with one rank on MI355X
+    (profiles/r05_hw_queues.txt) 22.5 - 23.2 ms per step at the default, 44 ms at 6 or 8 queues, 20.1 at 3,
+    **19.9 at 2** (without a process group: 19.3 at the default, 19.4 at 2).  ``GPU_MAX_HW_QUEUES`` is read
+    when the HIP runtime initialises, so this must run before the first device call; an explicit setting
+    in the environment wins."""
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+
+# ranks started by a launcher (torch.distributed.run, the driver's multi-GPU bench line) carry WORLD_SIZE
+if int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1 or _os.environ.get("PV2_BENCH_FORCE_DIST") == "1":
+    limit_hardware_queues_for_process_group()
+
 __version__ = "0.1.0"
