@@ -27,24 +27,17 @@ def _rel(a, b):
 
 
 def _check_plan(plan, tbl, K, n, stride):
-    """perm sorts the rows stably by their offset mask; tblp is the table in that order (padding -1);
-    tmask is the OR over 32 sorted rows."""
-    tbl = _np(tbl).reshape(K, stride)[:, :n]
-    mask = np.zeros(n, np.int64)
-    for k in range(K):
-        mask |= (tbl[k] >= 0).astype(np.int64) << k
-    perm = _np(plan.perm)[:n].astype(np.int64)
-    assert np.array_equal(np.sort(perm), np.arange(n))
-    assert np.array_equal(perm, np.argsort(mask, kind="stable"))
+    """The device plan equals oracle/osm_plan.py's restatement bit for bit: perm sorts the rows stably by
+    their offset mask, tblp is the table in that order (padding -1), tmask the OR over 32 sorted rows."""
+    from oracle.osm_plan import osm_plan
+
     n_pad = plan.n_pad
     assert n_pad % 256 == 0 and n_pad >= n
-    tblp = _np(plan.tblp).reshape(K, n_pad)
-    assert np.array_equal(tblp[:, :n], tbl[:, perm])
-    assert (tblp[:, n:] == -1).all()
-    sorted_mask = np.zeros(n_pad, np.int64)
-    sorted_mask[:n] = mask[perm]
-    want = np.bitwise_or.reduce(sorted_mask.reshape(-1, 32), axis=1)
-    assert np.array_equal(_np(plan.tmask).astype(np.int64) & 0xffffffff, want)
+    perm, tblp, tmask = osm_plan(_np(tbl).reshape(K, stride), n, n_pad)
+    assert np.array_equal(np.sort(_np(plan.perm)[:n]), np.arange(n))
+    assert np.array_equal(_np(plan.perm)[:n], perm)
+    assert np.array_equal(_np(plan.tblp).reshape(K, n_pad), tblp)
+    assert np.array_equal(_np(plan.tmask).view(np.uint32), tmask)
 
 
 @pytest.mark.parametrize("seed,batch,n", [(0, 2, 1500), (1, 1, 4000), (2, 3, 3)])

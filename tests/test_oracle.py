@@ -219,3 +219,32 @@ def test_compositing_closed_form_gradients():
     assert torch.allclose(gw, gw_cf) and torch.allclose(gx, gx_cf)
     assert torch.allclose(ga, orm.grad_alpha_closed_form(alphas.detach(), gw), rtol=1e-9, atol=1e-12)
     assert t.shape == (7, 133, 1) and torch.allclose(t[:, -1], (1 - alphas + 1e-7).prod(1))
+
+
+def test_osm_plan_restatement_properties():
+    """oracle/osm_plan.py (what the device plan of the output-stationary conv is compared with): on a
+    submanifold neighbour table the order is a stable sort by offset mask, the permuted table is the table,
+    the tile masks cover exactly the offsets present - and grouping by mask cuts the tile waste."""
+    from helpers import random_voxels
+    from oracle import rulebook as orb
+    from oracle.osm_plan import osm_plan, tile_waste
+
+    coords = random_voxels(3, batch=2, n_per_batch=1200)
+    n = len(coords)
+    pin, pout, ks = orb.subm_rulebook(coords, 3)
+    tbl = -np.ones((27, n), np.int32)
+    for k in range(27):
+        tbl[k, pout[ks[k]:ks[k + 1]]] = pin[ks[k]:ks[k + 1]]
+    n_pad = (n + 255) // 256 * 256
+    perm, tblp, tmask = osm_plan(tbl, n, n_pad)
+    assert sorted(perm.tolist()) == list(range(n))
+    masks = ((tbl >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    assert (np.diff(masks[perm]) >= 0).all()
+    same = np.diff(masks[perm]) == 0
+    assert (np.diff(perm)[same] > 0).all()                       # stable: equal masks keep row order
+    assert np.array_equal(tblp[:, :n], tbl[:, perm]) and (tblp[:, n:] == -1).all()
+    present = (tblp.reshape(27, -1, 32) >= 0).any(2)             # [K, tiles]
+    want = (present.astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    assert np.array_equal(tmask.astype(np.int64), want)
+    assert tbl[13].tolist() == list(range(n))                    # the centre offset: every row feeds itself
+    assert tile_waste(tbl, n, perm) < tile_waste(tbl, n, np.arange(n))
