@@ -12,9 +12,14 @@ what the point-to-point xGMI links like -, and the averages are copied back.  Pa
 everywhere keep ``grad is None``, as under DDP (so weight decay does not touch them).
 ``uniform_usage=True`` (single-dataset models: every rank runs the same code path, so the set of
 parameters with gradients is the same everywhere) needs nothing else.  ``uniform_usage=False`` (the
-multi-dataset model trains a different condition's norms per rank and step) reduces a usage flag
-per parameter along with the data and reads the flags back - one small device read per step, the
-counterpart of DDP's ``find_unused_parameters`` bitmap exchange.
+multi-dataset model trains a different condition's norms per rank and step) exchanges a usage flag
+per parameter - the counterpart of DDP's ``find_unused_parameters`` bitmap exchange.  Which parameters
+received a gradient is known to the HOST as soon as backward has been enqueued, so the flags travel
+host to host (a gloo all-reduce of one small CPU tensor: the group itself in the CPU tests, a gloo
+twin of the default group beside RCCL) and the device never has to be waited for; reading reduced
+flags back from the device - the round-4 form, still the fallback for sub-groups and for
+PV2_GSYNC_HOST_FLAGS=0 - blocks the host until backward and the reduction have finished, which made
+the multi-dataset step host-bound (34.9 ms against 21.5, profiles/r05_workloads.txt).
 
 Arena blocks.  The sparse backbone's native executor hands ALL its parameter gradients back as views
 of one flat buffer (ponderv2_amd/spunet_native.py: 177 tensors, 150 of the step's 160 MB).  When the
@@ -60,7 +65,7 @@ def _dense_strides(g):
 class FlatGradSync:
     def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
                  use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0,
-                 alias_grads: bool = True):
+                 alias_grads: bool = True, host_flags: bool = True):
         self.params = [p for p in params if p.requires_grad]
         # after the reduction ``.grad`` of a parameter outside the arenas becomes the flat buffer's view
         # instead of receiving a copy of it (False: copy back into the tensors autograd produced)
@@ -89,6 +94,8 @@ class FlatGradSync:
         self._blocks = []
         self.use_blocks = use_blocks
         self._flag_key, self._flags = None, None
+        # None: not decided yet; False: the flags ride with the data and are read back from the device
+        self._host_group = None if host_flags else False
         self._member_strides = {}     # parameter index -> strides of its gradient inside an arena block
         self.uniform_usage = uniform_usage
         # uniform usage is an ASSUMPTION about the model; it is checked, not trusted (see sync)
@@ -358,6 +365,27 @@ class FlatGradSync:
             out.append(src)
         return out
 
+    def _host_flag_group(self):
+        """The group the usage flags are exchanged on from host memory, or False.  Decided ONCE, by every
+        rank together (creating a group is collective, and a rank that failed to create its twin must
+        not leave the others waiting on it)."""
+        if self._host_group is not None:
+            return self._host_group
+        import os
+        if dist.get_backend(self.group) == "gloo":
+            self._host_group = self.group if self.group is not None else dist.group.WORLD
+            return self._host_group
+        ok, twin = 0.0, False
+        if os.environ.get("PV2_GSYNC_HOST_FLAGS", "1") != "0" and (self.group is None or self.group is dist.group.WORLD):
+            try:
+                twin, ok = dist.new_group(backend="gloo"), 1.0
+            except Exception:   # noqa: BLE001 - no gloo transport on this machine: the device read remains
+                twin = False
+        t = torch.tensor([ok], device=self._buffers()[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        self._host_group = twin if float(t) > 0.5 else False
+        return self._host_group
+
     @torch.no_grad()
     def sync(self):
         """Average ``.grad`` over the ranks of the group (call between backward and the optimiser
@@ -400,17 +428,24 @@ class FlatGradSync:
         rest = [i for i in used if i not in moved]
         if rest:
             self._gather(rest, flat, views)
+        host_flags = None
         if not self.uniform_usage:
             key = tuple(used)
-            if self._flag_key != key:  # the local set changes rarely: its device copy is cached
+            hg = self._host_flag_group()
+            if self._flag_key != key:  # the local set changes rarely: its flag vector is cached
                 f = torch.zeros(len(self.params), dtype=torch.float32)
                 f[used] = 1.0
-                self._flag_key, self._flags = key, f.to(flat.device)
-            flat[self.numel:].copy_(self._flags)
+                self._flag_key, self._flags = key, (f if hg else f.to(flat.device))
+            if hg:
+                # host to host: nothing here waits for the device (the data follows below, on RCCL)
+                host_flags = self._flags.clone()
+                dist.all_reduce(host_flags, group=hg)
+            else:
+                flat[self.numel:].copy_(self._flags)
         # RCCL averages in the reduction itself; other backends (gloo in the CPU tests) sum
         avg = dist.get_backend(self.group) == "nccl" and self.uniform_usage
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        end = self.numel + 1 if self.uniform_usage else flat.numel()
+        end = self.numel + 1 if self.uniform_usage else (self.numel if host_flags is not None else flat.numel())
         handles = [dist.all_reduce(flat[a:min(a + self.slice_elems, end)], op=op, group=self.group,
                                    async_op=True) for a in range(0, end, self.slice_elems)]
         for h in handles:
@@ -427,7 +462,9 @@ class FlatGradSync:
             self._steps += 1
         if self.uniform_usage or len(used) == len(self.params):
             anywhere = [p.grad is not None and i not in self._covered for i, p in enumerate(self.params)]
-        else:  # somebody else's parameters: one small read, only when this rank skipped some
+        elif host_flags is not None:
+            anywhere = (host_flags > 0).tolist()
+        else:  # somebody else's parameters: one small (blocking) device read, only when this rank skipped some
             anywhere = (flat[self.numel:] > 0).tolist()
         if not avg:
             flat[:self.numel].div_(world)

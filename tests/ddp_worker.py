@@ -80,16 +80,22 @@ def grad_sync_worker(rank, world, port, out_dir):
         unused_stay_none = all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp)
         # ... and with rank 1 skipping one parameter that rank 0 trains (the multi-dataset case):
         # both ranks end with half of rank 0's gradient; parameters unused everywhere stay None
-        local_backward()
-        victim = dict(model.named_parameters())[sorted(g_ddp)[0]]
-        mine = victim.grad.clone()
-        if rank == 1:
-            victim.grad = None
-        FlatGradSync(model.parameters(), uniform_usage=False).sync()
-        ref0 = mine.clone()
-        dist.broadcast(ref0, src=0)
-        skip_ok = bool(victim.grad is not None and torch.allclose(victim.grad, ref0 / world, atol=1e-7)
-                       and all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp))
+        # (the usage flags exchanged host to host, and riding with the data + read back: same result)
+        skip_ok = True
+        for host_flags in (True, False):
+            local_backward()
+            victim = dict(model.named_parameters())[sorted(g_ddp)[0]]
+            mine = victim.grad.clone()
+            if rank == 1:
+                victim.grad = None
+            FlatGradSync(model.parameters(), uniform_usage=False, host_flags=host_flags).sync()
+            ref0 = mine.clone()
+            dist.broadcast(ref0, src=0)
+            skip_ok = skip_ok and bool(
+                victim.grad is not None and torch.allclose(victim.grad, ref0 / world, atol=1e-7)
+                and all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp)
+                and all(torch.allclose(dict(model.named_parameters())[n].grad, g_ddp[n], rtol=1e-5, atol=1e-7)
+                        for n in sorted(g_ddp)[1:]))
         torch.save(dict(rank=rank, worst=worst, loss=float(out["loss"]), n_grads=len(g_ddp),
                         worst_flat=worst_flat, unused_stay_none=unused_stay_none, skip_ok=skip_ok,
                         n_params=len(names)),
