@@ -399,7 +399,10 @@ int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, co
 #define PV2_UNET_CONCAT 2
 typedef struct pv2_unet_op {
   int32_t kind, c_in, c_out, relu;
-  int32_t K, kflip, dx_accumulate, reserved;
+  int32_t K, kflip, dx_accumulate;
+  int32_t dx_producer;     /* CONV_BN: 1 + index of the unit whose output is x when this unit's grad-input is the
+                            * LAST gradient x receives in backward order (0: not so, or x is no unit's output):
+                            * that unit's BatchNorm backward sums ride in this unit's row reduce */
   int64_t n_in, n_out, nbr_stride;
   const pv2_conv_geom* geom;
   const int32_t* nbr;
@@ -675,6 +678,42 @@ int pv2_ray_gen(const int64_t* pixels, int n_scenes, int n_views, int n_rays, in
                 const float* view, const float* scene, const float* colors, const float* depths,
                 const int64_t* semantic, const double* bounds_lo, const double* bounds_hi, float* ray_o,
                 float* ray_d, float* rgb, float* depth, int64_t* semantic_row, pv2_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-ray epilogue of the composited rows and the semantic loss term (csrc/ray_epilogue.hip): the tail
+ * of SurfaceModel.get_outputs - RGBRenderer / DepthRenderer / SemanticRenderer,
+ * ponder/models/ponder/render_utils/renderers.py:5-75 - and the semantic term of SurfaceModel.get_loss
+ * (base_surface_model.py:102-211), around three library matrix products.
+ *   comp [R, nv] = f'(n_f2) geo(n_geo) grad(3) normal(3) rgb(3) t sum_w pad..; starts [R, S], rays
+ *   scene-major with R / n_scenes rays per scene; bg = RGBRenderer.background_color.
+ *   pv2_ray_rows_forward: lohi [n_scenes, 2] = min / max sample distance per scene;
+ *     xbar [R, n_f2 + n_geo + 4] = [grad | f' | geo | sum_w] (the semantic head's input, biases ride on
+ *     the last column); rgb [R,3] = (rgb + bg) - sum_w bg; depth [R] = clamp(t / (sum_w + 1e-10), lo, hi).
+ *   pv2_ray_rows_backward: d_comp [R, nv] (every element written) from d_xbar, g_rgb, g_depth (any NULL).
+ *   pv2_semantic_ce_forward: raw [R, R] = sem . gt^T, sem / gt [R, c_sem], depth_gt [R]:
+ *     l_ij = raw_ij / max(|sem_i|, 1e-12) / temperature; row i counts when depth_gt_i > 0 and gt_i != 0;
+ *     info [R, pv2_ray_loss_info_floats()] = {|sem_i|, scale_i, logsumexp_i, ok_i, loss_i, ..}.
+ *   pv2_ray_loss_finalize: surface_terms [6] = pv2_surface_loss_forward's out; info may be NULL (no
+ *     semantic term) -> out [9] = depth, rgb, psnr, semantic = w_sem sum loss_i / max(count, 1),
+ *     free_space, sdf, eikonal, TOTAL (the loss terms added in that order), count.
+ *   pv2_semantic_ce_backward: g_total [1] (device) -> d_raw [R, R], d_sem_norm [R, c_sem] = the gradient
+ *     of sem through its norm; the caller adds d_raw . gt.
+ * ------------------------------------------------------------------------------------------ */
+int pv2_ray_loss_info_floats(void);
+int pv2_ray_rows_forward(const float* comp, int nv, int n_f2, int n_geo, const float* starts,
+                         int64_t n_rays, int n_samples, int n_scenes, float bg0, float bg1, float bg2,
+                         float* lohi, float* xbar, float* rgb, float* depth, pv2_stream_t stream);
+int pv2_ray_rows_backward(const float* comp, int nv, int n_f2, int n_geo, int64_t n_rays, int n_scenes,
+                          float bg0, float bg1, float bg2, const float* lohi, const float* d_xbar,
+                          const float* g_rgb, const float* g_depth, float* d_comp, pv2_stream_t stream);
+int pv2_semantic_ce_forward(const float* raw, const float* sem, const float* gt, const float* depth_gt,
+                            int64_t n_rays, int c_sem, float temperature, float* info,
+                            pv2_stream_t stream);
+int pv2_ray_loss_finalize(const float* info, int64_t n_rays, float w_sem, const float* surface_terms,
+                          float* out, pv2_stream_t stream);
+int pv2_semantic_ce_backward(const float* raw, const float* sem, const float* info, const float* g_total,
+                             const float* out, int64_t n_rays, int c_sem, float w_sem, float* d_raw,
+                             float* d_sem_norm, pv2_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-ray / per-sample loss terms of the surface-rendering models (csrc/surface_loss.hip):

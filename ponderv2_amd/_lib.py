@@ -39,7 +39,7 @@ class ConvGeom(Structure):
 class UnetOp(Structure):
     """pv2_unet_op: one record of the natively executed sparse U-Net (csrc/spunet_exec.hip)."""
     _fields_ = ([(k, c_int32) for k in ("kind", "c_in", "c_out", "relu", "K", "kflip",
-                                       "dx_accumulate", "reserved")]
+                                       "dx_accumulate", "dx_producer")]
                 + [(k, c_int64) for k in ("n_in", "n_out", "nbr_stride")]
                 + [("geom", POINTER(ConvGeom))]
                 + [(k, c_void_p) for k in ("nbr", "x", "residual", "weight", "bn_weight", "bn_bias",
@@ -59,7 +59,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),
@@ -153,6 +153,14 @@ SIGNATURES = {
     "pv2_surface_loss_workspace_floats": (c_int, []),
     "pv2_surface_loss_forward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P]),
     "pv2_surface_loss_backward": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pv2_ray_loss_info_floats": (c_int, []),
+    "pv2_ray_rows_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_int64, c_int, c_int, c_float, c_float,
+                                     c_float, _P, _P, _P, _P, _P]),
+    "pv2_ray_rows_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_float, c_float, c_float,
+                                      _P, _P, _P, _P, _P, _P]),
+    "pv2_semantic_ce_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, _P, _P]),
+    "pv2_ray_loss_finalize": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
+    "pv2_semantic_ce_backward": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_float, _P, _P, _P]),
     "pv2_narrow_head_dims": (c_int, [POINTER(c_int)] * 4),
     "pv2_narrow_coarse_sample": (
         c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P,

@@ -53,12 +53,20 @@ int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout
                  const int32_t* kstart, const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
                  float* dweight, float* part, hipStream_t s);
 // sparse_conv_pr.hip
+// The conv + BatchNorm unit whose OUTPUT is the activation a grad-input launch completes the gradient of.
+struct BnProducer {
+  const float* y_conv;
+  const float* out_or_null;   // the activation when a ReLU follows the BatchNorm
+  const float* mean_invstd;
+  float* gsum;                // [2 c]: sum g, sum g * xhat
+};
 int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
                     const float* weight, int c_out, const float* y_conv, const float* out_or_null,
                     const float* mean_invstd, const float* bn_weight, float* prod_ws,
                     float* stats_ws, float* gsum, float* dy, float* dres_or_null, float* dx_or_null,
                     int dx_accumulate, float* dweight_or_null, float* part_ws, hipStream_t s,
-                    hipStream_t side);
+                    hipStream_t side, int bn_sums_ready, const BnProducer* dx_producer,
+                    int* dx_sums_done);
 // rownorm.hip: the statistics kernels' partial-sum geometry (blocks <= 1024, rows per block) and the
 // second half of the fused BatchNorm forward - combine the per-block partial sums (written by
 // col_partials or by row_reduce_kernel's epilogue, shifted by row 0 of x) and apply.
@@ -67,6 +75,13 @@ int bn_forward_from_partials(const float* x, int64_t n, int c, const float* part
                              const float* weight, const float* bias, const float* residual,
                              int relu, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean_invstd, float* y, hipStream_t s);
+
+int bn_apply(const float* x, int64_t n, int c, const float* mean_invstd, const float* weight,
+             const float* bias, const float* residual, int relu, float* y, hipStream_t s);
+int bn_backward_combine(const float* partial, int blocks, int c, float* gsum, hipStream_t s);
+int bn_backward_apply(const float* dy, const float* x, const float* y_or_null, const float* mean_invstd,
+                      const float* weight, const float* gsum, int64_t n, int c, float* dx, float* dres,
+                      hipStream_t s);
 
 int bn_forward_from_block_stats(const float* x, int64_t n, int c, const float* partial, int blocks,
                                 int64_t rows_per_block, const float* weight, const float* bias,

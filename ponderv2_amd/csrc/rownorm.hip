@@ -239,24 +239,27 @@ __global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
 //   MODE 1: out[0..C) = sum g (= dbias), out[C..2C) = sum g*xhat (= dweight)
 // (kCombineThreads / 32 = 32 sub-sums per channel: with up to 2048 partial rows the loop is a chain of
 // dependent loads - 8 sub-sums took 10 us per layer, 118 launches per step)
+// Round 6: the panel is 8 channels wide when there are many partial rows (128 sub-sums per channel, four
+// times the workgroups: 6.7 -> ~3 us per launch at ~1500 rows; the rows are read in 32-byte pieces).
 constexpr int kCombineThreads = 1024;
-constexpr int kCombineSubs = kCombineThreads / 32;
+constexpr int kCombineSubs = kCombineThreads / 32;   // (col_combine_blocks_kernel: 32-channel panels)
 template <int MODE, typename EX>
 __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
-    const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0, int64_t n,
-    float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-    float* __restrict__ out, const float* __restrict__ aff_w = nullptr,
+    int panel, const float* __restrict__ partial, int nb, int c, const typename EX::type* __restrict__ x0,
+    int64_t n, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float* __restrict__ out, const float* __restrict__ aff_w = nullptr,
     const float* __restrict__ aff_b = nullptr, float* __restrict__ affine = nullptr,
     int64_t extra_zero_rows = 0, const float* __restrict__ extra_g0 = nullptr, int n_extra_g0 = 0,
     const float* __restrict__ mean_invstd_in = nullptr) {
   __shared__ double r0[kCombineThreads];
   __shared__ double r1[kCombineThreads];
-  const int tid = threadIdx.x, q = tid >> 5, cc = tid & 31;
-  const int ch = blockIdx.x * 32 + cc;
+  const int subs = kCombineThreads / panel;   // sub-sums per channel: 32 or 128
+  const int tid = threadIdx.x, q = tid / panel, cc = tid % panel;
+  const int ch = blockIdx.x * panel + cc;
   double a0 = 0.0, a1 = 0.0;
   if (ch < c) {
 #pragma unroll 8
-    for (int b = q; b < nb; b += kCombineSubs) {
+    for (int b = q; b < nb; b += subs) {
       a0 += (double)partial[(int64_t)b * 2 * c + ch];
       a1 += (double)partial[(int64_t)b * 2 * c + c + ch];
     }
@@ -264,11 +267,26 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
   r0[tid] = a0;
   r1[tid] = a1;
   __syncthreads();
+  // the sub-sums in order of q, in two steps: eight threads per channel add subs / 8 each, one adds those
+  const int per = subs / 8;
+  double u0 = 0.0, u1 = 0.0;
+  if (q < 8) {
+    for (int k = q * per; k < (q + 1) * per; ++k) {
+      u0 += r0[k * panel + cc];
+      u1 += r1[k * panel + cc];
+    }
+  }
+  __syncthreads();
+  if (q < 8) {
+    r0[tid] = u0;
+    r1[tid] = u1;
+  }
+  __syncthreads();
   if (q != 0 || ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
-  for (int k = 0; k < kCombineSubs; ++k) {
-    t0 += r0[k * 32 + cc];
-    t1 += r1[k * 32 + cc];
+  for (int k = 0; k < 8; ++k) {
+    t0 += r0[k * panel + cc];
+    t1 += r1[k * panel + cc];
   }
   if (MODE == 0) {
     if (extra_zero_rows != 0) {
@@ -310,6 +328,13 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
     out[ch] = (float)t0;
     out[c + ch] = (float)t1;
   }
+}
+
+template <int MODE, typename EX, typename... A>
+inline void launch_combine(hipStream_t s, int c, const float* partial, int nb, A... rest) {
+  const int panel = nb >= 256 ? 8 : 32;
+  hipLaunchKernelGGL((col_combine_kernel<MODE, EX>), dim3((c + panel - 1) / panel), dim3(kCombineThreads), 0,
+                     s, panel, partial, nb, rest...);
 }
 
 // The forward statistics from PER-BLOCK moments (the epilogue of spconv_osm_kernel): block b of
@@ -538,12 +563,47 @@ void bn_partial_geometry(int64_t n, int c, int* blocks, int64_t* rows_per_block)
   partial_geometry(n, c, blocks, rows_per_block);
 }
 
+int bn_apply(const float* x, int64_t n, int c, const float* mean_invstd, const float* weight,
+             const float* bias, const float* residual, int relu, float* y, hipStream_t s) {
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((bn_apply_vec_kernel<F32, F32>), dim3(pv2::grid_for(n * c / 8, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<F32, F32>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, x, n * c, c, mean_invstd, weight, bias, residual, relu,
+                       y);
+  return pv2::check_launch("bn_apply");
+}
+
+// The two remaining steps of the BatchNorm backward when the per-block partial sums of {g, g * xhat} were
+// written by the epilogue of the grad-input row reduce that completed dy (sparse_conv_pr.hip STATS == 2):
+// the ordered combine into gsum, and - when the unit's turn comes - the elementwise pass.
+int bn_backward_combine(const float* partial, int blocks, int c, float* gsum, hipStream_t s) {
+  launch_combine<1, F32>(s, c, partial, blocks, c, (const float*)nullptr, (int64_t)0, 0.f, 0.f, nullptr, nullptr,
+                     gsum);
+  return pv2::check_launch("bn_backward_combine");
+}
+
+int bn_backward_apply(const float* dy, const float* x, const float* y_or_null, const float* mean_invstd,
+                      const float* weight, const float* gsum, int64_t n, int c, float* dx, float* dres,
+                      hipStream_t s) {
+  if ((c % 8) == 0)
+    hipLaunchKernelGGL((bn_backward_apply_vec_kernel<F32, F32>),
+                       dim3(pv2::grid_for(n * c / 8, kThreads)), dim3(kThreads), 0, s, dy, x, y_or_null,
+                       mean_invstd, weight, gsum, n, c, dx, dres, (int64_t)0);
+  else
+    hipLaunchKernelGGL((bn_backward_apply_kernel<F32, F32>), dim3(pv2::grid_for(n * c, kThreads)),
+                       dim3(kThreads), 0, s, dy, x, y_or_null, mean_invstd, weight, gsum, n, c, dx, dres,
+                       (int64_t)0);
+  return pv2::check_launch("bn_backward_apply");
+}
+
 int bn_forward_from_partials(const float* x, int64_t n, int c, const float* partial, int blocks,
                              const float* weight, const float* bias, const float* residual,
                              int relu, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean_invstd, float* y, hipStream_t s) {
-  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     partial, blocks, c, x, n, eps, momentum, running_mean, running_var,
+  launch_combine<0, F32>(s, c, partial, blocks, c, x, n, eps, momentum, running_mean, running_var,
                      mean_invstd);
   if ((c % 8) == 0)
     hipLaunchKernelGGL((bn_apply_vec_kernel<F32, F32>), dim3(pv2::grid_for(n * c / 8, kThreads)),
@@ -597,8 +657,7 @@ int bn_forward_t(const void* x, int64_t n, int c, const float* weight, const flo
     hipLaunchKernelGGL((col_partials_kernel<0, EX, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
                        (const TX*)x, (const TX*)nullptr, (const TY*)nullptr, nullptr, n, c, rpb,
                        workspace);
-  hipLaunchKernelGGL((col_combine_kernel<0, EX>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     workspace, blocks, c, (const TX*)x, n, eps, momentum, running_mean, running_var,
+  launch_combine<0, EX>(s, c, workspace, blocks, c, (const TX*)x, n, eps, momentum, running_mean, running_var,
                      mean_invstd);
   if (vec)
     hipLaunchKernelGGL((bn_apply_vec_kernel<EX, EY>), dim3(pv2::grid_for(n * c / 8, kThreads)),
@@ -629,8 +688,7 @@ int bn_backward_t(const void* dy, const void* x, const void* y_or_null, const fl
     hipLaunchKernelGGL((col_partials_kernel<1, EY, EX, EY>), dim3(blocks), dim3(kThreads), 0, s,
                        (const TY*)dy, (const TX*)x, (const TY*)y_or_null, mean_invstd, n, c, rpb,
                        workspace);
-  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     workspace, blocks, c, (const float*)nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
+  launch_combine<1, F32>(s, c, workspace, blocks, c, (const float*)nullptr, n, 0.f, 0.f, nullptr, nullptr, gsum);
   if (vec)
     hipLaunchKernelGGL((bn_backward_apply_vec_kernel<EX, EY>),
                        dim3(pv2::grid_for(n * c / 8, kThreads)), dim3(kThreads), 0, s, (const TY*)dy,
@@ -718,8 +776,7 @@ int pv2_bn_statistics(const float* x, int64_t n, int c, const float* weight, con
   else
     hipLaunchKernelGGL((col_partials_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
                        x, (const float*)nullptr, (const float*)nullptr, nullptr, n, c, rpb, workspace);
-  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     workspace, blocks, c, x, n, eps, momentum, running_mean, running_var, mean_invstd,
+  launch_combine<0, F32>(s, c, workspace, blocks, c, x, n, eps, momentum, running_mean, running_var, mean_invstd,
                      weight, bias, affine);
   return pv2::check_launch("bn_statistics");
 }
@@ -748,8 +805,7 @@ int pv2_bn_statistics_padded(const float* x, int64_t n_rows, int64_t extra_zero_
     hipLaunchKernelGGL((col_partials_kernel<0, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
                        x, (const float*)nullptr, (const float*)nullptr, nullptr, n_rows, c, rpb,
                        workspace);
-  hipLaunchKernelGGL((col_combine_kernel<0, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     workspace, blocks, c, x, n_rows + extra_zero_rows, eps, momentum, running_mean,
+  launch_combine<0, F32>(s, c, workspace, blocks, c, x, n_rows + extra_zero_rows, eps, momentum, running_mean,
                      running_var, mean_invstd, weight, bias, affine, extra_zero_rows);
   return pv2::check_launch("bn_statistics_padded");
 }
@@ -778,8 +834,7 @@ int pv2_bn_backward_padded(const float* dy, const float* x, int64_t n_rows, int6
   else
     hipLaunchKernelGGL((col_partials_kernel<1, F32, F32, F32>), dim3(blocks), dim3(kThreads), 0, s,
                        dy, x, (const float*)nullptr, mean_invstd, n_rows, c, rpb, workspace);
-  hipLaunchKernelGGL((col_combine_kernel<1, F32>), dim3((c + 31) / 32), dim3(kCombineThreads), 0, s,
-                     workspace, blocks, c, (const float*)nullptr, n_rows, 0.f, 0.f, nullptr, nullptr,
+  launch_combine<1, F32>(s, c, workspace, blocks, c, (const float*)nullptr, n_rows, 0.f, 0.f, nullptr, nullptr,
                      gsum, nullptr, nullptr, nullptr, (int64_t)0, total_parts, n_total_parts,
                      mean_invstd);
   const int64_t n_norm = n_rows + extra_zero_rows;

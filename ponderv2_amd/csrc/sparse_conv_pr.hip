@@ -141,11 +141,17 @@ __device__ __forceinline__ void next4(RowState<TS>& st, int (&p)[4]) {
   }
 }
 
-template <int TS, int NJ, bool STATS>
+// STATS == 2: the BACKWARD sums of the BatchNorm that PRODUCED the activation whose gradient this launch
+// completes (out = its gradient, all consumers added): per-block partial sums of g and g * xhat with
+// g = out * (act > 0), xhat = (yprod - mean) * invstd - what col_partials_kernel<1> computes in a pass of
+// its own over three matrices.  `sy` = the producer's conv output, `so` = its activation (null: no ReLU),
+// `smi` = its {mean, invstd}.
+template <int TS, int NJ, int STATS>
 __global__ __launch_bounds__(256) void row_reduce_kernel(
     const float* __restrict__ T, const int32_t* __restrict__ pos, int64_t pos_stride, int K, int c,
     int64_t n_rows, int64_t rows_per_block, const float* __restrict__ bias,
-    const float* addend, float* Y, float* __restrict__ partial) {
+    const float* addend, float* Y, float* partial, const float* __restrict__ sy,
+    const float* __restrict__ so, const float* __restrict__ smi) {
   constexpr int NT = 256 / TS;
   __shared__ float s_red[STATS ? 2048 * NJ : 1];
   const int tid = threadIdx.x, team = tid / TS, l = tid % TS;
@@ -154,17 +160,29 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
   const float4* T4 = reinterpret_cast<const float4*>(T);
   const float4* bias4 = reinterpret_cast<const float4*>(bias);
   const float4* add4p = reinterpret_cast<const float4*>(addend);
+  const float4* sy4 = reinterpret_cast<const float4*>(sy);
+  const float4* so4 = reinterpret_cast<const float4*>(so);
   float4* Y4 = reinterpret_cast<float4*>(Y);
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = min(n_rows, r_begin + rows_per_block);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 sh[NJ], a0[NJ], a1[NJ];
+  float4 sh[NJ], a0[NJ], a1[NJ], is4[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) sh[j] = a0[j] = a1[j] = zero;
+  for (int j = 0; j < NJ; ++j) sh[j] = a0[j] = a1[j] = is4[j] = zero;
+  if (STATS == 2) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = l + j * TS;
+      if (col < c4n) {
+        sh[j] = reinterpret_cast<const float4*>(smi)[col];          // mean
+        is4[j] = reinterpret_cast<const float4*>(smi + c)[col];     // invstd
+      }
+    }
+  }
 
-  // rows come in pairs (A, B); the very first B of a STATS launch is row 0 (the shift)
-  bool need_shift = STATS;
+  // rows come in pairs (A, B); the very first B of a STATS == 1 launch is row 0 (the shift)
+  bool need_shift = STATS == 1;
   for (int64_t ra = r_begin + team; ra < r_end || need_shift; ra += 2 * NT) {
     const int64_t rb = need_shift ? 0 : ra + NT;
     const bool va = ra < r_end, vb = need_shift || rb < r_end;
@@ -172,10 +190,13 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
     load_entries<TS>(sa, pos, pos_stride, K, va ? ra : 0, va, l, team_base);
     load_entries<TS>(sb, pos, pos_stride, K, vb ? rb : 0, vb, l, team_base);
     float4 accA[NJ], accB[NJ];
+    float4 yA[NJ], yB[NJ], oA[NJ], oB[NJ];   // STATS == 2: the producer's rows, requested up front
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = l + j * TS;
       float4 ia = zero, ib = zero;
+      yA[j] = yB[j] = zero;
+      oA[j] = oB[j] = make_float4(1.f, 1.f, 1.f, 1.f);
       if (col < c4n) {
         if (add4p) {
           if (va) ia = add4p[ra * c4n + col];
@@ -185,6 +206,14 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
           const float4 bv = bias4[col];
           add4(ia, bv);
           add4(ib, bv);
+        }
+        if (STATS == 2) {
+          if (va) yA[j] = sy4[ra * c4n + col];
+          if (vb) yB[j] = sy4[rb * c4n + col];
+          if (so4) {
+            if (va) oA[j] = so4[ra * c4n + col];
+            if (vb) oB[j] = so4[rb * c4n + col];
+          }
         }
       }
       accA[j] = ia;
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
       if (need_shift) sh[j] = accB[j];                 // row 0: the shift (block 0 also stores it below)
       if (va) Y4[ra * c4n + col] = accA[j];
       if (!need_shift && vb) Y4[rb * c4n + col] = accB[j];
-      if (STATS) {
+      if (STATS == 1) {
         if (va) {
           const float4 d = make_float4(accA[j].x - sh[j].x, accA[j].y - sh[j].y, accA[j].z - sh[j].z,
                                        accA[j].w - sh[j].w);
@@ -231,6 +260,17 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
           add4(a0[j], d);
           add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
         }
+      }
+      if (STATS == 2) {
+        auto one = [&](const float4& g_, const float4& yv, const float4& ov) {
+          const float4 g = make_float4(ov.x > 0.f ? g_.x : 0.f, ov.y > 0.f ? g_.y : 0.f,
+                                       ov.z > 0.f ? g_.z : 0.f, ov.w > 0.f ? g_.w : 0.f);
+          add4(a0[j], g);
+          add4(a1[j], make_float4(g.x * (yv.x - sh[j].x) * is4[j].x, g.y * (yv.y - sh[j].y) * is4[j].y,
+                                  g.z * (yv.z - sh[j].z) * is4[j].z, g.w * (yv.w - sh[j].w) * is4[j].w));
+        };
+        if (va) one(accA[j], yA[j], oA[j]);
+        if (vb) one(accB[j], yB[j], oB[j]);
       }
     }
     if (need_shift) {
@@ -259,14 +299,24 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
   }
 }
 
-template <bool STATS>
+// What the STATS modes of row_reduce_kernel need beyond the sum itself.
+struct ReduceStats {
+  int mode = 0;                   // 0 / 1 (forward statistics of the result) / 2 (backward sums, see above)
+  float* partial = nullptr;       // [blocks][2 c]
+  const float* sy = nullptr;      // mode 2
+  const float* so = nullptr;
+  const float* smi = nullptr;
+};
+
+template <int STATS>
 void launch_reduce(const float* T, const int32_t* pos, int64_t pos_stride, int K, int c,
                    int64_t n_rows, int blocks, int64_t rpb, const float* bias, const float* addend,
-                   float* Y, float* partial, hipStream_t s) {
+                   float* Y, const ReduceStats& st, hipStream_t s) {
   const int c4n = c / 4;
 #define PV2_RED(TS, NJ)                                                                          \
   hipLaunchKernelGGL((row_reduce_kernel<TS, NJ, STATS>), dim3(blocks), dim3(256), 0, s, T, pos,  \
-                     pos_stride, K, c, n_rows, rpb, bias, addend, Y, partial)
+                     pos_stride, K, c, n_rows, rpb, bias, addend, Y, st.partial, st.sy, st.so,   \
+                     st.smi)
   if (c4n <= 8) PV2_RED(8, 1);
   else if (c4n <= 16) PV2_RED(16, 1);
   else if (c4n <= 32) PV2_RED(32, 1);
@@ -275,9 +325,9 @@ void launch_reduce(const float* T, const int32_t* pos, int64_t pos_stride, int K
 #undef PV2_RED
 }
 
-int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
-                int64_t n_rows, const float* bias, const float* addend, float* out,
-                float* bn_partial, int* bn_blocks, hipStream_t s) {
+int reduce_rows_stats(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
+                      int64_t n_rows, const float* bias, const float* addend, float* out,
+                      const ReduceStats& st, int* bn_blocks, hipStream_t s) {
   PV2_REQUIRE(K >= 1 && K <= kMaxK, "pv2_spconv_reduce_rows: 1 <= K <= 32");
   PV2_REQUIRE(c >= 4 && (c % 4) == 0 && c <= 512,
               "pv2_spconv_reduce_rows: channel count must be a multiple of 4, at most 512");
@@ -288,19 +338,29 @@ int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K
   // statistics ride along (one partial row per workgroup, pv2_bn_workspace_floats) and 16384 otherwise.
   const int c4n = c / 4;
   const int nt = 256 / (c4n <= 8 ? 8 : c4n <= 16 ? 16 : c4n <= 32 ? 32 : 64);
-  const int64_t cap = bn_partial ? 2048 : 16384;
+  const int64_t cap = st.mode ? 2048 : 16384;
   int64_t rpb = (n_rows + cap - 1) / cap;
   rpb = (rpb + 2 * nt - 1) / (2 * nt) * (2 * nt);
   const int blocks = (int)((n_rows + rpb - 1) / rpb);
-  if (bn_partial) {
-    launch_reduce<true>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,
-                        bn_partial, s);
-    if (bn_blocks) *bn_blocks = blocks;
-  } else {
-    launch_reduce<false>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out,
-                         nullptr, s);
-  }
+  if (st.mode == 1)
+    launch_reduce<1>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out, st, s);
+  else if (st.mode == 2)
+    launch_reduce<2>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out, st, s);
+  else
+    launch_reduce<0>(prod, pos, pos_stride, K, c, n_rows, blocks, rpb, bias, addend, out, st, s);
+  if (st.mode && bn_blocks) *bn_blocks = blocks;
   return pv2::check_launch("spconv_reduce_rows");
+}
+
+int reduce_rows(const float* prod, const int32_t* pos, int64_t pos_stride, int K, int c,
+                int64_t n_rows, const float* bias, const float* addend, float* out,
+                float* bn_partial, int* bn_blocks, hipStream_t s) {
+  ReduceStats st;
+  if (bn_partial) {
+    st.mode = 1;
+    st.partial = bn_partial;
+  }
+  return reduce_rows_stats(prod, pos, pos_stride, K, c, n_rows, bias, addend, out, st, bn_blocks, s);
 }
 
 // Events that order the side stream of pv2_convbn_backward behind the caller's stream.  A wait
@@ -325,16 +385,28 @@ namespace pv2 {
 // Backward of one conv + BatchNorm unit (the body of pv2_convbn_backward).  dx_accumulate: the
 // grad-input is ADDED to what dx already holds (another consumer of the same activation wrote its
 // gradient first) - the row-reduce kernel takes dx as its addend, element for element in place.
+// bn_sums_ready: gsum already holds this unit's {sum g, sum g * xhat} (the launch that completed
+// grad_out computed them in its epilogue): only the elementwise half of the BatchNorm backward runs.
+// dx_producer: this unit's grad-input COMPLETES the gradient of its input activation, which is the
+// output of the conv + BatchNorm unit described there - its backward sums are taken in the row
+// reduce's epilogue and combined into dx_producer->gsum (*dx_sums_done = 1 when that happened).
 int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* x, int c_in,
                     const float* weight, int c_out, const float* y_conv, const float* out_or_null,
                     const float* mean_invstd, const float* bn_weight, float* prod_ws,
                     float* stats_ws, float* gsum, float* dy, float* dres_or_null, float* dx_or_null,
                     int dx_accumulate, float* dweight_or_null, float* part_ws, hipStream_t s,
-                    hipStream_t side) {
+                    hipStream_t side, int bn_sums_ready, const BnProducer* dx_producer,
+                    int* dx_sums_done) {
   PV2_REQUIRE(g != nullptr && g->n_out >= 2, "pv2_convbn_backward: needs at least two output rows");
-  if (int e = pv2_bn_backward(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, g->n_out, c_out,
-                              stats_ws, gsum, dy, dres_or_null, (pv2_stream_t)s))
+  if (dx_sums_done) *dx_sums_done = 0;
+  if (bn_sums_ready) {
+    if (int e = pv2::bn_backward_apply(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, gsum,
+                                       g->n_out, c_out, dy, dres_or_null, s))
+      return e;
+  } else if (int e = pv2_bn_backward(grad_out, y_conv, out_or_null, mean_invstd, bn_weight, g->n_out,
+                                     c_out, stats_ws, gsum, dy, dres_or_null, (pv2_stream_t)s)) {
     return e;
+  }
   if (dweight_or_null) {
     if (side != s) {  // the weight gradient feeds nothing until the optimizer: off the critical chain
       hipEvent_t ev = fork_event();
@@ -358,9 +430,23 @@ int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* 
     if (int e = pv2::spconv_products(true, dy, c_out, weight, g->K, c_in, g->pair_out, g->kstart,
                                      g->tile_start, g->n_tiles, prod_ws, s))
       return e;
-    if (int e = reduce_rows(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
-                            dx_accumulate ? dx_or_null : nullptr, dx_or_null, nullptr, nullptr, s))
+    ReduceStats st;
+    if (dx_producer && dx_producer->gsum && g->n_in >= 2) {
+      st.mode = 2;
+      st.partial = stats_ws;
+      st.sy = dx_producer->y_conv;
+      st.so = dx_producer->out_or_null;
+      st.smi = dx_producer->mean_invstd;
+    }
+    int blocks = 0;
+    if (int e = reduce_rows_stats(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
+                                  dx_accumulate ? dx_or_null : nullptr, dx_or_null, st, &blocks, s))
       return e;
+    if (st.mode == 2) {
+      // (combined at once: the workspace serves the next unit's statistics)
+      if (int e = pv2::bn_backward_combine(stats_ws, blocks, c_in, dx_producer->gsum, s)) return e;
+      if (dx_sums_done) *dx_sums_done = 1;
+    }
   }
   return PV2_OK;
 }
@@ -440,7 +526,8 @@ int pv2_convbn_backward(const pv2_conv_geom* g, const float* grad_out, const flo
   return pv2::convbn_backward(g, grad_out, x, c_in, weight, c_out, y_conv, out_or_null, mean_invstd,
                               bn_weight, prod_ws, stats_ws, gsum, dy, dres_or_null, dx_or_null, 0,
                               dweight_or_null, part_ws, (hipStream_t)stream,
-                              side_stream ? (hipStream_t)side_stream : (hipStream_t)stream);
+                              side_stream ? (hipStream_t)side_stream : (hipStream_t)stream, 0, nullptr,
+                              nullptr);
 }
 
 }  // extern "C"

@@ -14,6 +14,9 @@
 // skip), visited in reverse order; the FIRST gradient to arrive is written, later ones are added
 // by the row-reduce kernel's addend input (`dx_accumulate`) - no zero-fills, no separate add
 // kernels, fixed order.  Weight gradients go to the side stream behind one event per unit.
+#include <cstdlib>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -118,21 +121,47 @@ int pv2_unet_backward_ev(const pv2_unet_op* ops, int n_ops, float* prod_ws, floa
                 "pv2_unet_backward_ev: checkpoints must be unit indices in descending order");
   hipStream_t s = (hipStream_t)stream;
   int next_ckpt = 0;   // checkpoints are listed in the order the units finish: descending unit index
+  // sums_ready[i]: the BatchNorm backward sums of unit i were taken by the launch that completed the
+  // gradient of its output (the grad-input row reduce of the unit's LAST consumer in backward order,
+  // op.dx_producer) - unit i then runs only the elementwise half of its BatchNorm backward
+  std::vector<char> sums_ready((size_t)n_ops, 0);
+  static const bool fuse_sums = [] {
+    const char* e = getenv("PV2_BN_BWD_FUSED");   // 0: every BatchNorm backward takes its own sums (A / B)
+    return !(e && e[0] == '0');
+  }();
   for (int i = n_ops - 1; i >= 0; --i) {
     const pv2_unet_op& u = ops[i];
     int e = PV2_OK;
     switch (u.kind) {
-      case PV2_UNET_CONV_BN:
+      case PV2_UNET_CONV_BN: {
+        pv2::BnProducer prod{};
+        const int pi = u.dx_producer - 1;
+        const bool fuse = fuse_sums && u.dx != nullptr && pi >= 0 && pi < i && ops[pi].kind != PV2_UNET_CONCAT &&
+                          ops[pi].out == u.x && ops[pi].c_out == u.c_in && ops[pi].gsum != nullptr;
+        if (fuse) {
+          prod.y_conv = ops[pi].y_conv;
+          prod.out_or_null = ops[pi].relu ? ops[pi].out : nullptr;
+          prod.mean_invstd = ops[pi].mean_invstd;
+          prod.gsum = ops[pi].gsum;
+        }
+        int done = 0;
         e = pv2::convbn_backward(u.geom, u.grad_out, u.x, u.c_in, u.weight, u.c_out, u.y_conv,
                                  u.relu ? u.out : nullptr, u.mean_invstd, u.bn_weight, prod_ws,
                                  stats_ws, u.gsum, u.dy, u.dres, u.dx, u.dx_accumulate, u.dweight,
-                                 part_ws, s, side_stream ? (hipStream_t)side_stream : s);
+                                 part_ws, s, side_stream ? (hipStream_t)side_stream : s, sums_ready[i],
+                                 fuse ? &prod : nullptr, &done);
+        if (done) sums_ready[pi] = 1;
         break;
+      }
       case PV2_UNET_STEM: {
         // (the stem is the last unit of the backward pass: the product-row workspace is free and
         // serves as the weight gradient's partial-sum buffer, on the caller's stream)
-        e = pv2_bn_backward(u.grad_out, u.y_conv, u.relu ? u.out : nullptr, u.mean_invstd,
-                            u.bn_weight, u.n_out, u.c_out, stats_ws, u.gsum, u.dy, u.dres, stream);
+        if (sums_ready[i])
+          e = pv2::bn_backward_apply(u.grad_out, u.y_conv, u.relu ? u.out : nullptr, u.mean_invstd,
+                                     u.bn_weight, u.gsum, u.n_out, u.c_out, u.dy, u.dres, s);
+        else
+          e = pv2_bn_backward(u.grad_out, u.y_conv, u.relu ? u.out : nullptr, u.mean_invstd,
+                              u.bn_weight, u.n_out, u.c_out, stats_ws, u.gsum, u.dy, u.dres, stream);
         if (e == PV2_OK && u.dweight)
           e = pv2::spconv_wgrad(u.x, u.n_in, u.c_in, u.dy, u.n_out, u.c_out, u.K, u.geom->pair_in,
                                 u.geom->pair_out, u.geom->kstart, u.geom->tile_start_w,

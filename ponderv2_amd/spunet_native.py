@@ -81,7 +81,7 @@ class _Arena:
 class _Unit:
     __slots__ = ("kind", "conv", "bn", "rb", "geom", "geom_ptr", "c_in", "c_out", "relu", "src", "dst",
                  "res", "w_index", "affine", "n_in", "n_out", "y_off", "mi_off", "dy_off", "gsum_off",
-                 "dw_off", "acc_dx", "acc_res", "K")
+                 "dw_off", "acc_dx", "acc_res", "K", "dx_producer")
 
 
 class Plan:
@@ -157,6 +157,7 @@ def build_plan(model, x, condition=None, context=None):
             return None
         u.affine = (bn_weight, bn_bias)
         u.acc_dx = u.acc_res = False
+        u.dx_producer = 0
         u.dst = plan.act(u.n_out, u.c_out)
         plan.units.append(u)
         return u.dst
@@ -248,6 +249,20 @@ def build_plan(model, x, condition=None, context=None):
         if u.kind == UNET_CONV_BN:
             u.acc_dx = u.src in seen
             seen.add(u.src)
+    # The LAST gradient an activation receives in backward order comes from its first consumer in forward
+    # order.  When that consumer is a conv unit reading it as its input, the BatchNorm backward sums of
+    # the unit that PRODUCED the activation ride in that conv's grad-input row reduce (csrc/
+    # sparse_conv_pr.hip STATS == 2): the producer then skips the statistics pass of its BatchNorm backward.
+    producer = {u.dst: i for i, u in enumerate(plan.units) if u.kind != UNET_CONCAT}
+    first_consumer = {}
+    for i, u in enumerate(plan.units):
+        for a in (u.src, u.res):
+            if a is not None and a not in first_consumer:
+                first_consumer[a] = i
+    for a, i in first_consumer.items():
+        u = plan.units[i]
+        if u.kind == UNET_CONV_BN and u.src == a and u.res != a and a in producer and a != plan.out_act:
+            u.dx_producer = producer[a] + 1
     return plan
 
 
@@ -332,6 +347,7 @@ def _fill_forward(plan, feats, tensors):
                 u.c_in, u.c_out, n_tiles_w)))
         else:
             op.dx_accumulate = int(u.acc_dx)
+            op.dx_producer = u.dx_producer
             max_prod = max(max_prod, u.rb.n_pairs * max(u.c_in, u.c_out))
     plan.ops = ops
     plan.max_prod, plan.max_c = max_prod, max_c
