@@ -22,7 +22,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ray_epilogue
 from .kernels import _ptr, _require_device, _stream, zeros_by_kernel
 
 ENABLED = os.environ.get("PV2_FUSED_HEAD", "1") != "0"
@@ -577,28 +577,42 @@ def _render_outputs(model, ray_bundle, volume_feature):
         sdf, grad, weights, comp = field_render_folded(vol5, wfp, *head)
     else:
         sdf, grad, weights, comp = field_render(vol5, *head)
-    # ONE split of the composite row (its backward is one cat - six slices cost a zero-fill, a copy and
-    # an add each): columns f'(64) geo(64) grad(3) normal(3) rgb(3) t 1 pad
-    f2c, geoc, g3c, nrm, rgbc, tcol, wsum, _ = comp.split([F2, G, 3, 3, 3, 1, 1, NV - COL_ONE - 1], dim=1)
-    out = {}
-    bg = device_constant(model.rgb_renderer.background_color, dev, comp.dtype)
-    rgb = torch.addcmul(rgbc + bg, wsum, bg, value=-1.0)      # rgb + bg * (1 - wsum)
-    out["rgb"] = rgb if model.training else rgb.clamp(0.0, 1.0)
     md = field.semantic_decoder
-    if md is not None:
-        xbar = torch.cat([g3c, f2c, geoc], dim=1)
-        zero = _ZeroOf.apply(md.fc_p.weight, md.fc_p.bias)
-        hidden = F.linear(xbar, md.fc_c[0].weight) + (md.fc_c[0].bias + zero) * wsum
-        lin = md.last_linear
-        out["semantic"] = F.linear(hidden, lin.weight) + lin.bias * wsum
-    depth = tcol / (wsum + 1e-10)
-    lo, hi = torch.aminmax(starts.reshape(B, -1), dim=1)          # per scene: nearest / farthest sample
-    lo = lo[:, None].expand(B, R // B).reshape(-1, 1)
-    hi = hi[:, None].expand(B, R // B).reshape(-1, 1)
-    out["depth"] = torch.clamp(depth, lo, hi)
-    out["normal"] = nrm
-    out.update(weights=weights.unsqueeze(-1), sdf=sdf.unsqueeze(-1), gradients=grad,
+    bg_color = model.rgb_renderer.background_color
+
+    def per_ray_outputs():
+        """rgb / semantic / depth / normal with torch ops (renderers.py:5-75) - evaluation, and whoever
+        reads these entries; the training step gets its losses from the composite rows directly
+        (ray_epilogue.ray_losses)."""
+        # ONE split of the composite row (its backward is one cat - six slices cost a zero-fill, a copy and
+        # an add each): columns f'(64) geo(64) grad(3) normal(3) rgb(3) t 1 pad
+        f2c, geoc, g3c, nrm, rgbc, tcol, wsum, _ = comp.split([F2, G, 3, 3, 3, 1, 1, NV - COL_ONE - 1], dim=1)
+        res = {}
+        bg = device_constant(bg_color, dev, comp.dtype)
+        rgb = torch.addcmul(rgbc + bg, wsum, bg, value=-1.0)      # rgb + bg * (1 - wsum)
+        res["rgb"] = rgb if model.training else rgb.clamp(0.0, 1.0)
+        if md is not None:
+            xbar = torch.cat([g3c, f2c, geoc], dim=1)
+            zero = _ZeroOf.apply(md.fc_p.weight, md.fc_p.bias)
+            hidden = F.linear(xbar, md.fc_c[0].weight) + (md.fc_c[0].bias + zero) * wsum
+            lin = md.last_linear
+            res["semantic"] = F.linear(hidden, lin.weight) + lin.bias * wsum
+        depth = tcol / (wsum + 1e-10)
+        lo, hi = torch.aminmax(starts.reshape(B, -1), dim=1)          # per scene: nearest / farthest sample
+        lo = lo[:, None].expand(B, R // B).reshape(-1, 1)
+        hi = hi[:, None].expand(B, R // B).reshape(-1, 1)
+        res["depth"] = torch.clamp(depth, lo, hi)
+        res["normal"] = nrm
+        return res
+
+    out = dict(weights=weights.unsqueeze(-1), sdf=sdf.unsqueeze(-1), gradients=grad,
                z_vals=starts.unsqueeze(-1))
+    if model.training and ray_epilogue.ENABLED:
+        # the per-ray entries on demand; the loss terms straight from the composite rows
+        fused = dict(comp=comp, starts=starts, sdf=sdf, grad=grad, semantic=md, n_f2=F2, n_geo=G,
+                     num_scenes=B, background=tuple(float(v) for v in bg_color))
+        return ray_epilogue.RenderOutputs(out, fused, per_ray_outputs)
+    out.update(per_ray_outputs())
     if not model.training:
         out["sampled_points"] = o[:, None, :] + d[:, None, :] * starts[..., None]
     return out

@@ -479,7 +479,10 @@ class PonderIndoor(nn.Module):
 
     def render_loss(self, render_out, ray_dict):
         loss_dict = self.renderer.get_loss(render_out, ray_dict)
-        return sum(v for k, v in loss_dict.items() if "loss" in k), loss_dict
+        total = getattr(loss_dict, "total", None)   # (formed with the terms by the fused loss node)
+        if total is None:
+            total = sum(v for k, v in loss_dict.items() if "loss" in k)
+        return total, loss_dict
 
     def ppt_loss(self, data_dict):
         # two tall-skinny GEMMs over all voxels (96 -> 512 -> ~20 classes): the MFMA kernels of

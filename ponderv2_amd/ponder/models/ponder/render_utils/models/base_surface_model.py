@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ponderv2_amd import surface_loss
+from ponderv2_amd import ray_epilogue, surface_loss
 from ..builder import build_collider, build_field, build_sampler
 from ..renderers import DepthRenderer, NormalRenderer, RGBRenderer, SemanticRenderer
 
@@ -75,6 +75,10 @@ class SurfaceModel(nn.Module):
     def get_loss(self, preds_dict, targets):
         lw = self.loss.weights
         out = {}
+        if ray_epilogue.usable(preds_dict, targets, self.loss) and self.training:
+            # the fused head kept its composite rows: per-ray epilogue, semantic head and EVERY term in
+            # one autograd node (ponderv2_amd/ray_epilogue.py); ``.total`` is their sum
+            return ray_epilogue.ray_losses(preds_dict, targets, self.loss)
         depth_gt = targets["depth"]
         valid = depth_gt > 0.0
         if surface_loss.usable(preds_dict, targets) and lw.get("sparse_points_sdf_loss", 0.0) <= 0:
