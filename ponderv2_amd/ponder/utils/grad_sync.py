@@ -203,6 +203,8 @@ class FlatGradSync:
         return self._flat, self._views
 
     # ------------------------------------------------------------------ overlap with the backward
+    _post_reduce = None   # (test hook, see _reduce_slabs)
+
     def attach(self):
         """Register with the sparse executor (``overlap=True``): from now on its backward node reports
         the parameter-gradient arena and the per-slab events to ``_on_arena``."""
@@ -252,6 +254,13 @@ class FlatGradSync:
                             comm.wait_event(ev)
                     view = arena[lo:hi]
                     works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+                    if self._post_reduce is not None:
+                        # test hook (tests/test_gpu_grad_overlap.py): an in-place edit of the slab right
+                        # behind its reduction on the communication stream.  With ONE rank a reduction is
+                        # the identity, so a slab reduced BEFORE the side stream wrote its weight
+                        # gradients would go unnoticed; the edit would not - it would be overwritten.
+                        works[-1][0].wait()
+                        self._post_reduce(view)
         else:
             for lo, hi in slabs:
                 view = arena[lo:hi]
@@ -400,7 +409,15 @@ class FlatGradSync:
         flat, views = self._buffers()
         used = [i for i, p in enumerate(self.params) if p.grad is not None and i not in self._covered]
         if not self.uniform_usage:
-            flat.zero_()
+            # a silent rank contributes zeros: clear the slots of the parameters WITHOUT a gradient on this
+            # rank (they hold last step's averages) - one multi-tensor launch over exactly those slots.
+            # The used slots are overwritten below, or ARE the gradients (``alias_grads`` + in-place
+            # accumulation: clearing the whole buffer here wiped them); nothing else of the
+            # 160 MB buffer is touched.
+            used_set = set(used)
+            unused = [views[i] for i in range(len(self.params)) if i not in used_set and i not in self._covered]
+            if unused:
+                torch._foreach_zero_(unused)
         else:
             # the same slices are overwritten every step and the rest stay 0 - as long as the set of
             # parameters with gradients does not change.  When it does change on this rank, the

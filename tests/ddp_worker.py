@@ -96,9 +96,25 @@ def grad_sync_worker(rank, world, port, out_dir):
                 and all(p.grad is None for n, p in model.named_parameters() if n not in g_ddp)
                 and all(torch.allclose(dict(model.named_parameters())[n].grad, g_ddp[n], rtol=1e-5, atol=1e-7)
                         for n in sorted(g_ddp)[1:]))
+        # ... and with gradients KEPT IN PLACE between steps (zero_grad(set_to_none=False)): after the
+        # first sync ``.grad`` is a view of the flat buffer (alias_grads), the next backward accumulates
+        # into it, and the next sync must reduce THAT - not a buffer it has just cleared
+        inplace_ok = True
+        for uniform in (False, True):
+            local_backward()
+            reducer = FlatGradSync(model.parameters(), uniform_usage=uniform)
+            reducer.sync()
+            for step in range(2):
+                torch.manual_seed(7)
+                model.zero_grad(set_to_none=False)
+                model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})["loss"].backward()
+                reducer.sync()
+                inplace_ok = inplace_ok and all(
+                    torch.allclose(dict(model.named_parameters())[n].grad, g_ddp[n], rtol=1e-5, atol=1e-7)
+                    for n in g_ddp)
         torch.save(dict(rank=rank, worst=worst, loss=float(out["loss"]), n_grads=len(g_ddp),
                         worst_flat=worst_flat, unused_stay_none=unused_stay_none, skip_ok=skip_ok,
-                        n_params=len(names)),
+                        inplace_ok=inplace_ok, n_params=len(names)),
                    os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -29,6 +29,7 @@ def test_ddp_gradients_are_rank_means(tmp_path):
     # only one rank trains gets that rank's gradient / world on both
     assert all(r["worst_flat"] < 1e-5 for r in res), res
     assert all(r["unused_stay_none"] and r["skip_ok"] for r in res), res
+    assert all(r["inplace_ok"] for r in res), res   # gradients kept in place between steps (set_to_none=False)
     assert res[0]["n_params"] > res[0]["n_grads"]   # (the model does have unused parameters)
 
 

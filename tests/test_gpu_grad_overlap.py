@@ -61,6 +61,12 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
         try:
             first = step(sync)
             second = step(sync)
+            # ORDERING: double every slab on the communication stream right behind its
+            # reduction.  A slab reduced before the side stream has written its weight gradients (or the
+            # training stream its BatchNorm gradients) would end up holding the un-doubled local values.
+            sync._post_reduce = lambda view: view.mul_(2.0)
+            doubled = step(sync)
+            sync._post_reduce = None
         finally:
             sync.detach()
         assert sync._arena_layout is not None and len(sync._arena_layout[1]) >= 3
@@ -77,6 +83,18 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
             # them.  Not bitwise: the float atomics left on the path - scatter-mean, the sampler's volume
             # gradient - reorder between passes, see test_gpu_trainer.py)
             assert close(first[n], local[n]) and close(second[n], local[n]), n
+        names = {id(p): n for n, p in model.named_parameters()}
+        n_cov = 0
+        for i, p in enumerate(sync.params):
+            n = names[id(p)]
+            if n not in local:
+                continue
+            if i in sync._covered:
+                n_cov += 1
+                assert close(doubled[n], 2.0 * local[n]), ("slab reduced before its gradients were written", n)
+            else:
+                assert close(doubled[n], local[n]), n
+        assert n_cov > 40
         # the covered gradients are views of the executor's arena, reduced in place
         covered = [model_p for i, model_p in enumerate(sync.params) if i in sync._covered]
         assert len({p.grad.untyped_storage().data_ptr() for p in covered}) == 1
