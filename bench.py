@@ -881,7 +881,7 @@ def main():
         # behind the events its backward records - while the units below still run (PV2_GSYNC_OVERLAP=0:
         # the round-4 form, everything after backward)
         gsync = FlatGradSync(model.parameters(), uniform_usage=not ppt,
-                             overlap=os.environ.get("PV2_GSYNC_OVERLAP", "1") != "0").attach()
+                             overlap=os.environ.get("PV2_GSYNC_OVERLAP", "1") != "0" and not SKIP_SYNC).attach()
     elif dist_on:
         # find_unused_parameters: the ppt head is reported, never trained (quirk Q10), and the
         # multi-dataset model trains a different condition's BatchNorms per step.  static_graph

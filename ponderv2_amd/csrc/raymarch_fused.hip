@@ -36,7 +36,10 @@
 // Feature gathers use lane groups (32 lanes x float4 = 128 channels, 16 lanes x float4 = 64) on the
 // channels-last volume.  The coarse pass is one workgroup per ray: its S0 <= 128 samples are staged
 // in LDS, and the fixed-inv_s weights, the inverse-CDF samples and the sorted merge never leave it.
+#include <cstdlib>
+
 #include "common.h"
+#include "mfma_split.h"
 #include "raymarch_sampling.h"
 
 namespace {
@@ -946,6 +949,411 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(
                    starts_out, deltas_out, dbg_idx, dbg_sdf, dbg_w, tid, nthreads, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------
+// Rows mode, round 6: the main pass with its products TRANSPOSED, on the bf16 matrix cores, and every
+// activation in registers.
+//
+// field_fwd_kernel (above) runs one wave per workgroup behind 35 KB of LDS - one wave per SIMD - on the
+// fp32 MFMA with its weight rows fetched from L2 inside the product loop: 0.17 of that pipe.  Here a
+// product is D[out channel, sample] = W . X^T on v_mfma_f32_32x32x16_bf16 over three exact bf16 pieces
+// per operand (mfma_split.h: six MFMAs per 16 reduction steps, fp32 accuracy, 2.67 x the fp32 matrix
+// rate).  In that orientation a lane's accumulator registers hold 16 of a 32-channel block's outputs for
+// ONE sample (column i = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 h) - which is exactly what the B operand
+// of the next layer's product wants from that lane (eight reduction steps of column i), in a channel
+// order that only depends on h.  So a layer's output goes into the next product straight from the
+// accumulators: no LDS, no barrier, no transposes.  The weights are the A operand; they are cut into
+// bf16 pieces and laid out in that channel order ONCE per call by field_pack_kernel (a wave's fragment is
+// one contiguous 1 KB load from L2).  Everything per sample - features, Jacobian rows, the colour head,
+// the stores - is done by the two lanes (i, h = 0 / 1) that own the sample.
+// ------------------------------------------------------------------------------------------
+struct PackedT {
+  const uint4* p;   // [3 pieces][O / 32][K / 16][64 lanes] 16-byte fragments
+  int n_ob, n_ks;
+};
+// packed workspace (uint4 units): MW natural | W1[1:] acc-order | Mt acc-order | A_f2 [3][64] | A_geo [3][64]
+constexpr int kPkMW = 0;
+constexpr int kPkW1g = kPkMW + 3 * 8 * 4 * 64;
+constexpr int kPkMt = kPkW1g + 3 * 2 * 8 * 64;
+constexpr int kPkAf = kPkMt + 3 * 2 * 8 * 64;        // floats from here on: 3 x 64 + 3 x 64
+constexpr int kPkFwdEnd = kPkAf + (3 * 64 + 3 * 64) / 4;
+// backward: MW[:H] natural (out H, K F) | W1[1:]^T natural (out H, K G) | Mt acc-order | Wc1^T acc-order
+constexpr int kPkBM = kPkFwdEnd;
+constexpr int kPkBW1gt = kPkBM + 3 * 4 * 4 * 64;
+constexpr int kPkBMt = kPkBW1gt + 3 * 4 * 4 * 64;
+constexpr int kPkBWc1t = kPkBMt + 3 * 2 * 8 * 64;
+constexpr int kPkTotal = kPkBWc1t + 3 * 2 * 8 * 64;
+
+// reduction index held by element j of lane half h in step ks: the order of the features in memory, or
+// the order in which an accumulator block hands its rows over (see above)
+__device__ __forceinline__ int k_index(int ks, int h, int j, int acc_order) {
+  return acc_order ? 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * ks + 8 * h + j;
+}
+
+struct PackJob {
+  const float* W;
+  int ldw, n_ob, n_ks, acc_order, dst;
+};
+struct PackJobs {
+  PackJob j[8];
+  int n;
+  const float* A;    // colour head [3, kNA] (may be null)
+};
+
+__global__ __launch_bounds__(256) void field_pack_kernel(PackJobs jobs, uint4* __restrict__ out) {
+  const int job = blockIdx.y;
+  if (job == jobs.n) {   // the colour head's f' and geo columns as aligned rows
+    if (jobs.A == nullptr) return;
+    float* o = reinterpret_cast<float*>(out + kPkAf);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < 3 * 64; t += gridDim.x * 256) {
+      const int c = t / 64, k = t % 64;
+      o[t] = jobs.A[c * kNA + 3 + k];
+      o[3 * 64 + t] = jobs.A[c * kNA + 3 + kF2 + k];
+    }
+    return;
+  }
+  const PackJob J = jobs.j[job];
+  const int total = J.n_ob * J.n_ks * 64;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int lane = t & 63, ks = (t >> 6) % J.n_ks, ob = (t >> 6) / J.n_ks;
+    const int i = lane & 31, h = lane >> 5;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = J.W[(int64_t)(ob * 32 + i) * J.ldw + k_index(ks, h, j, J.acc_order)];
+    const pv2::Split8 sp = pv2::split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      out[J.dst + ((pc * J.n_ob + ob) * J.n_ks + ks) * 64 + lane] = __builtin_bit_cast(uint4, sp.p[pc]);
+  }
+}
+
+__device__ __forceinline__ pv2::bf16x8 wfrag(const PackedT& w, int pc, int ob, int ks, int lane) {
+  return __builtin_bit_cast(pv2::bf16x8, w.p[((pc * w.n_ob + ob) * w.n_ks + ks) * 64 + lane]);
+}
+
+// acc[ob] += W[ob0 + ob] . B for one 16-step slice: six bf16 MFMAs per output block
+template <int NOB>
+__device__ __forceinline__ void tstep(const PackedT& w, int ob0, int ks, const pv2::Split8& b,
+                                      pv2::f32x16 (&acc)[NOB], int lane) {
+  pv2::bf16x8 a[NOB][3];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) a[ob][pc] = wfrag(w, pc, ob0 + ob, ks, lane);
+#define PV2_TERM(ta, tb) \
+  _Pragma("unroll") for (int ob = 0; ob < NOB; ++ob) acc[ob] = pv2::mfma_bf16(a[ob][ta], b.p[tb], acc[ob]);
+  PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+}
+
+// the B operand of reduction slice `half` (0 / 1) of an accumulator block: eight of the lane's 16 rows
+__device__ __forceinline__ pv2::Split8 split_acc(const pv2::f32x16& a, int half) {
+  const int o = 8 * half;
+  return pv2::split8(make_float4(a[o], a[o + 1], a[o + 2], a[o + 3]), make_float4(a[o + 4], a[o + 5], a[o + 6], a[o + 7]));
+}
+
+template <int NB>
+__device__ __forceinline__ void zero_accv(pv2::f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+// channel of accumulator register r of block ob in lane half h
+__device__ __forceinline__ int acc_ch(int ob, int r, int h) { return ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// The 32 product steps of a tile in execution order - each: two 32-channel output blocks x 16 reduction
+// steps = 6 weight fragments, 12 MFMAs - and the ring of fragment registers that runs kAhead steps in
+// front of the matrix pipe (a step is ~400 cycles of MFMA work, a trip to L2 800+: with one wave per SIMD
+// nothing else hides it).
+//   steps  0 ..  7   h0 rows:   MW blocks (2 p, 2 p + 1),     p = step / 4, slice step % 4     B = f
+//   steps  8 .. 15   Wc1 f:     MW blocks (4 + 2 p, 5 + 2 p)                                    B = f
+//   steps 16 .. 23   q = M^T t: Mt blocks (0, 1), slice step - 16                               B = t
+//   steps 24 .. 31   geo:       W1[1:] blocks (0, 1), slice step - 24                           B = a1
+constexpr int kFwdSteps = 32;
+constexpr int kAhead = 3;
+struct FragSet {
+  pv2::bf16x8 a[2][3];
+};
+template <int S>
+__device__ __forceinline__ void load_fwd_step(FragSet& f, const uint4* __restrict__ packed, int lane) {
+  constexpr int mat = S >> 3, idx = S & 7;
+  constexpr int base = mat < 2 ? kPkMW : mat == 2 ? kPkMt : kPkW1g;
+  constexpr int n_ob = mat < 2 ? 8 : 2, n_ks = mat < 2 ? 4 : 8;
+  constexpr int ob0 = mat < 2 ? 4 * mat + 2 * (idx >> 2) : 0, ks = mat < 2 ? (idx & 3) : idx;
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      f.a[o][pc] = __builtin_bit_cast(pv2::bf16x8, packed[base + ((pc * n_ob + ob0 + o) * n_ks + ks) * 64 + lane]);
+}
+// step S: request the fragments of step S + kAhead, multiply with those of step S
+template <int S>
+__device__ __forceinline__ void fwd_step(FragSet (&ring)[kAhead + 1], const uint4* __restrict__ packed,
+                                         int lane, const pv2::Split8& b, pv2::f32x16 (&acc)[2]) {
+  if constexpr (S + kAhead < kFwdSteps) load_fwd_step<S + kAhead>(ring[(S + kAhead) % (kAhead + 1)], packed, lane);
+  const FragSet& f = ring[S % (kAhead + 1)];
+#define PV2_TERM(ta, tb)                                   \
+  acc[0] = pv2::mfma_bf16(f.a[0][ta], b.p[tb], acc[0]);    \
+  acc[1] = pv2::mfma_bf16(f.a[1][ta], b.p[tb], acc[1]);
+  PV2_SPLIT_TERMS(PV2_TERM)
+#undef PV2_TERM
+}
+
+__global__ __launch_bounds__(256) void field_fwd_rows_kernel(
+    Head P, const uint4* __restrict__ packed, const float* __restrict__ dirs,
+    const float* __restrict__ starts, const float* __restrict__ deltas, int64_t n_total, int S,
+    float* __restrict__ sdf_out, float* __restrict__ alpha_out, float* __restrict__ vals,
+    float* __restrict__ save_f, float* __restrict__ save_h0, float* __restrict__ save_a1,
+    float* __restrict__ save_q, const float* __restrict__ frows, const float* __restrict__ jrows) {
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t base = tile * 32;
+  if (base >= n_total) return;
+  const int64_t n = base + i;
+  const bool valid = n < n_total;
+  const int64_t nl = valid ? n : n_total - 1;   // (rows past the end read the last sample; nothing is stored)
+  const float* Af = reinterpret_cast<const float*>(packed + kPkAf);
+  const float* Ag = Af + 3 * 64;
+
+  FragSet ring[kAhead + 1];
+  load_fwd_step<0>(ring[0], packed, lane);
+  load_fwd_step<1>(ring[1], packed, lane);
+  load_fwd_step<2>(ring[2], packed, lane);
+  static_assert(kAhead == 3, "prologue loads steps 0 .. kAhead - 1");
+
+  // ---- features of the lane's sample: f (the B operand of the first two products, natural order)
+  pv2::Split8 fB[4];
+  {
+    const float* fr = frows + nl * kC + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float4 lo = ldg4(fr + 16 * ks), hi = ldg4(fr + 16 * ks + 4);
+      if (valid) {
+        *reinterpret_cast<float4*>(save_f + n * kF + 16 * ks + 8 * h) = lo;
+        *reinterpret_cast<float4*>(save_f + n * kF + 16 * ks + 8 * h + 4) = hi;
+      }
+      fB[ks] = pv2::split8(lo, hi);
+    }
+  }
+  pv2::f32x16 a1[4], tt[4];
+  // ---- h0 = M f + c0 -> a1 (partial) = softplus(h0), t = W1[0] softplus'(h0); two output blocks at a time
+#define PV2_H0_PAIR(PAIR)                                                                                   \
+  {                                                                                                         \
+    pv2::f32x16 acc[2];                                                                                     \
+    zero_accv(acc);                                                                                         \
+    fwd_step<4 * PAIR + 0>(ring, packed, lane, fB[0], acc);                                                 \
+    fwd_step<4 * PAIR + 1>(ring, packed, lane, fB[1], acc);                                                 \
+    fwd_step<4 * PAIR + 2>(ring, packed, lane, fB[2], acc);                                                 \
+    fwd_step<4 * PAIR + 3>(ring, packed, lane, fB[3], acc);                                                 \
+    _Pragma("unroll") for (int o = 0; o < 2; ++o) _Pragma("unroll") for (int g = 0; g < 4; ++g) {           \
+      const int ob = 2 * PAIR + o;                                                                          \
+      const int ch = ob * 32 + 8 * g + 4 * h;                                                               \
+      const float4 cb = ldg4(P.c0 + ch), v1 = ldg4(P.W1 + ch);                                              \
+      const float cbv[4] = {cb.x, cb.y, cb.z, cb.w}, v1v[4] = {v1.x, v1.y, v1.z, v1.w};                     \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                       \
+        const float h0 = acc[o][4 * g + q] + cbv[q];                                                        \
+        float sp, d1, d2;                                                                                   \
+        softplus_fast(h0, &sp, &d1, &d2);                                                                   \
+        acc[o][4 * g + q] = h0;                                                                             \
+        a1[ob][4 * g + q] = sp;                                                                             \
+        tt[ob][4 * g + q] = v1v[q] * d1;                                                                    \
+      }                                                                                                     \
+      if (valid)                                                                                            \
+        *reinterpret_cast<float4*>(save_h0 + n * kH + ch) =                                                 \
+            make_float4(acc[o][4 * g], acc[o][4 * g + 1], acc[o][4 * g + 2], acc[o][4 * g + 3]);           \
+    }                                                                                                       \
+  }
+  PV2_H0_PAIR(0)
+  PV2_H0_PAIR(1)
+#undef PV2_H0_PAIR
+  // ---- a1 += Wc1 f + bc1
+#define PV2_WC1_PAIR(PAIR)                                                                                  \
+  {                                                                                                         \
+    pv2::f32x16 acc[2];                                                                                     \
+    zero_accv(acc);                                                                                         \
+    fwd_step<8 + 4 * PAIR + 0>(ring, packed, lane, fB[0], acc);                                             \
+    fwd_step<8 + 4 * PAIR + 1>(ring, packed, lane, fB[1], acc);                                             \
+    fwd_step<8 + 4 * PAIR + 2>(ring, packed, lane, fB[2], acc);                                             \
+    fwd_step<8 + 4 * PAIR + 3>(ring, packed, lane, fB[3], acc);                                             \
+    _Pragma("unroll") for (int o = 0; o < 2; ++o) _Pragma("unroll") for (int g = 0; g < 4; ++g) {           \
+      const int ob = 2 * PAIR + o;                                                                          \
+      const int ch = ob * 32 + 8 * g + 4 * h;                                                               \
+      const float4 bb = ldg4(P.bc1 + ch);                                                                   \
+      a1[ob][4 * g] += acc[o][4 * g] + bb.x;                                                                \
+      a1[ob][4 * g + 1] += acc[o][4 * g + 1] + bb.y;                                                        \
+      a1[ob][4 * g + 2] += acc[o][4 * g + 2] + bb.z;                                                        \
+      a1[ob][4 * g + 3] += acc[o][4 * g + 3] + bb.w;                                                        \
+      if (valid)                                                                                            \
+        *reinterpret_cast<float4*>(save_a1 + n * kH + ch) =                                                 \
+            make_float4(a1[ob][4 * g], a1[ob][4 * g + 1], a1[ob][4 * g + 2], a1[ob][4 * g + 3]);           \
+    }                                                                                                       \
+  }
+  PV2_WC1_PAIR(0)
+  PV2_WC1_PAIR(1)
+#undef PV2_WC1_PAIR
+  // ---- q = M^T t + q0 (t straight from the accumulators), g = J^T q
+  float gx, gy, gz;
+  {
+    pv2::f32x16 q[2];
+    zero_accv(q);
+    // the sample's Jacobian rows, requested BEFORE the eight product steps that produce q (one wave per
+    // SIMD: a load issued where it is used is a round trip to L2 with the matrix pipe idle)
+    float4 jv[3][2][4];
+    {
+      const float* jr0 = jrows + nl * 3 * kF + 4 * h;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) jv[a][ob][g] = ldg4(jr0 + a * kF + ob * 32 + 8 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_step<16>(ring, packed, lane, split_acc(tt[0], 0), q);
+    fwd_step<17>(ring, packed, lane, split_acc(tt[0], 1), q);
+    fwd_step<18>(ring, packed, lane, split_acc(tt[1], 0), q);
+    fwd_step<19>(ring, packed, lane, split_acc(tt[1], 1), q);
+    fwd_step<20>(ring, packed, lane, split_acc(tt[2], 0), q);
+    fwd_step<21>(ring, packed, lane, split_acc(tt[2], 1), q);
+    fwd_step<22>(ring, packed, lane, split_acc(tt[3], 0), q);
+    fwd_step<23>(ring, packed, lane, split_acc(tt[3], 1), q);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = ob * 32 + 8 * g + 4 * h;
+        const float4 qb = ldg4(P.q0 + ch);
+        const float4 qv = make_float4(q[ob][4 * g] + qb.x, q[ob][4 * g + 1] + qb.y, q[ob][4 * g + 2] + qb.z,
+                                      q[ob][4 * g + 3] + qb.w);
+        if (valid) *reinterpret_cast<float4*>(save_q + n * kF + ch) = qv;
+        g0 += dot4(jv[0][ob][g], qv);
+        g1 += dot4(jv[1][ob][g], qv);
+        g2 += dot4(jv[2][ob][g], qv);
+      }
+    gx = g0 + __shfl_xor(g0, 32);
+    gy = g1 + __shfl_xor(g1, 32);
+    gz = g2 + __shfl_xor(g2, 32);
+  }
+  // ---- sdf = W1[0] . a1 + b1[0]
+  float sdf;
+  {
+    float p = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v1 = ldg4(P.W1 + ob * 32 + 8 * g + 4 * h);
+        p += a1[ob][4 * g] * v1.x + a1[ob][4 * g + 1] * v1.y + a1[ob][4 * g + 2] * v1.z + a1[ob][4 * g + 3] * v1.w;
+      }
+    sdf = p + __shfl_xor(p, 32) + P.b1[0];
+  }
+  // ---- geo = W1[1:] a1 + b1[1:]; the colour head's pre-activation y = A [g, f', geo, d] + b_rgb
+  float y[3] = {0.f, 0.f, 0.f};
+  {
+    pv2::f32x16 geo[2];
+    zero_accv(geo);
+    float4 f2v[8];   // f': this lane's half of the 64 channels, requested before the product steps
+    {
+      const float* f2 = frows + nl * kC + kF + 32 * h;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) f2v[m] = ldg4(f2 + 4 * m);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_step<24>(ring, packed, lane, split_acc(a1[0], 0), geo);
+    fwd_step<25>(ring, packed, lane, split_acc(a1[0], 1), geo);
+    fwd_step<26>(ring, packed, lane, split_acc(a1[1], 0), geo);
+    fwd_step<27>(ring, packed, lane, split_acc(a1[1], 1), geo);
+    fwd_step<28>(ring, packed, lane, split_acc(a1[2], 0), geo);
+    fwd_step<29>(ring, packed, lane, split_acc(a1[2], 1), geo);
+    fwd_step<30>(ring, packed, lane, split_acc(a1[3], 0), geo);
+    fwd_step<31>(ring, packed, lane, split_acc(a1[3], 1), geo);
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = ob * 32 + 8 * g + 4 * h;
+        const float* bp = P.b1 + 1 + ch;         // (b1 + 1: not 16-byte aligned - four dword loads)
+        const float4 gv = make_float4(geo[ob][4 * g] + bp[0], geo[ob][4 * g + 1] + bp[1], geo[ob][4 * g + 2] + bp[2],
+                                      geo[ob][4 * g + 3] + bp[3]);
+        if (valid) *reinterpret_cast<float4*>(vals + n * kNV + kF2 + ch) = gv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] += dot4(ldg4(Ag + c * 64 + ch), gv);
+      }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float4 fv = f2v[m];
+      if (valid) *reinterpret_cast<float4*>(vals + n * kNV + 32 * h + 4 * m) = fv;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) y[c] += dot4(ldg4(Af + c * 64 + 32 * h + 4 * m), fv);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] += __shfl_xor(y[c], 32);
+  }
+  // ---- per-sample scalars (one lane per sample)
+  if (h == 0 && valid) {
+    const int64_t ray = n / S;
+    const float d0 = dirs[ray * 3 + 0], d1 = dirs[ray * 3 + 1], d2 = dirs[ray * 3 + 2];
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* ar = P.A + c * kNA;
+      const float yy = y[c] + ar[0] * gx + ar[1] * gy + ar[2] * gz + ar[kNA - 3] * d0 + ar[kNA - 2] * d1 +
+                       ar[kNA - 1] * d2 + P.brgb[c];
+      rgb[c] = sigmoidf_(yy);
+    }
+    const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+    const float cosv = gx * d0 + gy * d1 + gz * d2;
+    const float half = fminf(cosv, 0.f) * deltas[n] * 0.5f;
+    const float inv_s = P.inv_s[0];
+    const float e1 = sigmoidf_((sdf - half) * inv_s), e2 = sigmoidf_((sdf + half) * inv_s);
+    float alpha = (e1 - e2 + 1e-5f) / (e1 + 1e-5f);
+    alpha = fminf(fmaxf(alpha, 0.f), 1.f);
+    sdf_out[n] = sdf;
+    alpha_out[n] = alpha;
+    float* v = vals + n * kNV + kF2 + kG;
+    *reinterpret_cast<float4*>(v) = make_float4(gx, gy, gz, gx / gn);
+    *reinterpret_cast<float4*>(v + 4) = make_float4(gy / gn, gz / gn, rgb[0], rgb[1]);
+    *reinterpret_cast<float4*>(v + 8) = make_float4(rgb[2], starts[n], 1.f, 0.f);
+  }
+}
+
+// The packed-weight workspace of a stream (allocated on first use; kPkTotal 16-byte fragments).
+inline int rows_workspace(hipStream_t s, uint4** out) {
+  struct Entry {
+    int dev;
+    hipStream_t s;
+    uint4* p;
+  };
+  static Entry table[64];
+  static int used = 0;
+  int dev = 0;
+  if (int e = pv2::hip_status(hipGetDevice(&dev))) return e;
+  for (int k = 0; k < used; ++k)
+    if (table[k].dev == dev && table[k].s == s) {
+      *out = table[k].p;
+      return PV2_OK;
+    }
+  if (used == 64) {
+    pv2::set_error("rows_workspace: more than 64 (device, stream) pairs");
+    return PV2_E_UNSUPPORTED;
+  }
+  uint4* p = nullptr;
+  if (int e = pv2::hip_status(hipMalloc(reinterpret_cast<void**>(&p), sizeof(uint4) * kPkTotal))) return e;
+  table[used++] = Entry{dev, s, p};
+  *out = p;
+  return PV2_OK;
+}
+
+inline bool rows_kernels_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("PV2_FIELD_ROWS_SPLIT");   // 0: the one-wave fp32-MFMA kernels (A / B)
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 inline uint32_t scramble_for(int64_t n) {
   if (n < 64 || n >= 0x7fffffffLL) return 0;
   for (uint32_t a : {7919u, 7907u, 7901u, 7883u})
@@ -1077,6 +1485,23 @@ int pv2_neus_field_forward_rows(const float* frows, const float* jrows, const fl
   PV2_REQUIRE((n_total + 31) / 32 < 0x7fffffffLL, "pv2_neus_field_forward_rows: too many samples");
   Vol v{nullptr, 1, 2, 2, 2, n_rays};   // no volume is read in this mode
   Head P{mw, c0, bc1, w1, b1, m_t, q0, a_rgb, b_rgb, inv_s, nullptr, nullptr};
+  if (rows_kernels_enabled()) {
+    hipStream_t s = (hipStream_t)stream;
+    uint4* packed = nullptr;
+    if (int e = rows_workspace(s, &packed)) return e;
+    PackJobs jobs{};
+    jobs.j[0] = PackJob{mw, kF, 8, 4, 0, kPkMW};
+    jobs.j[1] = PackJob{w1 + kH, kH, 2, 8, 1, kPkW1g};
+    jobs.j[2] = PackJob{m_t, kH, 2, 8, 1, kPkMt};
+    jobs.n = 3;
+    jobs.A = a_rgb;
+    hipLaunchKernelGGL(field_pack_kernel, dim3(8, jobs.n + 1), dim3(256), 0, s, jobs, packed);
+    const int64_t tiles = (n_total + 31) / 32;
+    hipLaunchKernelGGL(field_fwd_rows_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, P,
+                       (const uint4*)packed, dirs, starts, deltas, n_total, n_samples, sdf, alpha, values,
+                       save_f, save_h0, save_a1, save_q, frows, jrows);
+    return pv2::check_launch("neus_field_forward_rows");
+  }
   hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0,
                      (hipStream_t)stream, v, P, origins, dirs, starts, deltas, n_total, n_samples,
                      norm_pts, norm_div, sdf, alpha, values, save_f, save_h0, save_a1, save_q, frows,

@@ -204,6 +204,7 @@ class FlatGradSync:
 
     # ------------------------------------------------------------------ overlap with the backward
     _post_reduce = None   # (test hook, see _reduce_slabs)
+    _warned_accumulate = False
 
     def attach(self):
         """Register with the sparse executor (``overlap=True``): from now on its backward node reports
@@ -226,10 +227,21 @@ class FlatGradSync:
         if not (self.overlap and dist.is_available() and dist.is_initialized()):
             return False
         if self._inflight is not None or self._pending_first is not None:
-            # a second backward before sync(): gradient accumulation would add into an arena that is
-            # being reduced in place - not supported by the overlapped route
-            raise RuntimeError("FlatGradSync(overlap=True): call sync() after every backward() "
-                               "(gradient accumulation needs overlap=False)")
+            # a second backward before sync() (gradient accumulation, a model that runs the backbone
+            # twice, a skipped sync): its gradients must not land in an arena that is being reduced in
+            # place.  This backward takes the staged route (the executor keeps its own arena; sync()
+            # reduces those gradients through the flat buffer) - said once, not raised from inside an
+            # autograd node.
+            if not self._warned_accumulate:
+                self._warned_accumulate = True
+                import warnings
+
+                warnings.warn("FlatGradSync(overlap=True): a backward ran before the previous one was "
+                              "sync()ed; its gradients are reduced after the backward, not overlapped")
+            if self._inflight is not None:      # nothing may add into a slab that is still being reduced
+                for work, _ in self._inflight[1]:
+                    work.wait()
+            return False
         return all(id(t) in self._index_of and t.is_leaf and t.grad is None for t in tensors)
 
     def _reduce_slabs(self, arena, slabs, events=None):
