@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
 // Main pass, backward.  One wave per 32-sample tile.  Consumes d alpha (from the compositing
 // backward), the weights, the upstream gradient of the composited row per ray and of sdf / grad
 // per sample; produces d feature (for the volume scatter), gg (d loss / d grad sdf, total), the
-// operands of the weight-gradient GEMMs and the bias-like column sums (atomics into `sums`).
+// operands of the weight-gradient GEMMs and the bias-like column sums (one row of `tile_sums` per tile).
 // sums layout: c0[H] bc1[H] v1x[H] b1[1+G -> 68] qsum[F] brgb[4] inv_s[1]
 // ------------------------------------------------------------------------------------------
 constexpr int kSumC0 = 0, kSumBc1 = kH, kSumV1 = 2 * kH, kSumB1 = 3 * kH, kSumQ = 3 * kH + kGH,
@@ -456,7 +456,11 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
     const float* __restrict__ g_grad_up, const float* __restrict__ g_comp,
     float* __restrict__ gfeat, float* __restrict__ gvec, float* __restrict__ gz,
     float* __restrict__ tmat, float* __restrict__ gq, float* __restrict__ gh,
-    float* __restrict__ gy_out, float* __restrict__ sums, const float* __restrict__ jrows) {
+    float* __restrict__ gy_out, float* __restrict__ tile_sums, const float* __restrict__ jrows) {
+  // (round 6: the bias-like column sums of this tile go to ITS row of tile_sums - plain stores, added in
+  // tile order by sums_reduce_kernel: 4 224 tiles x ~520 float atomics on the same ~520 addresses were 220 of
+  // the kernel's 633 us, and made the sums depend on the order of arrival)
+  float* sums = tile_sums + (int64_t)blockIdx.x * kSumTotal;
   __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
   __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
   __shared__ float s_pt[32 * 4];
@@ -562,11 +566,14 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
       r4 += __shfl_xor(r4, o);
     }
     if (lane == 0) {
-      unsafeAtomicAdd(sums + kSumInvS, r0);
-      unsafeAtomicAdd(sums + kSumRgb + 0, r1);
-      unsafeAtomicAdd(sums + kSumRgb + 1, r2);
-      unsafeAtomicAdd(sums + kSumRgb + 2, r3);
-      unsafeAtomicAdd(sums + kSumB1, r4);
+      *(sums + kSumInvS) = r0;
+      *(sums + kSumRgb + 0) = r1;
+      *(sums + kSumRgb + 1) = r2;
+      *(sums + kSumRgb + 2) = r3;
+      *(sums + kSumB1) = r4;
+      sums[kSumB1 + 1 + kG] = sums[kSumB1 + 2 + kG] = sums[kSumB1 + 3 + kG] = 0.f;   // padding of the b1 block
+      sums[kSumRgb + 3] = 0.f;
+      sums[kSumInvS + 1] = sums[kSumInvS + 2] = sums[kSumInvS + 3] = 0.f;
     }
   }
   __syncthreads();
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
       bufA[s * kLd + lane] = ggeo;
       geo_sum += ggeo;
     }
-    unsafeAtomicAdd(sums + kSumB1 + 1 + lane, geo_sum);
+    *(sums + kSumB1 + 1 + lane) = geo_sum;
   }
 
   // ---- gq = J gg : 64-channel gather with the weights D_c = sum_a gg_a d_a w_c
@@ -647,10 +654,10 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
     qsum.z += __shfl_xor(qsum.z, 32);
     qsum.w += __shfl_xor(qsum.w, 32);
     if (sub == 0) {
-      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 0, qsum.x);
-      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 1, qsum.y);
-      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 2, qsum.z);
-      unsafeAtomicAdd(sums + kSumQ + 4 * cq + 3, qsum.w);
+      *(sums + kSumQ + 4 * cq + 0) = qsum.x;
+      *(sums + kSumQ + 4 * cq + 1) = qsum.y;
+      *(sums + kSumQ + 4 * cq + 2) = qsum.z;
+      *(sums + kSumQ + 4 * cq + 3) = qsum.w;
     }
   }
   __syncthreads();
@@ -691,9 +698,9 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
     s_bc1 += __shfl_xor(s_bc1, 32);
     s_v1 += __shfl_xor(s_v1, 32);
     if (h == 0) {
-      unsafeAtomicAdd(sums + kSumC0 + col, s_c0);
-      unsafeAtomicAdd(sums + kSumBc1 + col, s_bc1);
-      unsafeAtomicAdd(sums + kSumV1 + col, s_v1);
+      *(sums + kSumC0 + col) = s_c0;
+      *(sums + kSumBc1 + col) = s_bc1;
+      *(sums + kSumV1 + col) = s_v1;
     }
   }
   __syncthreads();
@@ -1354,6 +1361,81 @@ inline bool rows_kernels_enabled() {
   return v;
 }
 
+// out[blockIdx.y][c] = sum over the rows [blockIdx.y * rows_per_block, ...) of part[r][c], four interleaved
+// sub-sums added in a fixed order: the tile sums of field_bwd_kernel, in two launches (4 224 rows -> 66 -> 1)
+__global__ __launch_bounds__(256) void sums_reduce_kernel(const float* __restrict__ part, int64_t rows,
+                                                          int cols, int64_t rows_per_block,
+                                                          float* __restrict__ out) {
+  __shared__ float s_red[256];
+  const int tid = threadIdx.x, c = blockIdx.x * 64 + (tid & 63), q = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = rows < r0 + rows_per_block ? rows : r0 + rows_per_block;
+  float a = 0.f;
+  if (c < cols) {
+#pragma unroll 4
+    for (int64_t r = r0 + q; r < r1; r += 4) a += part[r * cols + c];
+  }
+  s_red[tid] = a;
+  __syncthreads();
+  if (q == 0 && c < cols)
+    out[(int64_t)blockIdx.y * cols + c] = ((s_red[tid] + s_red[tid + 64]) + s_red[tid + 128]) + s_red[tid + 192];
+}
+
+// Scratch of a stream for the tile sums: [tiles + ceil(tiles / 64)][kSumTotal] floats, grown on demand.
+inline int tile_sums_workspace(hipStream_t s, int64_t tiles, float** out) {
+  struct Entry {
+    int dev;
+    hipStream_t s;
+    float* p;
+    int64_t cap;
+  };
+  static Entry table[64];
+  static int used = 0;
+  int dev = 0;
+  if (int e = pv2::hip_status(hipGetDevice(&dev))) return e;
+  const int64_t need = (tiles + (tiles + 63) / 64) * kSumTotal;
+  Entry* hit = nullptr;
+  for (int k = 0; k < used; ++k)
+    if (table[k].dev == dev && table[k].s == s) hit = &table[k];
+  if (hit == nullptr) {
+    if (used == 64) {
+      pv2::set_error("tile_sums_workspace: more than 64 (device, stream) pairs");
+      return PV2_E_UNSUPPORTED;
+    }
+    table[used] = Entry{dev, s, nullptr, 0};
+    hit = &table[used++];
+  }
+  if (hit->cap < need) {
+    if (hit->p) {   // (kernels of this stream may still read the old buffer)
+      if (int e = pv2::hip_status(hipStreamSynchronize(s))) return e;
+      (void)hipFree(hit->p);
+      hit->p = nullptr;
+      hit->cap = 0;
+    }
+    if (int e = pv2::hip_status(hipMalloc(reinterpret_cast<void**>(&hit->p), sizeof(float) * need))) return e;
+    hit->cap = need;
+  }
+  *out = hit->p;
+  return PV2_OK;
+}
+
+// field_bwd_kernel over all tiles + the ordered reduction of its tile sums into sums[kSumTotal]
+template <typename Launch>
+inline int backward_with_sums(hipStream_t s, int64_t n_total, float* sums, Launch&& launch) {
+  const int64_t tiles = (n_total + 31) / 32;
+  float* ws = nullptr;
+  if (int e = tile_sums_workspace(s, tiles, &ws)) return e;
+  launch(ws);
+  const int64_t rpb = 64, groups = (tiles + rpb - 1) / rpb;
+  float* mid = ws + tiles * kSumTotal;
+  const dim3 cols((kSumTotal + 63) / 64);
+  hipLaunchKernelGGL(sums_reduce_kernel, dim3(cols.x, (unsigned)groups), dim3(256), 0, s, (const float*)ws,
+                     tiles, kSumTotal, rpb, mid);
+  hipLaunchKernelGGL(sums_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s, (const float*)mid, groups,
+                     kSumTotal, groups, sums);
+  return PV2_OK;
+}
+
 inline uint32_t scramble_for(int64_t n) {
   if (n < 64 || n >= 0x7fffffffLL) return 0;
   for (uint32_t a : {7919u, 7907u, 7901u, 7883u})
@@ -1528,12 +1610,13 @@ int pv2_neus_field_backward(const float* volume, int vol_b, int vol_z, int vol_y
   hipStream_t s = (hipStream_t)stream;
   Vol v{volume, vol_b, vol_z, vol_y, vol_x, n_rays / vol_b};
   Head P{mw, nullptr, nullptr, w1, nullptr, m_t, nullptr, a_rgb, nullptr, inv_s, w1g_t, wc1_t};
-  int st = pv2::zero_words(sums, kSumTotal, s);
+  int st = backward_with_sums(s, n_total, sums, [&](float* tile_sums) {
+    hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
+                       origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
+                       values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
+                       gq, gh, gy, tile_sums, (const float*)nullptr);
+  });
   if (st != PV2_OK) return st;
-  hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
-                     origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
-                     values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
-                     gq, gh, gy, sums, (const float*)nullptr);
   st = pv2::check_launch("neus_field_backward");
   if (st != PV2_OK || grad_volume == nullptr) return st;
   // grad_volume must be zero-initialised by the caller (it may already hold other contributions)
@@ -1562,12 +1645,13 @@ int pv2_neus_field_backward_rows(const float* jrows, const float* origins, const
   hipStream_t s = (hipStream_t)stream;
   Vol v{nullptr, 1, 2, 2, 2, n_rays};
   Head P{mw, nullptr, nullptr, w1, nullptr, m_t, nullptr, a_rgb, nullptr, inv_s, w1g_t, wc1_t};
-  int st = pv2::zero_words(sums, kSumTotal, s);
-  if (st != PV2_OK) return st;
-  hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
-                     origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
-                     values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
-                     gq, gh, gy, sums, jrows);
+  if (int st = backward_with_sums(s, n_total, sums, [&](float* tile_sums) {
+        hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)((n_total + 31) / 32)), dim3(64), 0, s, v, P,
+                           origins, dirs, starts, deltas, n_total, n_samples, norm_pts, norm_div, sdf,
+                           values, save_h0, weights, g_alpha, g_sdf, g_grad, g_comp, gfeat, gvec, gz, tmat,
+                           gq, gh, gy, tile_sums, jrows);
+      }))
+    return st;
   return pv2::check_launch("neus_field_backward_rows");
 }
 
