@@ -397,6 +397,7 @@ int pv2_spconv16_backward_weight(const void* in_feat, int64_t n_in, int c_in, co
 #define PV2_UNET_CONV_BN 0
 #define PV2_UNET_STEM 1
 #define PV2_UNET_CONCAT 2
+#define PV2_UNET_CONV_BN16 3   /* a conv + BatchNorm unit on 16-bit activations (dtype; sparse_conv16.hip) */
 typedef struct pv2_unet_op {
   int32_t kind, c_in, c_out, relu;
   int32_t K, kflip, dx_accumulate;
@@ -424,6 +425,24 @@ typedef struct pv2_unet_op {
   float* dweight;
   const float* weight_t;   /* STEM only, with dx: the weight as [c_in, K, c_out] (grad-input pass) */
   float eps, momentum;
+  /* The reduced-precision training mode (enable_amp, configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:12;
+   * csrc/sparse_conv16.hip): dtype = PV2_BF16 / PV2_F16 is the element type of x, residual, y_conv, out and
+   * of grad_out, dy, dres, dx for CONV_BN16 and CONCAT (widths then count 16-bit elements, multiples of 8),
+   * of out / residual / grad_out / dres only for the STEM (its conv stays fp32: the fp32 -> 16-bit edge is
+   * its BatchNorm).  Statistics, parameters and every parameter gradient stay fp32.  CONV_BN16 reads the
+   * packed weights of pv2_spconv16_pack_weights and walks gather tables: nbr / nbr_stride / perm / kflip
+   * over its output rows, the *_t set over its input rows (grad-input); tile_start16 / n_tiles16: chunks of
+   * 512 pairs (the weight gradient, which ADDS into dweight - the executor clears it first).  dx_tmp: scratch
+   * [n_in, c_in] for a grad-input that is added to an existing gradient (dx_accumulate). */
+  int32_t dtype, kflip_t;
+  int64_t nbr_t_stride, n_tiles16;
+  const void* packed_fwd;
+  const void* packed_bwd;
+  const int32_t* nbr_t;
+  const int32_t* perm;
+  const int32_t* perm_t;
+  const int32_t* tile_start16;
+  void* dx_tmp;
 } pv2_unet_op;
 int pv2_unet_forward(const pv2_unet_op* ops, int n_ops, float* prod_ws, float* stats_ws,
                      pv2_stream_t stream);

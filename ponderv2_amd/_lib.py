@@ -46,10 +46,13 @@ class UnetOp(Structure):
                                            "running_mean", "running_var", "y_conv", "mean_invstd",
                                            "out", "grad_out", "dy", "gsum", "dres", "dx", "dweight",
                                            "weight_t")]
-                + [("eps", c_float), ("momentum", c_float)])
+                + [("eps", c_float), ("momentum", c_float), ("dtype", c_int32), ("kflip_t", c_int32),
+                   ("nbr_t_stride", c_int64), ("n_tiles16", c_int64)]
+                + [(k, c_void_p) for k in ("packed_fwd", "packed_bwd", "nbr_t", "perm", "perm_t",
+                                           "tile_start16", "dx_tmp")])
 
 
-UNET_CONV_BN, UNET_STEM, UNET_CONCAT = 0, 1, 2
+UNET_CONV_BN, UNET_STEM, UNET_CONCAT, UNET_CONV_BN16 = 0, 1, 2, 3
 
 
 class PointsDesc(Structure):
@@ -59,7 +62,7 @@ class PointsDesc(Structure):
 _P = c_void_p  # every device pointer travels as void*
 
 # name -> (restype, argtypes); mirrors include/ponderv2_hip.h one to one.
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 SIGNATURES = {
     "pv2_abi_version": (c_int, []),

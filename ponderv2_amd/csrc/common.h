@@ -53,6 +53,7 @@ int spconv_wgrad(const float* in_feat, int64_t n_in, int c_in, const float* dout
                  const int32_t* kstart, const int32_t* tile_start, int tile_pairs, int64_t n_tiles,
                  float* dweight, float* part, hipStream_t s);
 // sparse_conv_pr.hip
+int fork_event_for(hipEvent_t* ev);   // a reusable event that orders a side stream behind the caller's
 // The conv + BatchNorm unit whose OUTPUT is the activation a grad-input launch completes the gradient of.
 struct BnProducer {
   const float* y_conv;

@@ -31,6 +31,6 @@ int pv2_zero_fill(void* ptr, int64_t nbytes, pv2_stream_t stream) {
   }
   return pv2::zero_words(ptr, nbytes / 4, (hipStream_t)stream);
 }
-int pv2_abi_version(void) { return 15; }  // 15: pv2_unet_op.dx_producer (BatchNorm backward sums in the grad-input row reduce of an activation's last consumer); 14: pv2_osm_plan / pv2_spconv_osm (mask-grouped output-stationary convs), pv2_conv_geom.osm_*; 13: mode argument of pv2_dconv3_pack_weights / _packed_floats (bf16-piece weights for mode 0); 12: pv2_cells_* (first projection level from the occupied cells), pv2_bn_*_padded; 11: out_mask_src of pv2_dconv3_forward, relu_mask_src of pv2_maxpool3d_cl_backward_add, pv2_voxelize_*, pv2_bn_statistics; 10: pv2_dconv3_* (dense 3x3x3 convolutions), pv2_trilinear_*_16 (half sampler); 9: pv2_narrow_* (narrow-decoder render head), pv2_unet_op.weight_t, pv2_small_inverse; 8: product-row convs (pv2_spconv_products / _reduce_rows / pv2_convbn_*), deterministic weight gradient; 7: folded final convolution (pv2_neus_fold_*); 5: output-stationary convs, pv2_spconv_forward_wt (4: pv2_bn_* workspace)
+int pv2_abi_version(void) { return 16; }  // 16: PV2_UNET_CONV_BN16 (16-bit units in the native U-Net executor), pv2_ray_* / pv2_semantic_ce_* (per-ray epilogue + loss node); 15: pv2_unet_op.dx_producer (BatchNorm backward sums in the grad-input row reduce of an activation's last consumer); 14: pv2_osm_plan / pv2_spconv_osm (mask-grouped output-stationary convs), pv2_conv_geom.osm_*; 13: mode argument of pv2_dconv3_pack_weights / _packed_floats (bf16-piece weights for mode 0); 12: pv2_cells_* (first projection level from the occupied cells), pv2_bn_*_padded; 11: out_mask_src of pv2_dconv3_forward, relu_mask_src of pv2_maxpool3d_cl_backward_add, pv2_voxelize_*, pv2_bn_statistics; 10: pv2_dconv3_* (dense 3x3x3 convolutions), pv2_trilinear_*_16 (half sampler); 9: pv2_narrow_* (narrow-decoder render head), pv2_unet_op.weight_t, pv2_small_inverse; 8: product-row convs (pv2_spconv_products / _reduce_rows / pv2_convbn_*), deterministic weight gradient; 7: folded final convolution (pv2_neus_fold_*); 5: output-stationary convs, pv2_spconv_forward_wt (4: pv2_bn_* workspace)
 const char* pv2_last_error(void) { return pv2::g_error; }
 }

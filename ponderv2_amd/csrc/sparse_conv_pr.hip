@@ -382,6 +382,12 @@ hipEvent_t fork_event() {
 
 namespace pv2 {
 
+// an event of the fork ring for other translation units (spunet_exec.hip's 16-bit units)
+int fork_event_for(hipEvent_t* ev) {
+  *ev = fork_event();
+  return *ev ? PV2_OK : PV2_E_WORKSPACE;
+}
+
 // Backward of one conv + BatchNorm unit (the body of pv2_convbn_backward).  dx_accumulate: the
 // grad-input is ADDED to what dx already holds (another consumer of the same activation wrote its
 // gradient first) - the row-reduce kernel takes dx as its addend, element for element in place.

@@ -13,8 +13,14 @@ BatchNorm affine pair, its output the backbone's output features.
 Same kernels, same order, same numbers as the per-unit path (convbn.py) up to the order in which the
 gradients of an activation with several consumers are added - here inside the grad-input row reduce
 (its addend), there by autograd's add kernels.  Anything the plan cannot express takes the modular
-path: eval mode, 16-bit activations, units the product-row path does not cover (channel counts that
-are no multiples of 32), inputs that need a gradient.
+path: eval mode, units the product-row path does not cover (channel counts that are no multiples of 32).
+
+Round 6: the reduced-precision training mode (the reference's ``enable_amp = True``,
+configs/scannet/pretrain-ponder-spunet-v1m1-0-base.py:12; precision.py) runs through the same executor:
+under ``precision.sparse_dtype()`` every unit behind the stem is a ``UNET_CONV_BN16`` record - the 16-bit
+output-stationary conv of csrc/sparse_conv16.hip on packed weights, the mixed-type BatchNorm, 16-bit
+activation and gradient arenas; statistics, master weights and every parameter gradient stay fp32.  The
+module-by-module walk of that mode was HOST-bound (18.4 - 21.2 ms per step at bs = 2, slower than fp32).
 """
 import ctypes
 import os
@@ -24,9 +30,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, kernels as K, precision, rownorm, sidestream
-from ._lib import UNET_CONCAT, UNET_CONV_BN, UNET_STEM, UnetOp
+from ._lib import UNET_CONCAT, UNET_CONV_BN, UNET_CONV_BN16, UNET_STEM, UnetOp
 
 ENABLED = os.environ.get("PV2_NATIVE_UNET", "1") != "0"
+NATIVE16 = os.environ.get("PV2_NATIVE_UNET16", "1") != "0"   # 0: the 16-bit mode walks the modules (A / B)
 # A gradient reducer that wants the parameter-gradient arena from INSIDE the backward node
 # (ponder/utils/grad_sync.py FlatGradSync(overlap=True).attach()): an object with ``wants(tensors)``,
 # ``slab_elems`` and ``_on_arena(arena, members, slabs, events)``.
@@ -94,6 +101,8 @@ class Plan:
         self.fwd = _Arena()
         self.act_off = []
         self.ops = None
+        self.dtype = None     # torch.bfloat16 / torch.float16: the 16-bit mode (None: fp32)
+        self.keep = []        # tensors the ops point into (packed weights)
 
     def act(self, rows, channels):
         self.acts.append((rows, channels))
@@ -122,15 +131,29 @@ def _plannable_conv(conv, bn, rb):
             and bn.momentum is not None and type(bn) is nn.BatchNorm1d)
 
 
-def build_plan(model, x, condition=None, context=None):
+def _plannable_conv16(conv, bn, rb):
+    """What kernels.spconv16_supported asks of a 16-bit conv, and a trainable plain BatchNorm1d behind it."""
+    return (conv.bias is None and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
+            and rb.nbr is not None and rb._transposed_os is not None and rb.n_out > 1 and rb.n_in > 0
+            and bn.training and bn.momentum is not None and type(bn) is nn.BatchNorm1d)
+
+
+def _is_conv(u):
+    return u.kind in (UNET_CONV_BN, UNET_CONV_BN16)
+
+
+def build_plan(model, x, condition=None, context=None, dtype=None):
     """Plan of ``model`` (SpUNet-v1m1 / -v1m3 layout) on the sparse tensor ``x`` whose
-    ``indice_dict`` holds the prebuilt geometry; None when a unit is outside what the executor covers."""
+    ``indice_dict`` holds the prebuilt geometry; None when a unit is outside what the executor covers.
+    ``dtype``: torch.bfloat16 / torch.float16 - the units behind the stem on 16-bit activations."""
     from .spconv import pytorch as spconv
 
     geo = x.indice_dict
     if not geo or "stem" not in geo:
         return None
     plan = Plan()
+    plan.dtype = dtype
+    conv_kind = UNET_CONV_BN if dtype is None else UNET_CONV_BN16
     n0 = x.indices.shape[0]
     level_rows = [n0] + [geo[f"spconv{l}"]["rulebook"].n_out for l in range(1, model.num_stages + 1)]
     level_idx = [x.indices] + [geo[f"spconv{l}"]["out_indices"] for l in range(1, model.num_stages + 1)]
@@ -141,7 +164,8 @@ def build_plan(model, x, condition=None, context=None):
             pointwise[level] = K.build_subm_rulebook(level_idx[level], 1)
         return pointwise[level]
 
-    def add_unit(conv, norm, rb, src, res=None, relu=True, kind=UNET_CONV_BN, c_in=None):
+    def add_unit(conv, norm, rb, src, res=None, relu=True, kind=None, c_in=None):
+        kind = conv_kind if kind is None else kind
         resolved = _bn_and_affine(norm, condition, context)
         if resolved is None:
             return None
@@ -152,6 +176,8 @@ def build_plan(model, x, condition=None, context=None):
         u.c_out, u.K = conv.out_channels, rb.K
         u.n_in, u.n_out = rb.n_in, rb.n_out
         if kind == UNET_CONV_BN and not _plannable_conv(conv, bn, rb):
+            return None
+        if kind == UNET_CONV_BN16 and not _plannable_conv16(conv, bn, rb):
             return None
         if kind == UNET_STEM and not (bn.training and bn.momentum is not None and type(bn) is nn.BatchNorm1d):
             return None
@@ -246,7 +272,7 @@ def build_plan(model, x, condition=None, context=None):
             if u.res in seen:
                 return None
             seen.add(u.res)
-        if u.kind == UNET_CONV_BN:
+        if _is_conv(u):
             u.acc_dx = u.src in seen
             seen.add(u.src)
     # The LAST gradient an activation receives in backward order comes from its first consumer in forward
@@ -269,7 +295,7 @@ def build_plan(model, x, condition=None, context=None):
 def supported(model, x) -> bool:
     return (ENABLED and K.USE_PR == "all" and K.USE_CONVBN and x.features.is_cuda and model.training
             and not getattr(model, "cls_mode", False) and x.features.dtype == torch.float32
-            and precision.sparse_dtype() is None
+            and (precision.sparse_dtype() is None or NATIVE16)
             and x.indices.shape[0] > 1 and torch.is_grad_enabled())
 
 
@@ -278,7 +304,7 @@ def run(model, x, condition=None, context=None):
     cover this model / input (the caller then walks the modules)."""
     if not supported(model, x):
         return None
-    plan = build_plan(model, x, condition, context)
+    plan = build_plan(model, x, condition, context, dtype=precision.sparse_dtype())
     if plan is None:
         return None
     feats = x.features
@@ -301,18 +327,28 @@ def run(model, x, condition=None, context=None):
             rownorm._bump_batches_tracked(u.bn)
     global CALLS
     CALLS += 1
+    # (in the 16-bit mode the result is 16-bit, as on the modular walk: its consumers widen it)
     return SpUNetFunction.apply(feats.contiguous(), plan, *tensors)
+
+
+def _floats(plan, rows, ch, half):
+    """Arena floats of a [rows, ch] matrix: fp32, or 16-bit elements when ``half`` in the 16-bit mode."""
+    n = rows * ch
+    return (n + 1) // 2 if (half and plan.dtype is not None) else n
 
 
 def _fill_forward(plan, feats, tensors):
     dev = feats.device
     arena = plan.fwd
+    half = plan.dtype is not None
+    code = K.DTYPE_CODE[plan.dtype] if half else 0
     plan.act_off = [None] * len(plan.acts)
     for u in plan.units:
         if u.kind != UNET_CONCAT:
-            u.y_off = arena.reserve(u.n_out * u.c_out)
+            # (the stem's conv output stays fp32; everything else is in the plan's element type)
+            u.y_off = arena.reserve(_floats(plan, u.n_out, u.c_out, u.kind != UNET_STEM))
             u.mi_off = arena.reserve(2 * u.c_out)
-        plan.act_off[u.dst] = arena.reserve(plan.acts[u.dst][0] * plan.acts[u.dst][1])
+        plan.act_off[u.dst] = arena.reserve(_floats(plan, plan.acts[u.dst][0], plan.acts[u.dst][1], True))
     arena.allocate(dev)
     ops = (UnetOp * len(plan.units))()
     act_ptr = [None if off is None else arena.ptr(off) for off in plan.act_off]
@@ -321,6 +357,7 @@ def _fill_forward(plan, feats, tensors):
     for op, u in zip(ops, plan.units):
         op.kind, op.c_in, op.c_out, op.relu = u.kind, u.c_in, u.c_out, int(bool(u.relu))
         op.n_in, op.n_out = u.n_in, u.n_out
+        op.dtype = code
         op.x = act_ptr[u.src]
         op.residual = act_ptr[u.res] if u.res is not None else None
         op.out = act_ptr[u.dst]
@@ -345,6 +382,22 @@ def _fill_forward(plan, feats, tensors):
             n_tiles_w = u.geom.n_tiles_w
             max_prod = max(max_prod, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
                 u.c_in, u.c_out, n_tiles_w)))
+        elif u.kind == UNET_CONV_BN16:
+            # packed 16-bit copies of the fp32 master weight, once per optimiser step (cached on the conv
+            # module, shared with the modular walk: kernels.packed_weights)
+            cache = u.conv.__dict__.setdefault("_pv2_packed", {})
+            fwd, bwd = K.packed_weights(w.detach().reshape(u.c_out, u.rb.K, u.c_in), plan.dtype, cache)
+            plan.keep += [fwd, bwd]
+            op.packed_fwd, op.packed_bwd = fwd.data_ptr(), bwd.data_ptr()
+            rb = u.rb
+            op.nbr, op.nbr_stride, op.kflip = rb.nbr.data_ptr(), rb.nbr_stride, rb.kflip
+            op.perm = rb.perm.data_ptr() if rb.perm is not None else None
+            nbr_t, stride_t, perm_t, kflip_t = rb._transposed_os
+            op.nbr_t, op.nbr_t_stride, op.kflip_t = nbr_t.data_ptr(), stride_t, kflip_t
+            op.perm_t = perm_t.data_ptr() if perm_t is not None else None
+            ts16, n16, _ = rb.tiles(_lib.WGRAD_TILE)
+            op.tile_start16, op.n_tiles16 = ts16.data_ptr(), n16
+            op.dx_accumulate = int(u.acc_dx)
         else:
             op.dx_accumulate = int(u.acc_dx)
             op.dx_producer = u.dx_producer
@@ -360,7 +413,7 @@ def _gradient_slabs(plan, tensors, hook, parena):
     [(lo, hi)], [unit index whose completion finishes the slab]) - or None when the reducer does not want
     this plan.  The stem (unit 0; its weight travels zero-padded, so its gradient is not a parameter's
     ``.grad``) stays outside the slabs."""
-    convs = [(i, u) for i, u in enumerate(plan.units) if u.kind == UNET_CONV_BN]
+    convs = [(i, u) for i, u in enumerate(plan.units) if _is_conv(u)]
     if len(convs) < 2:
         return None
     wanted = []
@@ -409,7 +462,10 @@ class SpUNetFunction(torch.autograd.Function):
         ctx.feats = feats
         ctx.save_for_backward(*tensors)
         rows, ch = plan.acts[plan.out_act]
-        return plan.fwd.view(plan.act_off[plan.out_act], rows, ch)
+        if plan.dtype is None:
+            return plan.fwd.view(plan.act_off[plan.out_act], rows, ch)
+        off = plan.act_off[plan.out_act]
+        return plan.fwd.tensor[off:off + (rows * ch + 1) // 2].view(plan.dtype)[:rows * ch].view(rows, ch)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -420,19 +476,26 @@ class SpUNetFunction(torch.autograd.Function):
         arena = _Arena()
         g_off = [None] * len(plan.acts)
         want_dx = ctx.needs_input_grad[0]   # (a learnable mask token was written into the input features)
+        half = plan.dtype is not None
+        if half:
+            assert grad_out.dtype == plan.dtype, (grad_out.dtype, plan.dtype)
         for a, (rows, ch) in enumerate(plan.acts):
             if (a != 0 or want_dx) and a != plan.out_act:
-                g_off[a] = arena.reserve(rows * ch)
+                g_off[a] = arena.reserve(_floats(plan, rows, ch, a != 0))
         # parameter gradients live in their OWN (small) arena: ``AccumulateGrad`` keeps the returned
         # views as ``param.grad`` until the next ``zero_grad`` - carved from the activation-gradient
         # arena they would pin its ~GB through the following forward
         parena = _Arena()
+        tmp_floats = 0
         for u in plan.units:
             if u.kind == UNET_CONCAT:
                 continue
-            u.dy_off = arena.reserve(u.n_out * u.c_out)
+            u.dy_off = arena.reserve(_floats(plan, u.n_out, u.c_out, u.kind != UNET_STEM))
             u.gsum_off = parena.reserve(2 * u.c_out)
             u.dw_off = parena.reserve(u.c_out * u.rb.K * u.c_in)
+            if u.kind == UNET_CONV_BN16 and u.acc_dx:
+                tmp_floats = max(tmp_floats, _floats(plan, u.n_in, u.c_in, True))
+        tmp_off = arena.reserve(tmp_floats) if tmp_floats else None
         arena.allocate(dev)
         parena.allocate(dev)
         g_ptr = [None if off is None else arena.ptr(off) for off in g_off]
@@ -449,11 +512,13 @@ class SpUNetFunction(torch.autograd.Function):
             if u.kind == UNET_CONV_BN:
                 part_floats = max(part_floats, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
                     u.c_in, u.c_out, u.geom.n_tiles_w)))
+            elif u.kind == UNET_CONV_BN16:
+                op.dx_tmp = arena.ptr(tmp_off) if (u.acc_dx and tmp_off is not None) else None
             elif want_dx:   # the stem's grad-input pass reads the weight as [c_in, K, c_out]
                 w_t = tensors[u.w_index].detach().permute(2, 1, 0).contiguous()
                 op.weight_t = w_t.data_ptr()
         # weight gradients on the backward side stream when every one of them is only stored
-        weights = [tensors[u.w_index] for u in plan.units if u.kind == UNET_CONV_BN]
+        weights = [tensors[u.w_index] for u in plan.units if _is_conv(u)]
         side = None
         if sidestream.active(grad_out) and all(sidestream.safe_leaf(w) for w in weights):
             # (the plan too: its rulebooks own the pair lists / tile prefixes the side stream's kernels

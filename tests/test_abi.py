@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in the header but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert handle.pv2_abi_version() == _lib.ABI_VERSION == 15
+    assert handle.pv2_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_ops_reject_cpu_tensors():

@@ -234,3 +234,51 @@ def test_spunet_16bit_mode_tracks_fp32(device, monkeypatch):
     # gradient direction in proportion to the rounding step: fp16 (11 bits) must sit close to the
     # fp32 gradient, bf16 (8 bits) further out but still pointing the same way.
     assert medians[torch.float16] > 0.97 and medians[torch.bfloat16] > 0.8
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_native_executor_runs_the_16bit_mode(device, dtype):
+    """Round 6: under ``precision.sparse_activations`` the whole sparse U-Net is ONE
+    native call per direction (``UNET_CONV_BN16`` records, csrc/spunet_exec.hip) - the same kernels in
+    the same order as the module-by-module walk: forward bits identical, parameter gradients equal up to
+    the order in which 16-bit gradients of an activation with several consumers are added and the float
+    atomics of the 16-bit weight gradient."""
+    from golden_cases import FULL_BACKBONE
+    from ponderv2_amd import precision, spunet_native
+    from ponderv2_amd.ponder.models import build_model
+
+    torch.manual_seed(0)
+    cfg = dict(FULL_BACKBONE)
+    model = build_model(cfg).to(device).train()
+    coords = random_voxels(11, batch=2, n_per_batch=6000)
+    grid = torch.from_numpy(coords[:, 1:]).to(device)
+    counts = np.bincount(coords[:, 0], minlength=2)
+    data = dict(grid_coord=grid, feat=torch.randn(len(coords), cfg["in_channels"], device=device),
+                offset=torch.from_numpy(np.cumsum(counts)).to(device))
+    probe = None
+    res = {}
+    for native in (True, False):
+        spunet_native.NATIVE16 = native
+        try:
+            model.zero_grad()
+            calls = spunet_native.CALLS
+            with precision.sparse_activations(dtype):
+                out = model(dict(data))
+            assert (spunet_native.CALLS > calls) == native
+            assert out.dtype == dtype
+            if probe is None:
+                probe = torch.randn(out.shape, device=device)
+            (out.float() * probe).sum().backward()
+            res[native] = (out.detach().clone(),
+                           {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            spunet_native.NATIVE16 = True
+    assert torch.equal(res[True][0], res[False][0])        # same kernels, same order: same bits
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 100
+    worst = 1.0
+    for k, g in res[True][1].items():
+        h = res[False][1][k]
+        assert torch.isfinite(g).all(), k
+        if g.numel() > 64 and h.abs().max() > 0:
+            worst = min(worst, torch.nn.functional.cosine_similarity(g.flatten(), h.flatten(), dim=0).item())
+    assert worst > 0.99, worst
