@@ -282,3 +282,52 @@ def test_native_executor_runs_the_16bit_mode(device, dtype):
         if g.numel() > 64 and h.abs().max() > 0:
             worst = min(worst, torch.nn.functional.cosine_similarity(g.flatten(), h.flatten(), dim=0).item())
     assert worst > 0.99, worst
+
+
+def test_fp16_gradscaler_step_through_an_overflow(device):
+    """The reference's training step (ponder/engines/train.py:183-196: autocast + GradScaler) in fp16
+    THROUGH a real overflow: with a loss scale that pushes the backbone's 16-bit
+    gradients past fp16's range the native 16-bit executor must hand the scaler non-finite parameter
+    gradients (Inf or NaN - an isfinite check cannot tell, csrc/mfma_split.h), the scaler skips the step
+    and halves the scale, parameters stay untouched; once the scale fits, steps are taken and every
+    parameter stays finite."""
+    import golden_cases as gc
+    import ddp_worker
+    from ponderv2_amd import spunet_native
+    from ponderv2_amd.ponder.datasets import collate_fn
+    from ponderv2_amd.ponder.models import build_model
+    from ponderv2_amd.ponder.utils.config import ConfigDict
+
+    torch.manual_seed(5)
+    cfg = gc.indoor_model_cfg(dict(gc.SMALL_BACKBONE, base_channels=32, channels=(32, 32, 64, 64, 64, 64, 32, 96)),
+                              grid_shape=(32, 32, 8), ray_nsample=6)
+    model = build_model(ConfigDict(cfg)).to(device).train()
+    batch = collate_fn([ddp_worker.tiny_scene(60), ddp_worker.tiny_scene(61)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 30, growth_interval=1000)
+    backbone = [p for n, p in model.named_parameters() if n.startswith("backbone.") and p.requires_grad]
+    skipped = taken = 0
+    for step in range(40):
+        before = [p.detach().clone() for p in backbone[:8]]
+        opt.zero_grad(set_to_none=True)
+        calls = spunet_native.CALLS
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        assert spunet_native.CALLS == calls + 1       # the 16-bit units ran in the native executor
+        scale = scaler.get_scale()
+        scaler.scale(out["loss"]).backward()
+        scaler.step(opt)
+        scaler.update()
+        moved = any(not torch.equal(a, p.detach()) for a, p in zip(before, backbone[:8]))
+        if scaler.get_scale() < scale:                # an overflow: the step was skipped
+            skipped += 1
+            assert not moved
+            assert taken == 0                         # (overflows come first, while the scale is too large)
+        else:
+            taken += 1
+            assert moved
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+        if taken >= 3:
+            break
+    assert skipped >= 1 and taken >= 3, (skipped, taken, scaler.get_scale())
