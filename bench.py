@@ -28,9 +28,12 @@ os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_cache", 
 os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(ROOT, "miopen_cache", "cache"))
 
 if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1 or os.environ.get("PV2_BENCH_FORCE_DIST") == "1":
-    # six streams over ROCclr's four default hardware queues serialise once a process group is in the
-    # process: 22.5 - 23.2 ms per step against 19.9 with two queues (ponderv2_amd/__init__.py, profiles/
-    # r05_hw_queues.txt); read at HIP initialisation, hence up here
+    # With an RCCL communicator in the process ROCclr's default of four hardware queues costs the step
+    # +1.6 ms even when NO reduction is issued, +2.9 ms with one (one rank, MI355X; 21.6 against 18.7 ms);
+    # three or two queues: +0.4 ms.  Round 6 measured that it is NOT the number of this program's streams
+    # (four instead of six changed nothing, profiles/r06_one_rank_pg.txt), so the launchers keep round 5's
+    # setting for ranks of a process group; the library no longer sets it on import.  Read at HIP
+    # initialisation, hence up here; an explicit value in the environment wins.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import torch  # noqa: E402

@@ -9,11 +9,12 @@ All device arithmetic goes through libponderv2_hip.so (include/ponderv2_hip.h).
 """
 import os as _os
 
-# The dense UNet3D projection runs on MIOpen.  On gfx950 MIOpen's immediate-mode heuristics pick a
-# pathological fp32 3-D weight-gradient solver (553 ms per step); the solver search fixes that
-# (9 ms) but costs ~100 s on every fresh process.  The search results for the shapes of the
-# ScanNet configuration ship in miopen_cache/ (MIOpen user find-db + kernel cache for this
-# GPU / MIOpen build) and are picked up in immediate mode.
+# The dense UNet3D projection runs on the hand-written kernels of csrc/dense_conv.hip (round 4); the library
+# convolutions are only its FALLBACK (evaluation mode, other layer orders, host tensors).  For that
+# fallback: on gfx950 MIOpen's immediate-mode heuristics pick a pathological fp32 3-D weight-gradient
+# solver (553 ms per step); the solver search fixes that (9 ms) but costs ~100 s on every fresh process,
+# so the search results for the shapes of the ScanNet configuration ship in miopen_cache/ (MIOpen user
+# find-db + kernel cache for this GPU / MIOpen build) and are picked up in immediate mode.
 _ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 _os.environ.setdefault("MIOPEN_USER_DB_PATH", _os.path.join(_ROOT, "miopen_cache", "db"))
 _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(_ROOT, "miopen_cache", "cache"))
@@ -21,18 +22,19 @@ _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(_ROOT, "miopen_c
 
 
 def limit_hardware_queues_for_process_group():
-    """With an RCCL process group in the process the step runs on six HIP streams (training, input,
-    geometry, weight-gradient side stream, communication stream, RCCL's own) over ROCclr's default of FOUR
-    hardware queues - and the streams that share a queue serialise: measured with one rank on MI355X
-    (profiles/r05_hw_queues.txt) 22.5 - 23.2 ms per step at the default, 44 ms at 6 or 8 queues, 20.1 at 3,
-    **19.9 at 2** (without a process group: 19.3 at the default, 19.4 at 2).  ``GPU_MAX_HW_QUEUES`` is read
-    when the HIP runtime initialises, so this must run before the first device call; an explicit setting
-    in the environment wins."""
+    """``GPU_MAX_HW_QUEUES=2`` - for the LAUNCHER of a multi-rank job to call (or set) before the ranks'
+    HIP runtimes initialise; ``bench.py`` and ``engines/launch.py`` do.  The library itself no longer
+    touches the process environment on import; ``PV2_LIMIT_HW_QUEUES=1`` asks for it.
+    Why two: with an RCCL communicator in the process the default of four hardware queues costs the step
+    +1.6 ms with no reduction issued at all and +2.9 ms with one; two or three queues +0.4 ms; without a
+    communicator the count does not matter (profiles/r06_one_rank_pg.txt, profiles/r05_hw_queues.txt).
+    Round 6 also brought this program from six HIP streams per rank to four (geometry built on the input
+    stream, slab reductions stream-ordered on one communication stream): no change at four queues - the
+    interaction is between RCCL and the queues, not the stream count."""
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 
-# ranks started by a launcher (torch.distributed.run, the driver's multi-GPU bench line) carry WORLD_SIZE
-if int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1 or _os.environ.get("PV2_BENCH_FORCE_DIST") == "1":
+if _os.environ.get("PV2_LIMIT_HW_QUEUES") == "1":
     limit_hardware_queues_for_process_group()
 
 __version__ = "0.1.0"

@@ -577,6 +577,16 @@ def _record_stream(obj, stream, _seen=None):
 _GEOMETRY_STREAMS = {}
 
 
+GEOMETRY_ON_INPUT_STREAM = os.environ.get("PV2_GEOMETRY_ON_INPUT", "1") != "0"
+
+
+def _is_input_stream(dev, stream) -> bool:
+    from .ponder.datasets import voxelize
+
+    s = voxelize._INPUT_STREAMS.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    return s is not None and s == stream
+
+
 def prefetch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int = 4,
                            stem_ksize: int = 5, stem_key: str = "stem") -> PendingGeometry:
     """``prepare_unet_geometry`` without stalling the host: the tables are built on a side stream
@@ -586,6 +596,21 @@ def prefetch_unet_geometry(indices: torch.Tensor, spatial_shape, n_levels: int =
     is input-pipeline work, the counterpart of the reference's dataloader workers."""
     _require_device(indices)
     dev = indices.device
+    cur = torch.cuda.current_stream(dev)
+    if GEOMETRY_ON_INPUT_STREAM and _is_input_stream(dev, cur):
+        # Round 6: called from the batch's staging (datasets.voxelize.input_stream) the tables are built ON
+        # that stream - it is a side stream already, one batch ahead of the training stream.  A stream of
+        # their own was one more HIP stream per rank (six with a process group, over four hardware queues:
+        # the streams that share a queue serialise, +3 ms per step measured in round 5).
+        launched = _launch_unet_geometry(indices, spatial_shape, n_levels, stem_ksize, stem_key)
+        if launched is None:
+            return PendingGeometry(None, None, None, cur, 0)
+        state, counts = launched
+        host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(cur)
+        return PendingGeometry(state, host, event, cur, indices.shape[0])
     side = _GEOMETRY_STREAMS.get(dev.index)
     if side is None:
         # HIGH priority by default: ~190 tiny dependent kernels that otherwise wait for a gap between

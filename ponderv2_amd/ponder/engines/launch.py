@@ -56,8 +56,8 @@ def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist
     if dist_url in (None, "auto"):
         assert num_machines == 1, "dist_url=auto is not supported in multi-machine jobs"
         dist_url = f"tcp://127.0.0.1:{_free_port()}"
-    # (the spawned ranks import ponderv2_amd afresh: tell them they are part of a multi-rank job before
-    # their HIP runtime initialises - see ponderv2_amd.limit_hardware_queues_for_process_group)
+    # (the spawned ranks carry an RCCL communicator: two hardware queues - bench.py's header has the
+    # measurements; set by the LAUNCHER, before the ranks' HIP runtimes initialise, not by the library)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     mp.spawn(_worker, nprocs=num_gpus_per_machine, daemon=False,
              args=(main_func, world_size, num_gpus_per_machine, machine_rank, dist_url, cfg, timeout))

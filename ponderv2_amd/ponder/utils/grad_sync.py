@@ -45,6 +45,8 @@ the heads, the stem) travels through the flat buffer as before.  The collectives
 same order on every rank (slabs in completion order, then the flat slices); a step whose backward
 did not run natively on this rank reduces the same slabs from a staging buffer inside ``sync()``.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -62,6 +64,21 @@ def _dense_strides(g):
     return tuple(g.stride())
 
 
+STREAM_OPS = os.environ.get("PV2_GSYNC_STREAM_OPS", "1") != "0"
+
+
+class _OnStream:
+    """What ``wait()`` of an asynchronous collective's handle does, for work that is simply queued on a
+    stream: the caller's current stream waits for everything that stream holds so far."""
+
+    def __init__(self, stream):
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class FlatGradSync:
     def __init__(self, params, process_group=None, slice_mb: float = 64.0, uniform_usage: bool = True,
                  use_blocks: bool = True, overlap: bool = False, slab_mb: float = 48.0,
@@ -71,8 +88,11 @@ class FlatGradSync:
         # instead of receiving a copy of it (False: copy back into the tensors autograd produced)
         self.alias_grads = bool(alias_grads)
         # in-place reduction of the sparse executor's arena behind per-slab events (see the module
-        # docstring); needs every rank to take the same code path: uniform usage only
-        self.overlap = bool(overlap) and uniform_usage
+        # docstring).  Every rank issues the slab collectives in the same order whatever the model does
+        # with its OTHER parameters (the arena's layout is agreed once, ``_arm``; a rank whose backward did
+        # not fill it stages zeros / its gradients, ``_finish_inplace``) - so the route also serves
+        # ``uniform_usage=False`` (round 6: the multi-dataset model, whose arena holds the conv weights only)
+        self.overlap = bool(overlap)
         self.slab_elems = max(int(slab_mb * 2 ** 20 // 4), 1)
         self._index_of = {id(p): i for i, p in enumerate(self.params)}
         self._arena_layout = None     # (arena numel, ((lo, hi), ...), ((param index, offset, numel), ...))
@@ -265,7 +285,14 @@ class FlatGradSync:
                         for ev in events[j]:
                             comm.wait_event(ev)
                     view = arena[lo:hi]
-                    works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+                    if STREAM_OPS:
+                        # a SYNCHRONOUS collective issued under the communication stream: stream-ordered on
+                        # it (the host does not block), and where the backend runs such ops on the caller's
+                        # stream, one HIP stream fewer per rank than the asynchronous form's internal one
+                        dist.all_reduce(view, op=op, group=self.group)
+                        works.append((_OnStream(comm), view))
+                    else:
+                        works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
                     if self._post_reduce is not None:
                         # test hook (tests/test_gpu_grad_overlap.py): an in-place edit of the slab right
                         # behind its reduction on the communication stream.  With ONE rank a reduction is
@@ -457,7 +484,7 @@ class FlatGradSync:
         rest = [i for i in used if i not in moved]
         if rest:
             self._gather(rest, flat, views)
-        host_flags = None
+        host_flags = flags_work = None
         if not self.uniform_usage:
             key = tuple(used)
             hg = self._host_flag_group()
@@ -467,8 +494,9 @@ class FlatGradSync:
                 self._flag_key, self._flags = key, (f if hg else f.to(flat.device))
             if hg:
                 # host to host: nothing here waits for the device (the data follows below, on RCCL)
+                # (asynchronous: the host goes on to enqueue the data reduction while the flags travel)
                 host_flags = self._flags.clone()
-                dist.all_reduce(host_flags, group=hg)
+                flags_work = dist.all_reduce(host_flags, group=hg, async_op=True)
             else:
                 flat[self.numel:].copy_(self._flags)
         # RCCL averages in the reduction itself; other backends (gloo in the CPU tests) sum
@@ -479,6 +507,8 @@ class FlatGradSync:
                                    async_op=True) for a in range(0, end, self.slice_elems)]
         for h in handles:
             h.wait()
+        if flags_work is not None:
+            flags_work.wait()
         if self.uniform_usage:
             if self._steps % self.check_every == 0:
                 mine = float(sum(i + 1 for i in used))

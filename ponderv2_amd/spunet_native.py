@@ -88,7 +88,7 @@ class _Arena:
 class _Unit:
     __slots__ = ("kind", "conv", "bn", "rb", "geom", "geom_ptr", "c_in", "c_out", "relu", "src", "dst",
                  "res", "w_index", "affine", "n_in", "n_out", "y_off", "mi_off", "dy_off", "gsum_off",
-                 "dw_off", "acc_dx", "acc_res", "K", "dx_producer")
+                 "dw_off", "acc_dx", "acc_res", "K", "dx_producer", "affine_in_arena")
 
 
 class Plan:
@@ -412,28 +412,33 @@ def _gradient_slabs(plan, tensors, hook, parena):
     the units last to first, the arena is laid out first to last): ([(parameter, offset, numel)],
     [(lo, hi)], [unit index whose completion finishes the slab]) - or None when the reducer does not want
     this plan.  The stem (unit 0; its weight travels zero-padded, so its gradient is not a parameter's
-    ``.grad``) stays outside the slabs."""
+    ``.grad``) stays outside the slabs.  Members are the LEAF tensors only: a BatchNorm affine pair that is
+    computed (SpUNet-v1m3's prompt-driven normalisation, spconv_unet_v1m3_pdnorm.py:23-72: the modulated
+    pair is a slice of a product) has its gradient in a second arena that no slab covers - autograd still
+    reads it, and the parameters behind it are reduced with the rest after the backward."""
     convs = [(i, u) for i, u in enumerate(plan.units) if _is_conv(u)]
     if len(convs) < 2:
-        return None
-    wanted = []
-    for _, u in convs:
-        wanted += list(tensors[u.w_index:u.w_index + 3])
-    if not hook.wants(wanted):
         return None
     members = []
     for _, u in convs:
         w, bw, bb = tensors[u.w_index:u.w_index + 3]
-        members += [(bb, u.gsum_off, u.c_out), (bw, u.gsum_off + u.c_out, u.c_out), (w, u.dw_off, w.numel())]
+        if not w.is_leaf:
+            return None
+        if u.affine_in_arena:
+            members += [(bb, u.gsum_off, u.c_out), (bw, u.gsum_off + u.c_out, u.c_out)]
+        members.append((w, u.dw_off, w.numel()))
+    if not hook.wants([t for t, _, _ in members]):
+        return None
     end = parena.size
     spans, units = [], []
     hi = end
     for pos in range(len(convs) - 1, -1, -1):
         i, u = convs[pos]
-        if hi - u.gsum_off >= hook.slab_elems or pos == 0:
-            spans.append((u.gsum_off, hi))
+        lo = u.gsum_off if u.affine_in_arena else u.dw_off
+        if hi - lo >= hook.slab_elems or pos == 0:
+            spans.append((lo, hi))
             units.append(i)
-            hi = u.gsum_off
+            hi = lo
     return members, spans, units
 
 
@@ -486,18 +491,22 @@ class SpUNetFunction(torch.autograd.Function):
         # views as ``param.grad`` until the next ``zero_grad`` - carved from the activation-gradient
         # arena they would pin its ~GB through the following forward
         parena = _Arena()
+        narena = _Arena()   # gradients of COMPUTED affine pairs (never reduced in place, see _gradient_slabs)
         tmp_floats = 0
         for u in plan.units:
             if u.kind == UNET_CONCAT:
                 continue
             u.dy_off = arena.reserve(_floats(plan, u.n_out, u.c_out, u.kind != UNET_STEM))
-            u.gsum_off = parena.reserve(2 * u.c_out)
+            bw, bb = tensors[u.w_index + 1], tensors[u.w_index + 2]
+            u.affine_in_arena = bw.is_leaf and bb.is_leaf
+            u.gsum_off = (parena if u.affine_in_arena else narena).reserve(2 * u.c_out)
             u.dw_off = parena.reserve(u.c_out * u.rb.K * u.c_in)
             if u.kind == UNET_CONV_BN16 and u.acc_dx:
                 tmp_floats = max(tmp_floats, _floats(plan, u.n_in, u.c_in, True))
         tmp_off = arena.reserve(tmp_floats) if tmp_floats else None
         arena.allocate(dev)
         parena.allocate(dev)
+        narena.allocate(dev)
         g_ptr = [None if off is None else arena.ptr(off) for off in g_off]
         g_ptr[plan.out_act] = grad_out.data_ptr()
         ops = plan.ops
@@ -508,7 +517,8 @@ class SpUNetFunction(torch.autograd.Function):
             op.dres = g_ptr[u.res] if u.res is not None else None
             if u.kind == UNET_CONCAT:
                 continue
-            op.dy, op.gsum, op.dweight = arena.ptr(u.dy_off), parena.ptr(u.gsum_off), parena.ptr(u.dw_off)
+            op.dy, op.dweight = arena.ptr(u.dy_off), parena.ptr(u.dw_off)
+            op.gsum = (parena if u.affine_in_arena else narena).ptr(u.gsum_off)
             if u.kind == UNET_CONV_BN:
                 part_floats = max(part_floats, int(_lib.lib().pv2_spconv_wgrad_partial_floats(
                     u.c_in, u.c_out, u.geom.n_tiles_w)))
@@ -552,16 +562,20 @@ class SpUNetFunction(torch.autograd.Function):
             hook._on_arena(parena.tensor, members, spans, events)
         grads = [None] * len(tensors)
         convs = [u for u in plan.units if u.kind != UNET_CONCAT]
-        specs = []
-        for u in convs:   # (reserved in this order per unit: gsum, dweight)
-            specs += [(u.gsum_off, u.c_out), (u.gsum_off + u.c_out, u.c_out),
-                      (u.dw_off, tensors[u.w_index].numel())]
-        pieces = parena.views(specs)
-        for j, u in enumerate(convs):
-            i = u.w_index
-            grads[i] = pieces[3 * j + 2].view(tensors[i].shape)
-            grads[i + 1] = pieces[3 * j + 1]     # d bn weight = sum g * xhat
-            grads[i + 2] = pieces[3 * j]         # d bn bias   = sum g
+        for ar, pick in ((parena, True), (narena, False)):
+            specs, owners = [], []
+            for u in convs:   # (reserved in this order per unit: gsum, dweight)
+                if u.affine_in_arena == pick:
+                    specs += [(u.gsum_off, u.c_out), (u.gsum_off + u.c_out, u.c_out)]
+                    owners += [(u, 2), (u, 1)]        # d bn bias = sum g, d bn weight = sum g * xhat
+                if pick:
+                    specs.append((u.dw_off, tensors[u.w_index].numel()))
+                    owners.append((u, 0))
+            if not specs:
+                continue
+            for (u, slot), piece in zip(owners, ar.views(specs)):
+                i = u.w_index
+                grads[i + slot] = piece.view(tensors[i].shape) if slot == 0 else piece
         ctx.plan = None
         g_feats = arena.view(g_off[0], *plan.acts[0]) if want_dx else None
         return (g_feats, None) + tuple(grads)

@@ -274,6 +274,55 @@ def overlap_sync_worker(rank, world, port, out_dir):
             dist.all_reduce(t)
             ok = ok and torch.allclose(p.grad, t / world, atol=1e-6)
     ok = ok and (not lone.overlap) and (not lone._armed) and len(lone._covered) == 0 and armed
+    # Round 6: the multi-dataset model's plan (SpUNet-v1m3 PDNorm) under the overlapped route: only the conv
+    # weights are members of the executor's arena - the BatchNorm pairs of that model are computed tensors,
+    # their parameters ordinary gradients that differ from rank to rank in WHICH of them exist this step
+    # (one condition per rank and step) - with uniform_usage=False.  Bit for bit the flat form's result.
+    model_e, model_f = make(), make()
+    pe, pf = list(model_e.parameters()), list(model_f.parameters())
+    over2 = FlatGradSync(pe, slice_mb=0.02, overlap=True, slab_mb=0.1, uniform_usage=False)
+    flat2 = FlatGradSync(pf, slice_mb=0.02, overlap=False, uniform_usage=False)
+    owned_w = [i for i in owned if pe[i].dim() == 2]           # weights only
+    offs_w, off = {}, 0
+    for i in owned_w:
+        offs_w[i] = off
+        off += (pe[i].numel() + 63) // 64 * 64
+    spans_w, hi = [], off
+    for i in reversed(owned_w):
+        if hi - offs_w[i] >= over2.slab_elems or i == owned_w[0]:
+            spans_w.append((offs_w[i], hi))
+            hi = offs_w[i]
+    pd_ok = len(spans_w) >= 2
+    for step in range(4):
+        grads = local(200 + step)
+        # the "conditions": every third bias exists on one rank only, alternating with the step
+        silent = {i for i in range(len(pe)) if pe[i].dim() == 1 and i % 3 == 0 and (i // 3 + step + rank) % 2 == 0}
+        for p, gr, i in zip(pf, grads, range(len(pf))):
+            p.grad = None if i in silent else gr.clone()
+        for p in pe:
+            p.grad = None
+        assert over2.wants([pe[i] for i in owned_w]), (step, over2.overlap, over2._inflight is None, over2._pending_first is None, [pe[i].grad is None for i in owned_w][:4])
+        arena = torch.full((off,), float("nan"))
+        for i in owned_w:
+            arena[offs_w[i]:offs_w[i] + pe[i].numel()].copy_(grads[i].reshape(-1))
+        over2._on_arena(arena, [(pe[i], offs_w[i], pe[i].numel()) for i in owned_w], spans_w, None)
+        for i in owned_w:
+            pe[i].grad = arena[offs_w[i]:offs_w[i] + pe[i].numel()].view_as(pe[i])
+        for i in set(range(len(pe))) - set(owned_w):
+            pe[i].grad = None if i in silent else grads[i].clone()
+        over2.sync()
+        flat2.sync()
+        for i, (a, b) in enumerate(zip(pe, pf)):
+            pd_ok = pd_ok and (a.grad is None) == (b.grad is None)
+            if a.grad is not None:
+                pd_ok = pd_ok and torch.equal(a.grad, b.grad)
+        for i, gr in enumerate(grads):
+            t = torch.zeros_like(gr) if i in silent else gr.clone()
+            dist.all_reduce(t)
+            if pe[i].grad is not None:
+                pd_ok = pd_ok and torch.allclose(pe[i].grad, t / world, atol=1e-6)
+    pd_ok = pd_ok and over2._armed and len(over2._covered) == len(owned_w)
+    ok = ok and pd_ok
     # rank 1 has NO arena family on the first synchronised step, rank 0 has one
     model_c = make()
     pc = list(model_c.parameters())
