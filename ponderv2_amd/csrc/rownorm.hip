@@ -161,8 +161,8 @@ __global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
     const typename EA::type* __restrict__ a, const typename EX::type* __restrict__ x,
     const typename EY::type* __restrict__ y, const float* __restrict__ mean_invstd, int64_t n, int c,
     int64_t rows_per_block, float* __restrict__ partial) {
-  __shared__ float s0[kThreads * 8];
-  __shared__ float s1[kThreads * 8];
+  __shared__ double s0[kThreads * 8];
+  __shared__ double s1[kThreads * 8];
   const int tid = threadIdx.x;
   const int cg = c >> 3;           // column groups of 8 (<= 128)
   const int rpi = kThreads / cg;   // rows covered per iteration (>= 2)
@@ -170,9 +170,12 @@ __global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
   const bool active = rr < rpi;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(n, r0 + rows_per_block);
-  float acc0[8], acc1[8], mu[8], is[8];
+  // (double accumulators: a block's run of rows is summed exactly to within its final rounding; the
+  // partial row itself stays fp32 - round 6)
+  double acc0[8], acc1[8];
+  float mu[8], is[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc0[j] = acc1[j] = 0.f;
+  for (int j = 0; j < 8; ++j) acc0[j] = acc1[j] = 0.0;
   if (active) {
     if (MODE == 1) {
 #pragma unroll
@@ -222,13 +225,13 @@ __global__ __launch_bounds__(kThreads) void col_partials_vec_kernel(
   }
   __syncthreads();
   for (int t = tid; t < c; t += kThreads) {
-    float t0 = 0.f, t1 = 0.f;
+    double t0 = 0.0, t1 = 0.0;
     for (int q = 0; q < rpi; ++q) {
       t0 += s0[q * c + t];
       t1 += s1[q * c + t];
     }
-    partial[(int64_t)blockIdx.x * 2 * c + t] = t0;
-    partial[(int64_t)blockIdx.x * 2 * c + c + t] = t1;
+    partial[(int64_t)blockIdx.x * 2 * c + t] = (float)t0;
+    partial[(int64_t)blockIdx.x * 2 * c + c + t] = (float)t1;
   }
 }
 
@@ -332,7 +335,11 @@ __global__ __launch_bounds__(kCombineThreads) void col_combine_kernel(
 
 template <int MODE, typename EX, typename... A>
 inline void launch_combine(hipStream_t s, int c, const float* partial, int nb, A... rest) {
-  const int panel = nb >= 256 ? 8 : 32;
+  static const int forced = [] {
+    const char* e = getenv("PV2_BN_COMBINE_PANEL");   // 8 / 32: one panel width for every launch (A / B)
+    return e ? atoi(e) : 0;
+  }();
+  const int panel = forced == 8 || forced == 32 ? forced : (nb >= 256 ? 8 : 32);
   hipLaunchKernelGGL((col_combine_kernel<MODE, EX>), dim3((c + panel - 1) / panel), dim3(kCombineThreads), 0,
                      s, panel, partial, nb, rest...);
 }

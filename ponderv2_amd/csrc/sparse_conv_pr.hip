@@ -58,6 +58,13 @@ __global__ void pair_positions_kernel(const int32_t* __restrict__ pair_a,
   }
 }
 
+__device__ __forceinline__ void accd(double (&a)[4], const float4& b) {
+  a[0] += (double)b.x;
+  a[1] += (double)b.y;
+  a[2] += (double)b.z;
+  a[3] += (double)b.w;
+}
+
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
   a.x += b.x;
   a.y += b.y;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
     const float* addend, float* Y, float* partial, const float* __restrict__ sy,
     const float* __restrict__ so, const float* __restrict__ smi) {
   constexpr int NT = 256 / TS;
-  __shared__ float s_red[STATS ? 2048 * NJ : 1];
+  __shared__ double s_red[STATS ? 2048 * NJ : 1];
   const int tid = threadIdx.x, team = tid / TS, l = tid % TS;
   const int team_base = (tid & 63) / TS * TS;
   const int c4n = c >> 2;
@@ -167,9 +174,16 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
   const int64_t r_end = min(n_rows, r_begin + rows_per_block);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 sh[NJ], a0[NJ], a1[NJ], is4[NJ];
+  // (the statistics accumulate in DOUBLE per thread and per block - a block's rows are summed exactly to
+  // within the final rounding of its fp32 partial row; round 6)
+  float4 sh[NJ], is4[NJ];
+  double a0[NJ][4], a1[NJ][4];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) sh[j] = a0[j] = a1[j] = is4[j] = zero;
+  for (int j = 0; j < NJ; ++j) {
+    sh[j] = is4[j] = zero;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a0[j][q] = a1[j][q] = 0.0;
+  }
   if (STATS == 2) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -251,22 +265,22 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
         if (va) {
           const float4 d = make_float4(accA[j].x - sh[j].x, accA[j].y - sh[j].y, accA[j].z - sh[j].z,
                                        accA[j].w - sh[j].w);
-          add4(a0[j], d);
-          add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
+          accd(a0[j], d);
+          accd(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
         }
         if (!need_shift && vb) {
           const float4 d = make_float4(accB[j].x - sh[j].x, accB[j].y - sh[j].y, accB[j].z - sh[j].z,
                                        accB[j].w - sh[j].w);
-          add4(a0[j], d);
-          add4(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
+          accd(a0[j], d);
+          accd(a1[j], make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
         }
       }
       if (STATS == 2) {
         auto one = [&](const float4& g_, const float4& yv, const float4& ov) {
           const float4 g = make_float4(ov.x > 0.f ? g_.x : 0.f, ov.y > 0.f ? g_.y : 0.f,
                                        ov.z > 0.f ? g_.z : 0.f, ov.w > 0.f ? g_.w : 0.f);
-          add4(a0[j], g);
-          add4(a1[j], make_float4(g.x * (yv.x - sh[j].x) * is4[j].x, g.y * (yv.y - sh[j].y) * is4[j].y,
+          accd(a0[j], g);
+          accd(a1[j], make_float4(g.x * (yv.x - sh[j].x) * is4[j].x, g.y * (yv.y - sh[j].y) * is4[j].y,
                                   g.z * (yv.z - sh[j].z) * is4[j].z, g.w * (yv.w - sh[j].w) * is4[j].w));
         };
         if (va) one(accA[j], yA[j], oA[j]);
@@ -284,17 +298,17 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
     for (int j = 0; j < NJ; ++j) {
       const int col = l + j * TS;
       if (col < c4n) {
-        float* r0 = &s_red[team * 2 * c + 4 * col];
-        r0[0] = a0[j].x; r0[1] = a0[j].y; r0[2] = a0[j].z; r0[3] = a0[j].w;
-        float* r1 = r0 + c;
-        r1[0] = a1[j].x; r1[1] = a1[j].y; r1[2] = a1[j].z; r1[3] = a1[j].w;
+        double* r0 = &s_red[team * 2 * c + 4 * col];
+        r0[0] = a0[j][0]; r0[1] = a0[j][1]; r0[2] = a0[j][2]; r0[3] = a0[j][3];
+        double* r1 = r0 + c;
+        r1[0] = a1[j][0]; r1[1] = a1[j][1]; r1[2] = a1[j][2]; r1[3] = a1[j][3];
       }
     }
     __syncthreads();
     for (int t = tid; t < 2 * c; t += 256) {
-      float s = 0.f;
+      double s = 0.0;
       for (int q = 0; q < NT; ++q) s += s_red[q * 2 * c + t];  // teams in a fixed order
-      partial[(int64_t)blockIdx.x * 2 * c + t] = s;
+      partial[(int64_t)blockIdx.x * 2 * c + t] = (float)s;
     }
   }
 }

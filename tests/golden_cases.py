@@ -356,24 +356,31 @@ def float64_gradient_errors(params, g):
                 ref32_global_rel=(num32["all"] / den["all"]) ** 0.5 if have32 else None,
                 ref32_backbone_rel=(num32["backbone"] / den["backbone"]) ** 0.5 if have32 else None,
                 worst_tensor_rel=worst[0], worst_tensor_ref32_rel=worst[1], worst_tensor=worst[2],
-                tensors=len(g["g64_names"]))
+                tensors=len(g["g64_names"]), top=sorted(per_tensor, reverse=True)[:8])
 
 
-def check_float64_gradients_tight(f64):
+def check_float64_gradients_tight(f64, tensor_floor=5e-3):
     """On the well-conditioned fixtures (the reference's real initialisation) the GPU's fp32 gradients
-    must sit within 1e-3 of the float64 ones globally and over the backbone - or within three times what
+    must sit within 1e-3 of the float64 ones globally and over the backbone - or within TWICE what
     the reference's own fp32 pass manages on that batch, whichever is larger - and no single tensor may
-    be off by more than 3x its reference-fp32 figure (or 1e-2; a single tensor's figure is an estimate
-    from 8 projections, +-25 %).  Measured on MI355X (round 5, ours / the reference's fp32, global):
-    configs[1] 1.13e-3 / 1.15e-3; configs[3] Structured3D 2.7e-4 / 5.4e-4, ScanNet 1.8e-3 / 2.1e-3,
-    S3DIS 1.0e-3 / 6.2e-4 (backbone 1.3e-3 / 6.5e-4, one first-level BatchNorm bias at 6.8e-3 - the
-    one case where this fp32 program is the less accurate of the two); configs[4] 7.5e-5 / 2.8e-4."""
+    be off by more than twice its reference-fp32 figure (or ``tensor_floor``: 5e-3, the round-4 bar; a
+    single tensor's figure is an estimate from 8 projections, +-25 %).  Measured on MI355X (round 6, ours /
+    the reference's fp32, global | backbone): configs[1] 1.13e-3 / 1.15e-3 | 1.24e-3 / 1.25e-3; configs[3]
+    Structured3D 2.1e-4 / 5.4e-4 | 2.4e-4 / 2.9e-4, ScanNet 1.8e-3 / 2.1e-3 | 2.0e-3 / 1.9e-3, S3DIS
+    9.4e-4 / 6.2e-4 | 1.24e-3 / 6.5e-4; configs[4] 7.4e-5 / 2.8e-4 | 1.5e-4 / 5.4e-4.
+    S3DIS is the one batch where this program lands further out than the reference's fp32 (one first-level
+    BatchNorm bias at 6.4e-3: that fixture alone gets ``tensor_floor=1e-2``).  Round 6 looked for a cause in
+    the column sums of the BatchNorm backward and found the figure to be a property of
+    the rounding pattern, not of one kernel: with every statistic accumulated in DOUBLE per block (what
+    ships) the five fixtures read as above; with fp32 accumulation S3DIS reads 4.0e-4 (below the reference)
+    and configs[1] 2.0e-3 (1.75x above it) - the same code, the order of a few fp32 additions apart
+    (profiles/r06_gradient_distance.txt)."""
     assert f64["tensors"] > 200, f64
     for key in ("global_rel", "backbone_rel"):
         ref = f64["ref32_" + key]
         assert ref is not None, "fixture without the reference's fp32 record"
-        assert f64[key] <= max(3.0 * ref, 1e-3), f64
-    assert f64["worst_tensor_rel"] <= max(3.0 * f64["worst_tensor_ref32_rel"], 1e-2), f64
+        assert f64[key] <= max(2.0 * ref, 1e-3), f64
+    assert f64["worst_tensor_rel"] <= max(2.0 * f64["worst_tensor_ref32_rel"], tensor_floor), f64
 
 
 def check_float64_gradients(f64, closed_form=True):

@@ -149,7 +149,9 @@ def test_ponder_ppt_full_size_real_initialisation_tight_gradients(device, condit
     assert flips == 0
     losses = {k: v for k, v in errs.items() if not k.startswith(("grad_", "render", "ref32_"))}
     assert max(losses.values()) < 1e-4, errs
-    gc.check_float64_gradients_tight(f64)
+    # (S3DIS, index 2: the known outlier - one first-level BatchNorm bias at 6.4e-3 - keeps the wider
+    # per-tensor floor; every other fixture is held to the round-4 bar)
+    gc.check_float64_gradients_tight(f64, tensor_floor=1e-2 if condition_index == 2 else 5e-3)
     _check_real_init_render(errs)
 
 
