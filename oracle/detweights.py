@@ -34,6 +34,18 @@ def fill_deterministic(module):
     return module
 
 
+def real_init_modulation(module, scale=0.05):
+    """For the real-initialisation fixtures of SpUNet-v1m3: the reference zero-initialises the PDNorm
+    modulation layers (spconv_unet_v1m3_pdnorm.py:389-404), which would leave the modulation path without
+    signal.  Both sides call this after their constructors: small closed-form values for exactly those
+    layers, everything else keeps the constructor's (seeded) initialisation."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if ".modulation." in name:
+                p.copy_(formula_tensor(name, p.shape, scale).to(p.dtype))
+    return module
+
+
 GRAD_PROBES = 8
 
 

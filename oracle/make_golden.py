@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import ref_shims  # noqa: E402
-from oracle.detweights import GRAD_PROBES, fill_deterministic, formula_tensor, grad_probe  # noqa: E402
+from oracle.detweights import (GRAD_PROBES, fill_deterministic, formula_tensor, grad_probe,  # noqa: E402
+                               real_init_modulation)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -150,9 +151,28 @@ def _gradient_projections(model):
     return names, norms, projs
 
 
-def spunet_case():
+def _compact_gradients(params, names, small=4096):
+    """Every gradient of ``names`` for a fixture file: in full (float64) up to ``small`` elements, as its
+    projections on GRAD_PROBES seeded random probes plus its norm beyond (oracle/detweights.grad_probe)."""
+    out = {}
+    for i, k in enumerate(names):
+        g = params[k].grad.detach().double()
+        if g.numel() <= small:
+            out[f"grad_{i}"] = g.numpy()
+        else:
+            flat = g.reshape(-1)
+            out[f"gproj_{i}"] = np.array([float(flat @ grad_probe(k, j, g.shape).double().reshape(-1))
+                                          for j in range(GRAD_PROBES)])
+            out[f"gnorm_{i}"] = np.array(float(flat.norm()))
+    return out
+
+
+def spunet_case(real_init=False):
     """Reference SpUNetBase (spconv_unet_v1m1_base.py:86-278) on the oracle sparse-conv runtime,
-    float64, two small scenes."""
+    float64, two small scenes.  ``real_init`` (round 6): the constructor's own initialisation under
+    ``torch.manual_seed(0)`` (spconv_unet_v1m1_base.py:225-240) instead of the closed-form weights - a
+    well-conditioned twin of the fixture, whose gradients can be held to fp32 bounds; every parameter's
+    gradient is recorded."""
     from helpers import random_voxels
     from ponder.models.builder import MODELS
 
@@ -162,8 +182,10 @@ def spunet_case():
     n = len(coords)
     feat = formula_tensor("spunet.feat", (n, 6), 1.0).double()
     cfg = dict(SMALL_BACKBONE)
+    torch.manual_seed(0)
     model = MODELS.build(cfg).double()
-    fill_deterministic(model)
+    if not real_init:
+        fill_deterministic(model)
     model.train()
     feat.requires_grad_(True)
     out = model(dict(grid_coord=grid_coord, feat=feat,
@@ -173,10 +195,14 @@ def spunet_case():
     names = ["conv_input.0.weight", "enc.1.block0.conv1.weight", "down.2.0.weight",
              "up.1.0.weight", "dec.0.block0.proj.0.weight", "dec.3.block0.bn2.bias"]
     params = dict(model.named_parameters())
+    if real_init:
+        names = [k for k, p in params.items() if p.grad is not None]
     np.savez_compressed(
-        os.path.join(GOLDEN, "spunet_small.npz"), coords=coords, out=out.detach().numpy(),
+        os.path.join(GOLDEN, "spunet_small_real_init.npz" if real_init else "spunet_small.npz"),
+        coords=coords, out=out.detach().numpy(),
         dfeat=feat.grad.numpy(), grad_names=np.array(names),
-        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)})
+        **(_compact_gradients(params, names) if real_init else
+           {f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)}))
     print("spunet_small: out", tuple(out.shape), "mean |out|", out.abs().mean().item())
 
 
@@ -564,9 +590,12 @@ PDNORM_BACKBONE = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_ch
                        zero_init=False, norm_decouple=True, norm_adaptive=True, norm_affine=True)
 
 
-def spunet_pdnorm_case():
+def spunet_pdnorm_case(real_init=False):
     """Reference SpUNet-v1m3 (spconv_unet_v1m3_pdnorm.py:236-427: per-condition BatchNorm +
-    context modulation) on the oracle sparse-conv runtime, float64, condition "S3DIS"."""
+    context modulation) on the oracle sparse-conv runtime, float64, condition "S3DIS".  ``real_init``
+    (round 6): the constructor's own initialisation under ``torch.manual_seed(0)`` - with the modulation
+    layers' weights redrawn (the reference zero-initialises them, spconv_unet_v1m3_pdnorm.py:389-404, which
+    would leave the modulation path untested) - and every parameter's gradient recorded."""
     from helpers import random_voxels
     from ponder.models.builder import MODELS
 
@@ -575,9 +604,13 @@ def spunet_pdnorm_case():
     n = len(coords)
     feat = formula_tensor("pdnorm.feat", (n, 6), 1.0).double().requires_grad_(True)
     context = formula_tensor("pdnorm.context", (1, 32), 1.0).double().requires_grad_(True)
-    model = MODELS.build(dict(PDNORM_BACKBONE)).double()
-    fill_deterministic(model)
-    model.train()
+    torch.manual_seed(0)
+    model = MODELS.build(dict(PDNORM_BACKBONE))
+    if real_init:
+        real_init_modulation(model)
+    else:
+        fill_deterministic(model)
+    model = model.double().train()
     out = model(dict(grid_coord=torch.from_numpy(coords[:, 1:].astype(np.int64)), feat=feat,
                      offset=torch.from_numpy(np.cumsum(counts)).long(), condition=["S3DIS"],
                      context=context))
@@ -590,10 +623,14 @@ def spunet_pdnorm_case():
              "dec.3.block0.bn2.bns.1.weight", "up.1.conv.weight"]
     unused = [k for k, p in params.items() if ".bns.0." in k or ".bns.2." in k]
     assert unused and all(params[k].grad is None for k in unused)  # other datasets' BN untouched
+    if real_init:
+        names = [k for k, p in params.items() if p.grad is not None]
     np.savez_compressed(
-        os.path.join(GOLDEN, "spunet_pdnorm_small.npz"), coords=coords, out=out.detach().numpy(),
+        os.path.join(GOLDEN, "spunet_pdnorm_small_real_init.npz" if real_init else "spunet_pdnorm_small.npz"),
+        coords=coords, out=out.detach().numpy(),
         dfeat=feat.grad.numpy(), dcontext=context.grad.numpy(), grad_names=np.array(names),
-        **{f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)})
+        **(_compact_gradients(params, names) if real_init else
+           {f"grad_{i}": params[k].grad.numpy() for i, k in enumerate(names)}))
     print("spunet_pdnorm_small: out", tuple(out.shape), "mean |out|", out.abs().mean().item(),
           "|dcontext|", context.grad.abs().max().item())
 
@@ -707,6 +744,9 @@ def main():
                  # round 5: the REAL initialisation for configs[3] (one fixture per condition) and configs[4]
                  ppt_full_real=lambda: ponder_ppt_full_case(ConfigDict, real_init=True),
                  outdoor_full_real=lambda: ponder_outdoor_full_case(ConfigDict, real_init=True),
+                 # round 6: real-initialisation twins of the two small backbone fixtures
+                 spunet_real=lambda: spunet_case(real_init=True),
+                 pdnorm_real=lambda: spunet_pdnorm_case(real_init=True),
                  narrow_decoder=narrow_decoder_case)
     for name, fn in cases.items():
         if not only or name in only:

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from oracle.detweights import fill_deterministic, formula_tensor
+from oracle.detweights import fill_deterministic, formula_tensor, real_init_modulation
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -86,15 +86,38 @@ class ReplayRand:
         return out.to(self.device)
 
 
-def run_spunet(device, dtype):
+def _gradient_errors(params, g):
+    """errs / cos per recorded gradient of a backbone fixture: full tensors where the fixture holds them,
+    projections on the seeded probes for the large ones (oracle/make_golden.py _compact_gradients)."""
+    from oracle.detweights import GRAD_PROBES, grad_probe
+
+    errs, cos = {}, {}
+    for i, name in enumerate(g["grad_names"]):
+        name = str(name)
+        grad = params[name].grad
+        if f"grad_{i}" in g.files:
+            errs[name] = rel_err(grad, g[f"grad_{i}"])
+            cos[name] = cos_err(grad, g[f"grad_{i}"])
+        else:
+            flat = grad.detach().double().reshape(-1)
+            ref = g[f"gproj_{i}"]
+            e2 = np.mean([(float(flat @ grad_probe(name, j, grad.shape).to(grad.device).double().reshape(-1))
+                           - float(ref[j])) ** 2 for j in range(GRAD_PROBES)])
+            errs[name] = float(e2 ** 0.5 / (float(g[f"gnorm_{i}"]) + 1e-30))   # |error| / |gradient|
+    return errs, cos
+
+
+def run_spunet(device, dtype, real_init=False):
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    g = np.load(os.path.join(GOLDEN, "spunet_small.npz"))
+    g = np.load(os.path.join(GOLDEN, "spunet_small_real_init.npz" if real_init else "spunet_small.npz"))
     coords = g["coords"]
     counts = np.bincount(coords[:, 0])
+    torch.manual_seed(0)     # (real_init: the constructor's draws are the fixture's weights)
     model = build_model(ConfigDict(SMALL_BACKBONE)).to(dtype)
-    fill_deterministic(model)
+    if not real_init:
+        fill_deterministic(model)
     model = model.to(device).train()
     n = len(coords)
     feat = formula_tensor("spunet.feat", (n, 6), 1.0).to(dtype).to(device).requires_grad_(True)
@@ -105,9 +128,9 @@ def run_spunet(device, dtype):
     params = dict(model.named_parameters())
     errs = {"out": rel_err(out, g["out"]), "dfeat": rel_err(feat.grad, g["dfeat"])}
     cos = {"dfeat": cos_err(feat.grad, g["dfeat"])}
-    for i, name in enumerate(g["grad_names"]):
-        errs[str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
-        cos[str(name)] = cos_err(params[str(name)].grad, g[f"grad_{i}"])
+    ge, gcos = _gradient_errors(params, g)
+    errs.update(ge)
+    cos.update(gcos)
     if dtype == torch.float64:
         return errs
     return errs, cos
@@ -519,16 +542,21 @@ PDNORM_BACKBONE = dict(type="SpUNet-v1m3", in_channels=6, num_classes=0, base_ch
                        zero_init=False, norm_decouple=True, norm_adaptive=True, norm_affine=True)
 
 
-def run_spunet_pdnorm(device, dtype):
+def run_spunet_pdnorm(device, dtype, real_init=False):
     from ponderv2_amd.ponder.models import build_model
     from ponderv2_amd.ponder.utils.config import ConfigDict
 
-    g = np.load(os.path.join(GOLDEN, "spunet_pdnorm_small.npz"))
+    g = np.load(os.path.join(GOLDEN, "spunet_pdnorm_small_real_init.npz" if real_init
+                             else "spunet_pdnorm_small.npz"))
     coords = g["coords"]
     counts = np.bincount(coords[:, 0])
-    model = build_model(ConfigDict(PDNORM_BACKBONE)).to(dtype)
-    fill_deterministic(model)
-    model = model.to(device).train()
+    torch.manual_seed(0)
+    model = build_model(ConfigDict(PDNORM_BACKBONE))
+    if real_init:
+        real_init_modulation(model)
+    else:
+        fill_deterministic(model)
+    model = model.to(dtype).to(device).train()
     n = len(coords)
     feat = formula_tensor("pdnorm.feat", (n, 6), 1.0).to(dtype).to(device).requires_grad_(True)
     context = formula_tensor("pdnorm.context", (1, 32), 1.0).to(dtype).to(device).requires_grad_(True)
@@ -541,9 +569,9 @@ def run_spunet_pdnorm(device, dtype):
     errs = {"out": rel_err(out, g["out"]), "dfeat": rel_err(feat.grad, g["dfeat"]),
             "dcontext": rel_err(context.grad, g["dcontext"])}
     cos = {"dfeat": cos_err(feat.grad, g["dfeat"]), "dcontext": cos_err(context.grad, g["dcontext"])}
-    for i, name in enumerate(g["grad_names"]):
-        errs[str(name)] = rel_err(params[str(name)].grad, g[f"grad_{i}"])
-        cos[str(name)] = cos_err(params[str(name)].grad, g[f"grad_{i}"])
+    ge, gcos = _gradient_errors(params, g)
+    errs.update(ge)
+    cos.update(gcos)
     untouched = [k for k, p in params.items() if ".bns.0." in k or ".bns.2." in k]
     assert untouched and all(params[k].grad is None for k in untouched)
     if dtype == torch.float64:

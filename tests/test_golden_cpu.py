@@ -17,6 +17,18 @@ def test_spunet_topology_matches_reference(cpu_kernels):
     assert max(errs.values()) < 1e-9, errs
 
 
+def test_spunet_real_initialisation_twin_matches_reference(cpu_kernels):
+    """Round 6: the same backbone with the reference's OWN initialisation (the constructor's seeded draws -
+    our classes draw in the same order) - every parameter's gradient, float64 on the host."""
+    errs = gc.run_spunet(torch.device("cpu"), torch.float64, real_init=True)
+    assert len(errs) > 80 and max(errs.values()) < 1e-9, errs
+
+
+def test_spunet_pdnorm_real_initialisation_twin_matches_reference(cpu_kernels):
+    errs = gc.run_spunet_pdnorm(torch.device("cpu"), torch.float64, real_init=True)
+    assert len(errs) > 80 and max(errs.values()) < 1e-9, errs
+
+
 def test_neus_head_matches_reference(cpu_kernels):
     errs = gc.run_neus(torch.device("cpu"))
     assert max(errs.values()) < 2e-4, errs

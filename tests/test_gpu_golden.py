@@ -29,6 +29,27 @@ def test_spunet_gpu_vs_reference_golden(device):
     assert max(cos.values()) < 1e-3, cos
 
 
+def test_spunet_real_initialisation_twin_gpu_vs_reference(device):
+    """The small backbone with the reference's REAL initialisation (round 6): a
+    well-conditioned net, so forward AND every parameter gradient are held to fp32 bounds - where the
+    closed-form fixture above can only bound gradients by percents."""
+    errs, cos = gc.run_spunet(device, torch.float32, real_init=True)
+    worst = max(errs, key=errs.get)
+    print("worst", worst, errs[worst], "out", errs["out"], "tensors", len(errs))
+    assert errs["out"] < 1e-5, errs["out"]
+    assert len(errs) > 80 and errs[worst] < 1e-4, (worst, errs[worst])   # measured 1.4e-6
+    assert max(cos.values()) < 1e-5, cos
+
+
+def test_spunet_pdnorm_real_initialisation_twin_gpu_vs_reference(device):
+    errs, cos = gc.run_spunet_pdnorm(device, torch.float32, real_init=True)
+    worst = max(errs, key=errs.get)
+    print("worst", worst, errs[worst], "out", errs["out"], "tensors", len(errs))
+    assert errs["out"] < 1e-5, errs["out"]
+    assert len(errs) > 80 and errs[worst] < 1e-4, (worst, errs[worst])   # measured 1.4e-6
+    assert max(cos.values()) < 1e-5, cos
+
+
 def test_neus_head_gpu_vs_reference_golden(device):
     errs = gc.run_neus(device)
     print(errs)
