@@ -1002,6 +1002,11 @@ int64_t pv2_dconv3_packed_floats(int c_out, int c_in, int mode);
 int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out, int64_t s_red,
                             int64_t s_z, int64_t s_y, int64_t s_x, int flip, int mode, float* packed,
                             pv2_stream_t stream);
+/* Reduced-precision products for the dense convolutions (process-wide switch, 0 restores fp32): every
+ * product of pv2_dconv3_forward / _backward_weight on the LEADING bf16 piece of each operand only - what
+ * the reference's enable_amp = True buys from the library's 16-bit convolutions (ponder/engines/train.py:
+ * 183-196, unet3d.py:45-156): operands cut to bf16 by truncation, fp32 sums, fp32 results. */
+int pv2_dconv3_set_one_term(int on);
 int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,
                        const float* in_mask_src, const float* bias, const float* addend, int relu,

@@ -217,6 +217,7 @@ SIGNATURES["pv2_trilinear_backward_16"] = (
 SIGNATURES["pv2_trilinear_backward_backward_16"] = (
     c_int, [_P, _P, _P, c_int, POINTER(VolumeDesc), _P, _P, POINTER(PointsDesc), _P, _P, _P,
             c_int, c_int, c_int, _P])
+SIGNATURES["pv2_dconv3_set_one_term"] = (c_int, [c_int])
 SIGNATURES["pv2_dconv3_packed_floats"] = (c_int64, [c_int, c_int, c_int])
 SIGNATURES["pv2_dconv3_pack_weights"] = (c_int, [_P, c_int, c_int] + [c_int64] * 5 + [c_int, c_int, _P, _P])
 SIGNATURES["pv2_dconv3_forward"] = (

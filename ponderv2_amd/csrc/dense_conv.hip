@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void dconv_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowW = 28;   // dwords per cell row of the split halo tile
 
-template <int NB, int MT, int PFN, bool MASKED>
+template <int NB, int MT, int PFN, bool MASKED, bool ONE>
 __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
     int n_groups, int tiles_per_wg, const float* __restrict__ in_scale,
@@ -594,11 +594,11 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)           \
   _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)           \
     acc[mt][nb] = pv2::mfma_bf16(aq[ac][mt][ta], bq[wc][nb][tb], acc[mt][nb]);
-      PV2_SPLIT_TERMS(PV2_TERM)
+      if constexpr (ONE) { PV2_TERM(0, 0) } else { PV2_SPLIT_TERMS(PV2_TERM) }
 #undef PV2_TERM
       // issue order: one MFMA, then up to two of the other requests
 #pragma unroll
-      for (int k = 0; k < 6 * MT * NB; ++k) {
+      for (int k = 0; k < (ONE ? 1 : 6) * MT * NB; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(kOther, 2, 0);
       }
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void dconvT_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowS = 12;
 
-template <int NB, int PFN, bool MASKED>
+template <int NB, int PFN, bool MASKED, bool ONE>
 __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
     int n_groups, int tiles_per_wg, const float* __restrict__ mask_src,
@@ -936,10 +936,10 @@ __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
       }
 #define PV2_TERM(ta, tb) \
   _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = pv2::mfma_bf16(aq[cur][ta], bq[cur][nb][tb], acc[nb]);
-      PV2_SPLIT_TERMS(PV2_TERM)
+      if constexpr (ONE) { PV2_TERM(0, 0) } else { PV2_SPLIT_TERMS(PV2_TERM) }
 #undef PV2_TERM
 #pragma unroll
-      for (int k = 0; k < 6 * NB; ++k) {
+      for (int k = 0; k < (ONE ? 1 : 6) * NB; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(kOther, 2, 0);
       }
@@ -987,6 +987,7 @@ __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
 // transposed conv); per tap ONE class accumulator takes six MFMAs; the neighbour's cells come from LDS
 // one tap ahead, the weight fragments two taps ahead.
 // ---------------------------------------------------------------------------------------------
+template <bool ONE>
 __global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
     int n_groups, const float* __restrict__ bias, const float* __restrict__ addend,
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
       if (t + 1 < 27) cells_of(t + 1, aq[(t + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);   // (the requests stay in front of the MFMAs)
 #define PV2_TERM(ta, tb) acc[cls] = pv2::mfma_bf16(aq[t & 1][ta], wq[t % 3][tb], acc[cls]);
-      PV2_SPLIT_TERMS(PV2_TERM)
+      if constexpr (ONE) { PV2_TERM(0, 0) } else { PV2_SPLIT_TERMS(PV2_TERM) }
 #undef PV2_TERM
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1347,7 +1348,7 @@ __global__ __launch_bounds__(kWgThreads) void dconv_wgrad_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kCellU16 = 96;   // ushorts per cell row: 3 pieces x 32 channels
 
-template <int XI, int GI, bool SHARED_A>
+template <int XI, int GI, bool SHARED_A, bool ONE>
 __global__ __launch_bounds__(kWgThreads) void dconv_wgrad_split_kernel(
     const float* __restrict__ X, int c_x, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* __restrict__ G, int c_g,
@@ -1510,7 +1511,7 @@ __global__ __launch_bounds__(kWgThreads) void dconv_wgrad_split_kernel(
         }
 #define PV2_TERM(ta, tb) \
   _Pragma("unroll") for (int u = 0; u < CNT; ++u) acc[u] = pv2::mfma_bf16(fa[SHARED_A ? 0 : u][ta], fb[u][tb], acc[u]);
-        PV2_SPLIT_TERMS(PV2_TERM)
+        if constexpr (ONE) { PV2_TERM(0, 0) } else { PV2_SPLIT_TERMS(PV2_TERM) }
 #undef PV2_TERM
       }
     }
@@ -1682,6 +1683,8 @@ int env_int(const char* name, int fallback) {
 
 // every dense convolution runs on the bf16 matrix cores (dconv_split_kernel, dconvT_split_kernel,
 // dconv_strided_split_kernel) unless PV2_FP32_MFMA=1
+bool g_one_term = false;   // pv2_dconv3_set_one_term
+
 bool split_conv(int mode) {
   static const bool on = env_int("PV2_FP32_MFMA", 0) != 1;
   return on && mode >= 0 && mode <= 2;
@@ -1727,7 +1730,10 @@ int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out,
 
 // mode 0: conv k3 s1 p1 (out grid = in grid); mode 1: transposed conv k3 s2 p1 (out = 2 x in);
 // mode 2: strided conv k3 s2 p1 (out = in / 2, in even): the grad-input of mode 1.
-int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
+}  // extern "C"
+
+template <bool ONE>
+static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,
                        const float* in_mask_src, const float* bias, const float* addend, int relu,
                        const float* out_mask_src, float* out, pv2_stream_t stream) {
@@ -1797,8 +1803,8 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
   const int n_groups = nbtot / nb;
   if (mode == 1 && split) {
-    if (int e = set_lds(dconvT_split_kernel, lds)) return e;
-    hipLaunchKernelGGL(dconvT_split_kernel, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g,
+    if (int e = set_lds(dconvT_split_kernel<ONE>, lds)) return e;
+    hipLaunchKernelGGL(dconvT_split_kernel<ONE>, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g,
                        c_in, reinterpret_cast<const pv2::bf16x8*>(packed_w), c_out, n_groups, bias, addend,
                        out);
     return pv2::check_launch("dconv3_forward(transposed, split)");
@@ -1837,8 +1843,8 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
 #define PV2_DSTRIDE_LAUNCH(NB_, MASKED_)                                                                \
   do {                                                                                                  \
-    if (int e = set_lds(dconv_strided_split_kernel<NB_, 13, MASKED_>, lds)) return e;                   \
-    hipLaunchKernelGGL((dconv_strided_split_kernel<NB_, 13, MASKED_>), grid, dim3(256), lds, s, x, g,   \
+    if (int e = set_lds(dconv_strided_split_kernel<NB_, 13, MASKED_, ONE>, lds)) return e;                   \
+    hipLaunchKernelGGL((dconv_strided_split_kernel<NB_, 13, MASKED_, ONE>), grid, dim3(256), lds, s, x, g,   \
                        c_in, wq, c_out, n_groups, tpw, in_mask_src, out_mask_src, out);                 \
   } while (0)
     if (nb == 2) {
@@ -1855,8 +1861,8 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
     const pv2::bf16x8* wq = reinterpret_cast<const pv2::bf16x8*>(packed_w);
 #define PV2_DSPLIT_LAUNCH_MT(NB_, MT_, PFN_, MASKED_)                                                     \
   do {                                                                                                   \
-    if (int e = set_lds(dconv_split_kernel<NB_, MT_, PFN_, MASKED_>, lds)) return e;                     \
-    hipLaunchKernelGGL((dconv_split_kernel<NB_, MT_, PFN_, MASKED_>), grid, dim3(256), lds, s, x, g, c_in, \
+    if (int e = set_lds(dconv_split_kernel<NB_, MT_, PFN_, MASKED_, ONE>, lds)) return e;                     \
+    hipLaunchKernelGGL((dconv_split_kernel<NB_, MT_, PFN_, MASKED_, ONE>), grid, dim3(256), lds, s, x, g, c_in, \
                        wq, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias, addend, relu,    \
                        out_mask_src, out);                                                               \
   } while (0)
@@ -1897,6 +1903,18 @@ int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, co
 #undef PV2_DCONV_MASK
 #undef PV2_DCONV_LAUNCH
   return pv2::check_launch("dconv3_forward");
+}
+
+extern "C" {
+
+int pv2_dconv3_forward(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
+                       int c_out, int mode, const float* in_scale, const float* in_shift,
+                       const float* in_mask_src, const float* bias, const float* addend, int relu,
+                       const float* out_mask_src, float* out, pv2_stream_t stream) {
+  return g_one_term ? dconv3_forward_t<true>(x, b, z, y, xx, c_in, packed_w, c_out, mode, in_scale, in_shift,
+                                             in_mask_src, bias, addend, relu, out_mask_src, out, stream)
+                    : dconv3_forward_t<false>(x, b, z, y, xx, c_in, packed_w, c_out, mode, in_scale, in_shift,
+                                              in_mask_src, bias, addend, relu, out_mask_src, out, stream);
 }
 
 // Geometry shared by the partial-size query and the launch.
@@ -1944,7 +1962,10 @@ int64_t pv2_dconv3_wgrad_partial_floats(int b, int z, int y, int xx, int c_x, in
 //         front of it), gy [b,z,y,xx,c_g] the output gradient (gy_mask_src: the output, for the ReLU mask);
 // mode 1: transposed conv k3 s2 p1 - x the coarse input, gy [b,2z,2y,2xx,c_g].
 // dw[n*s_n + c*s_c + kz*s_z + ky*s_y + kx*s_x], n over c_g, c over c_x.
-int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int c_x,
+}  // extern "C"
+
+template <bool ONE>
+static int dconv3_backward_weight_t(const float* x, int b, int z, int y, int xx, int c_x,
                                const float* in_scale, const float* in_shift, const float* gy,
                                int c_g, const float* gy_mask_src, int mode, float* partial_ws,
                                float* dw, int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y,
@@ -1971,8 +1992,8 @@ int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int 
   if (split) {
 #define PV2_WSPLIT_LAUNCH(XI_, GI_, SA_)                                                                   \
   do {                                                                                                     \
-    if (int e = set_lds(dconv_wgrad_split_kernel<XI_, GI_, SA_>, lds)) return e;                           \
-    hipLaunchKernelGGL((dconv_wgrad_split_kernel<XI_, GI_, SA_>), grid, dim3(kWgThreads), lds, s, x, c_x,  \
+    if (int e = set_lds(dconv_wgrad_split_kernel<XI_, GI_, SA_, ONE>, lds)) return e;                           \
+    hipLaunchKernelGGL((dconv_wgrad_split_kernel<XI_, GI_, SA_, ONE>), grid, dim3(kWgThreads), lds, s, x, c_x,  \
                        in_scale, in_shift, gy, c_g, gy_mask_src, g, n_tiles, n_nblk, n_cblk, partial_ws);  \
   } while (0)
     bool launched = true;
@@ -2008,6 +2029,29 @@ int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int 
   hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      partial_ws, n_slots, n_nblk, n_cblk, c_g, c_x, s_n, s_c, s_z, s_y, s_x, dw);
   return pv2::check_launch("dconv3_backward_weight");
+}
+
+extern "C" {
+
+int pv2_dconv3_backward_weight(const float* x, int b, int z, int y, int xx, int c_x,
+                               const float* in_scale, const float* in_shift, const float* gy,
+                               int c_g, const float* gy_mask_src, int mode, float* partial_ws,
+                               float* dw, int64_t s_n, int64_t s_c, int64_t s_z, int64_t s_y,
+                               int64_t s_x, pv2_stream_t stream) {
+  return g_one_term ? dconv3_backward_weight_t<true>(x, b, z, y, xx, c_x, in_scale, in_shift, gy, c_g, gy_mask_src,
+                                                     mode, partial_ws, dw, s_n, s_c, s_z, s_y, s_x, stream)
+                    : dconv3_backward_weight_t<false>(x, b, z, y, xx, c_x, in_scale, in_shift, gy, c_g,
+                                                      gy_mask_src, mode, partial_ws, dw, s_n, s_c, s_z, s_y, s_x,
+                                                      stream);
+}
+
+// Products of the dense convolutions on the LEADING bf16 piece of each operand only (one MFMA where the fp32
+// mode issues six): the reduced-precision training mode (the reference's enable_amp = True runs these layers
+// through the library's 16-bit convolutions, ponder/engines/train.py:183-196).  Operands are cut to bf16 by
+// truncation, sums stay fp32, results are stored as fp32.  Process-wide; 0 restores the fp32 products.
+int pv2_dconv3_set_one_term(int on) {
+  g_one_term = on != 0;
+  return PV2_OK;
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ from . import _lib, dense_conv as dc, rownorm, sidestream
 from .kernels import _ptr, _stream, workspace
 
 ENABLED = os.environ.get("PV2_DENSE_UNET", "1") != "0"
+DENSE_AMP = os.environ.get("PV2_DENSE_AMP", "1") != "0"
 
 
 class Spec:
@@ -138,9 +139,44 @@ def _bn_conv(L, st, x, bn, bn_w, bn_b, w):
     return out, stats
 
 
+def _one_term_mode():
+    """True inside a 16-bit autocast region (the reference's ``enable_amp = True``,
+    ponder/engines/train.py:183-196, runs this network through the library's 16-bit convolutions): the
+    node's products then use the leading bf16 piece of each operand only - one MFMA where the fp32 mode
+    issues six (pv2_dconv3_set_one_term; sums and results stay fp32).  PV2_DENSE_AMP=0: fp32 products
+    whatever the region says (rounds 4 - 5)."""
+    return (DENSE_AMP and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16))
+
+
+class _one_term:
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            _lib.check(_lib.lib().pv2_dconv3_set_one_term(1), "pv2_dconv3_set_one_term")
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.lib().pv2_dconv3_set_one_term(0)
+        return False
+
+
 class _DenseUNet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, spec, *params):
+        ctx.one_term = _one_term_mode()
+        with _one_term(ctx.one_term):
+            return _DenseUNet._forward(ctx, x0, spec, *params)
+
+    @staticmethod
+    def backward(ctx, g):
+        with _one_term(ctx.one_term):
+            return _DenseUNet._backward(ctx, g)
+
+    @staticmethod
+    def _forward(ctx, x0, spec, *params):
         L = _lib.lib()
         x0 = dc._cl(x0)
         st = _stream(x0)
@@ -171,7 +207,7 @@ class _DenseUNet(torch.autograd.Function):
         return x
 
     @staticmethod
-    def backward(ctx, g):
+    def _backward(ctx, g):
         L = _lib.lib()
         spec = ctx.spec
         tensors = ctx.saved_tensors

@@ -103,3 +103,40 @@ def test_fused_dense_unet_vs_stock_modules_float64(device):
             assert got[name].grad.abs().max() < 1e-3 and p.grad.abs().max() < 1e-9, name
             continue
         assert rel(got[name].grad, p.grad) < 2e-4, name
+
+
+def test_fused_dense_unet_under_autocast_uses_bf16_products(device):
+    """Round 6: inside a 16-bit autocast region (the reference's ``enable_amp = True``) the node's products
+    run on the leading bf16 piece of each operand (pv2_dconv3_set_one_term): results within bf16 rounding of
+    the fp32 node's (the operands lose 16 mantissa bits, sums stay fp32), every gradient finite and pointing
+    the same way; outside the region the fp32 products are back, bit for bit."""
+    from ponderv2_amd import dense_unet
+
+    net = _net(3, device)
+    torch.manual_seed(7)
+    x0 = torch.relu(torch.randn(2, 32, 8, 16, 32)).to(device).contiguous(memory_format=torch.channels_last_3d)
+    probe = torch.randn(2, 32, 8, 16, 32, device=device)
+
+    def run(amp):
+        net.zero_grad()
+        xd = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            assert dense_unet._one_term_mode() == amp
+            out = net(None, first=xd)
+        (out.float() * probe).sum().backward()
+        return out.detach().float(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()
+                                                       if p.grad is not None}
+
+    ref = run(False)
+    amp = run(True)
+    again = run(False)
+    assert torch.equal(ref[0], again[0]) and torch.equal(ref[1], again[1])   # the switch is back at fp32
+    err = (amp[0] - ref[0]).abs().max().item() / ref[0].abs().max().item()
+    assert 1e-5 < err < 3e-2, err        # bf16 operands: visibly not fp32, and within a few roundings
+    cos = torch.nn.functional.cosine_similarity(amp[1].flatten(), ref[1].flatten(), dim=0).item()
+    assert cos > 0.999, cos
+    for k, g in amp[2].items():
+        assert torch.isfinite(g).all(), k
+        if g.numel() > 64 and ref[2][k].abs().max() > 1e-6 and not k.endswith("upsample.bias"):
+            c = torch.nn.functional.cosine_similarity(g.flatten(), ref[2][k].flatten(), dim=0).item()
+            assert c > 0.99, (k, c)
