@@ -80,7 +80,12 @@ class ConvBNFunction(torch.autograd.Function):
             dw = torch.empty((c_out, k, c_in), dtype=torch.float32, device=dev)
             floats = int(_lib.lib().pv2_spconv_wgrad_partial_floats(c_in, c_out, g.n_tiles_w))
             if sidestream.active(grad_out) and sidestream.safe_leaf(weight_okc):
-                side = sidestream.native_fork(dev, (feats, dy, dw, rb))   # (rb: the pair lists the kernels read)
+                # (rb: the pair lists the kernels read.  NOT dw: a second reference to the gradient keeps
+                # autograd's AccumulateGrad from adopting it - it then CLONES it on the training stream, at
+                # once, while the side stream may not have written it yet.  Found in round 6 as an intermittent
+                # garbage weight gradient on the output-stationary route, whose short grad-input lets the
+                # training stream reach the accumulation first; ``.grad`` itself keeps dw alive until the join.)
+                side = sidestream.native_fork(dev, (feats, dy, rb))
                 part = K.workspace("wgrad", dev, floats, stream=side)
             else:
                 part = K.workspace("wgrad", dev, floats)

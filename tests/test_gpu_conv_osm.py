@@ -190,8 +190,9 @@ def test_conv_bn_unit_on_the_osm_route_equals_the_product_row_route(device, kind
             outs[mode] = _unit_case(kind)
     finally:
         _lib.lib().pv2_debug_set_osm(2, -1, -1, 0)
-    for a, b in zip(outs[1], outs[0]):
-        assert _rel(a, b) < 3e-5, _rel(a, b)
+    names = ("out", "dx", "dw", "d bn weight", "d bn bias", "d residual", "running_mean", "running_var")
+    for name, a, b in zip(names, outs[1], outs[0]):
+        assert _rel(a, b) < 3e-5, (name, _rel(a, b), float(a.abs().max()), float(b.abs().max()))
 
 
 def _unit_case(kind):
