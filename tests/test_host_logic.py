@@ -853,6 +853,7 @@ def test_gradient_slabs_partition_the_executor_arena_in_completion_order():
             tensors += [w, bw, bb]
             u.gsum_off = arena.reserve(2 * c_out)
             u.dw_off = arena.reserve(w.numel())
+            u.affine_in_arena = True      # (leaf BatchNorm pairs: their gradients are arena members)
         plan.units.append(u)
     hook = Hook()
     members, spans, units = sn._gradient_slabs(plan, tensors, hook, arena)
@@ -868,6 +869,17 @@ def test_gradient_slabs_partition_the_executor_arena_in_completion_order():
     for t, off, n in members:
         assert t.numel() == n and spans[-1][0] <= off and off + n <= arena.size
         assert sum(lo <= off and off + n <= hi for lo, hi in spans) == 1          # inside exactly one slab
+    # round 6: a COMPUTED BatchNorm pair (SpUNet-v1m3's modulated affine: not a leaf) keeps its gradient in a
+    # second arena - such a unit contributes its conv weight only, and its slab starts at the weight
+    pd = plan.units[4]
+    assert pd.kind == UNET_CONV_BN
+    pd.affine_in_arena = False
+    members2, spans2, units2 = sn._gradient_slabs(plan, tensors, hook, arena)
+    assert len(members2) == 3 * len(convs) - 2
+    assert all(off != pd.gsum_off and off != pd.gsum_off + pd.c_out for _, off, _ in members2)
+    for t, off, n in members2:
+        assert sum(lo <= off and off + n <= hi for lo, hi in spans2) == 1
+    pd.affine_in_arena = True
     # too few conv units, or a reducer that declines: no slabs
     assert sn._gradient_slabs(plan, tensors, type("No", (), {"slab_elems": 1, "wants": lambda s, t: False})(),
                               arena) is None
