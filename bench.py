@@ -1060,9 +1060,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": (f"{args.amp} autocast entered around the whole model (reference enable_amp=True): "
-                      f"sparse backbone on the {args.amp} MFMA kernels (fp32 accumulation, statistics "
-                      "and master weights); dense UNet3D, ray march and losses f32 on the hand-written "
-                      "kernels (above the reference's 16-bit precision there)"
+                      f"sparse backbone on the {args.amp} MFMA kernels through the native executor (fp32 "
+                      "accumulation, statistics and master weights); dense UNet3D products on the leading "
+                      "bf16 piece of each operand, fp32 sums and results (csrc/dense_conv.hip one-term mode); "
+                      "ray march and losses f32 on the hand-written kernels (above the reference's 16-bit "
+                      "precision there)"
                       if args.amp else
                       "f32" if args.dense_dtype == "float32" else
                       f"f32 sparse conv + render head; {args.dense_dtype} autocast for the dense "
