@@ -91,12 +91,17 @@ class FoldedVolume:
 
         return library_conv(self.conv, self.pre)
 
+    def x5(self):
+        """The (B,Z,Y,X,32) channels-last fp32 view of the activations."""
+        widen = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+        x5 = widen(self.pre.permute(0, 2, 3, 4, 1))   # (float64 stays: the host doubles of the tests)
+        return x5 if x5.is_contiguous() else x5.contiguous()
+
     def rows(self):
         """(x5, wfp): the (B,Z,Y,X,32) channels-last fp32 view of the activations and the
         [C_out, 40] matrix [Wf | bf | 0] (built by torch ops: gradients reach the module)."""
         widen = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
-        x5 = widen(self.pre.permute(0, 2, 3, 4, 1))   # (float64 stays: the host doubles of the tests)
-        x5 = x5 if x5.is_contiguous() else x5.contiguous()
+        x5 = self.x5()
         conv = self.conv
         wf = widen(conv.weight.reshape(conv.out_channels, conv.in_channels)).to(x5.dtype)
         bf = (widen(conv.bias).to(x5.dtype) if conv.bias is not None
@@ -401,36 +406,61 @@ class _FieldRenderFolded(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_grad, _g_weights, g_comp):
-        (wfp, origins, dirs, starts, deltas, MW, W1, A, inv_s, sdf, alpha, vals, sf, sh0, sa1, sq,
-         weights, Mt, gval, gder, jrows) = ctx.saved_tensors
-        L = _lib.lib()
-        B, Z, Y, X, C = ctx.vol_shape
-        R, S = starts.shape
-        N = R * S
-        dev = wfp.device
-        st = _stream(wfp)
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        g_comp = (torch.zeros((R, NV), dtype=torch.float32, device=dev) if g_comp is None
-                  else g_comp.contiguous())
-        g_sdf = None if g_sdf is None else g_sdf.contiguous()
-        g_grad = None if g_grad is None else g_grad.contiguous()
-        gw = new(R, S)
-        _lib.check(L.pv2_raymarch_accumulate_backward(_ptr(weights), _ptr(vals), _ptr(g_comp), R, S,
-                                                      NV, _ptr(gw), None, st),
-                   "pv2_raymarch_accumulate_backward")
-        g_alpha = new(R, S)
-        _lib.check(L.pv2_raymarch_weights_backward(_ptr(alpha), _ptr(gw), R, S, _ptr(g_alpha), st),
-                   "pv2_raymarch_weights_backward")
-        gfeat, gvec, gz, tmat = new(N, FS + F2), new(N, 4), new(N, 2 * H), new(N, H)
-        gq, gh, gy, sums = new(N, FS), new(N, 68), new(N, 4), new(NSUM)
-        W1gt = W1[1:].t().contiguous()
-        Wc1t = MW[H:].t().contiguous()
-        _lib.check(L.pv2_neus_field_backward_rows(
-            _ptr(jrows), _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S, _ptr(MW),
-            _ptr(W1), _ptr(Mt), _ptr(W1gt), _ptr(Wc1t), _ptr(A), _ptr(inv_s), ctx.norm[0],
-            ctx.norm[1], _ptr(sdf), _ptr(vals), _ptr(sh0), _ptr(weights), _ptr(g_alpha), _ptr(g_sdf),
-            _ptr(g_grad), _ptr(g_comp), _ptr(gfeat), _ptr(gvec), _ptr(gz), _ptr(tmat), _ptr(gq),
-            _ptr(gh), _ptr(gy), _ptr(sums), st), "pv2_neus_field_backward_rows")
+        g_vol, params_fn, g_inv_s = _folded_backward(ctx.saved_tensors, ctx.vol_shape, ctx.norm, ctx.inv_s_shape,
+                                                     g_sdf, g_grad, g_comp, ctx.needs_input_grad[0],
+                                                     ctx.needs_input_grad[1])
+        g = params_fn()
+        return (g_vol, g["wfp"], None, None, None, None, g["MW"], g["c0"], g["bc1"], g["W1"], g["b1"], g["A"],
+                g["b_rgb"], g_inv_s, None, None)
+
+
+def _folded_backward(saved, vol_shape, norm, inv_s_shape, g_sdf, g_grad, g_comp, need_vol, need_wfp):
+    """The backward of the folded head in two parts: what the CRITICAL chain needs - the gradient of the
+    32-channel volume, on the caller's stream - and a closure that computes every PARAMETER gradient (the
+    A^T B reductions over the saved rows and what hangs off them), which may run on another stream.
+    -> (g_vol or None, params_fn() -> dict of gradients of the collapsed parameters, g_inv_s)."""
+    (wfp, origins, dirs, starts, deltas, MW, W1, A, inv_s, sdf, alpha, vals, sf, sh0, sa1, sq,
+     weights, Mt, gval, gder, jrows) = saved
+    L = _lib.lib()
+    B, Z, Y, X, C = vol_shape
+    R, S = starts.shape
+    N = R * S
+    dev = wfp.device
+    st = _stream(wfp)
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    g_comp = (torch.zeros((R, NV), dtype=torch.float32, device=dev) if g_comp is None
+              else g_comp.contiguous())
+    g_sdf = None if g_sdf is None else g_sdf.contiguous()
+    g_grad = None if g_grad is None else g_grad.contiguous()
+    gw = new(R, S)
+    _lib.check(L.pv2_raymarch_accumulate_backward(_ptr(weights), _ptr(vals), _ptr(g_comp), R, S,
+                                                  NV, _ptr(gw), None, st),
+               "pv2_raymarch_accumulate_backward")
+    g_alpha = new(R, S)
+    _lib.check(L.pv2_raymarch_weights_backward(_ptr(alpha), _ptr(gw), R, S, _ptr(g_alpha), st),
+               "pv2_raymarch_weights_backward")
+    gfeat, gvec, gz, tmat = new(N, FS + F2), new(N, 4), new(N, 2 * H), new(N, H)
+    gq, gh, gy, sums = new(N, FS), new(N, 68), new(N, 4), new(NSUM)
+    W1gt = W1[1:].t().contiguous()
+    Wc1t = MW[H:].t().contiguous()
+    _lib.check(L.pv2_neus_field_backward_rows(
+        _ptr(jrows), _ptr(origins), _ptr(dirs), _ptr(starts), _ptr(deltas), R, S, _ptr(MW),
+        _ptr(W1), _ptr(Mt), _ptr(W1gt), _ptr(Wc1t), _ptr(A), _ptr(inv_s), norm[0],
+        norm[1], _ptr(sdf), _ptr(vals), _ptr(sh0), _ptr(weights), _ptr(g_alpha), _ptr(g_sdf),
+        _ptr(g_grad), _ptr(g_comp), _ptr(gfeat), _ptr(gvec), _ptr(gz), _ptr(tmat), _ptr(gq),
+        _ptr(gh), _ptr(gy), _ptr(sums), st), "pv2_neus_field_backward_rows")
+    # the folded convolution: gradient of the 32-channel volume (the chain the rest of the backward waits for)
+    g_vol = None
+    if need_vol:
+        wf = wfp[:, :KX]
+        gx = _gemm_nt(gfeat, wf.t().contiguous())              # gfeat . Wf      [N, 32]
+        qx = _gemm_nt(sq, wf[:FS].t().contiguous())            # q . Wf_sdf      [N, 32]
+        g_vol = zeros_by_kernel(vol_shape, torch.float32, dev)
+        _lib.check(L.pv2_neus_fold_scatter(
+            B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), R, S, norm[0], norm[1],
+            _ptr(gx), _ptr(gvec), _ptr(qx), _ptr(g_vol), st), "pv2_neus_fold_scatter")
+
+    def params_fn():
         # head weight gradients: exactly as in _FieldRender.backward
         g_MW = zeros_by_kernel((2 * H, FS), torch.float32, dev)
         _gemm_tn_into(gz, sf, g_MW)
@@ -447,25 +477,118 @@ class _FieldRenderFolded(torch.autograd.Function):
         g_A = torch.cat([g_Ap[:3, COL_G:COL_G + 3], g_Ap[:3, COL_F2:COL_F2 + F2],
                          g_Ap[:3, COL_GEO:COL_GEO + G],
                          gy.reshape(R, S, 4).sum(1)[:, :3].t().mm(dirs)], dim=1)
-        # the folded convolution: gradient of the 32-channel volume and of [Wf | bf]
-        g_vol = g_wfp = None
-        if ctx.needs_input_grad[0]:
-            wf = wfp[:, :KX]
-            gx = _gemm_nt(gfeat, wf.t().contiguous())              # gfeat . Wf      [N, 32]
-            qx = _gemm_nt(sq, wf[:FS].t().contiguous())            # q . Wf_sdf      [N, 32]
-            g_vol = zeros_by_kernel(ctx.vol_shape, torch.float32, dev)
-            _lib.check(L.pv2_neus_fold_scatter(
-                B, Z, Y, X, C, _ptr(origins), _ptr(dirs), _ptr(starts), R, S, ctx.norm[0], ctx.norm[1],
-                _ptr(gx), _ptr(gvec), _ptr(qx), _ptr(g_vol), st), "pv2_neus_fold_scatter")
-        if ctx.needs_input_grad[1]:
+        g_wfp = None
+        if need_wfp:
             g_wfp = zeros_by_kernel((FS + F2, KXP), torch.float32, dev)
             _gemm_tn_into(gfeat, gval, g_wfp)                      # gfeat^T [xt, s]
             y = (gvec[:, :3, None] * gder).sum(1)                  # sum_a gg_a d[xt, s]/dp_a  [N, 40]
             _gemm_tn_into(sq, y.contiguous(), g_wfp[:FS])          # + q^T (...) on the SDF rows
-        return (g_vol, g_wfp, None, None, None, None, g_MW, sums[SUM_C0:SUM_C0 + H].clone(),
-                sums[SUM_BC1:SUM_BC1 + H].clone(), g_W1, sums[SUM_B1:SUM_B1 + 1 + G].clone(), g_A,
-                sums[SUM_RGB:SUM_RGB + 3].clone(), sums[SUM_INVS].reshape(ctx.inv_s_shape), None,
-                None)
+        return dict(wfp=g_wfp, MW=g_MW, c0=sums[SUM_C0:SUM_C0 + H].clone(),
+                    bc1=sums[SUM_BC1:SUM_BC1 + H].clone(), W1=g_W1, b1=sums[SUM_B1:SUM_B1 + 1 + G].clone(),
+                    A=g_A, b_rgb=sums[SUM_RGB:SUM_RGB + 3].clone())
+
+    params_fn.reads = (gz, sf, tmat, gq, gh, sa1, gy, vals, sums, gfeat, gval, gvec, gder, sq, dirs, W1, MW)
+    return g_vol, params_fn, sums[SUM_INVS].reshape(inv_s_shape)
+
+
+class _SavedProxy:
+    """Stands in for ``ctx`` when one Function's forward body is reused inside another: records what it
+    would have saved / set."""
+
+    def __init__(self, real):
+        self._real, self.saved = real, ()
+
+    def save_for_backward(self, *tensors):
+        self.saved = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        self._real.mark_non_differentiable(*tensors)
+
+
+LEAVES_ENABLED = os.environ.get("PV2_HEAD_LEAVES", "1") != "0"
+
+
+def _head_leaves(field, conv):
+    """The nn.Parameters behind the collapsed head and the folded convolution, in the order
+    ``_FieldRenderFoldedLeaves`` takes them - or None when one of them is not a plain fp32 device leaf."""
+    sd, rd = field.sdf_decoder, field.rgb_decoder
+    ps = [conv.weight, conv.bias, sd.lin0.weight, sd.lin0.bias, sd.fc_c[0].weight, sd.fc_c[0].bias,
+          sd.fc_c[1].weight, sd.fc_c[1].bias, sd.lin1.weight, sd.lin1.bias, rd.lin0.weight, rd.lin0.bias,
+          rd.fc_c[0].weight, rd.fc_c[0].bias, sd.fc_p.weight, sd.fc_p.bias, rd.fc_p.weight, rd.fc_p.bias]
+    if any(p is None or not isinstance(p, torch.nn.Parameter) or not p.is_cuda or p.dtype != torch.float32
+           or not p.requires_grad for p in ps):
+        return None
+    return ps
+
+
+def _collapse_values(ps):
+    """``collapse`` without a graph, from the leaves of ``_head_leaves`` (+ the folded convolution's
+    [Wf | bf | 0]): the same torch products in the same order."""
+    (cw, cb, W0, b0, Wc0, bc0, Wc1, bc1, W1, b1, Wr1, br1, Wrc, brc) = [p.detach() for p in ps[:14]]
+    with torch.no_grad():
+        MW = torch.cat([W0.mm(Wc0), Wc1], dim=0)
+        c0 = W0.mv(bc0) + b0
+        A = Wr1.mm(Wrc)
+        b_rgb = Wr1.mv(brc) + br1
+        wf = cw.reshape(cw.shape[0], cw.shape[1])
+        pad = torch.zeros((cw.shape[0], KXP - KX - 1), dtype=wf.dtype, device=wf.device)
+        wfp = torch.cat([wf, cb[:, None], pad], dim=1)
+    return dict(MW=MW, c0=c0, bc1=bc1, W1=W1, b1=b1, A=A, b_rgb=b_rgb, wfp=wfp)
+
+
+class _FieldRenderFoldedLeaves(torch.autograd.Function):
+    """``_FieldRenderFolded`` with the parameter COLLAPSE inside the node (round 6): its inputs are the
+    nn.Parameters themselves, so (i) the ~25 small torch launches of ``collapse`` / ``FoldedVolume.rows`` and
+    of their autograd backward are gone from the training stream, and (ii) every parameter gradient of the
+    head - four A^T B reductions over the 135 k saved rows, the folded convolution's two, the products that
+    carry them back through the collapse - is a LEAF gradient that feeds nothing until the optimizer: it
+    runs on the backward side stream (sidestream.py), beside the chain that carries the volume's gradient
+    on to the projection network.  Same kernels, same products, same numbers as the composite."""
+
+    @staticmethod
+    def forward(ctx, x5, inv_s, cp, geom, *leaves):
+        origins, dirs, starts, deltas, norm_pts, norm_div = geom
+        proxy = _SavedProxy(ctx)
+        out = _FieldRenderFolded.forward(proxy, x5, cp["wfp"], origins, dirs, starts, deltas, cp["MW"], cp["c0"],
+                                         cp["bc1"], cp["W1"], cp["b1"], cp["A"], cp["b_rgb"], inv_s, norm_pts,
+                                         norm_div)
+        ctx.n_inner = len(proxy.saved)
+        ctx.save_for_backward(*proxy.saved, *leaves)
+        ctx.vol_shape, ctx.norm, ctx.inv_s_shape = proxy.vol_shape, proxy.norm, proxy.inv_s_shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_grad, _g_weights, g_comp):
+        from . import sidestream
+
+        saved = ctx.saved_tensors
+        inner, leaves = saved[:ctx.n_inner], saved[ctx.n_inner:]
+        g_vol, params_fn, g_inv_s = _folded_backward(inner, ctx.vol_shape, ctx.norm, ctx.inv_s_shape, g_sdf, g_grad,
+                                                     g_comp, ctx.needs_input_grad[0], True)
+        (cw, cb, W0, b0, Wc0, bc0, Wc1, bc1, W1, b1, Wr1, br1, Wrc, brc, p0, p1, p2, p3) = leaves
+
+        def leaf_gradients():
+            g = params_fn()
+            top = g["MW"][:H]
+            g_W0 = torch.addmm(torch.outer(g["c0"], bc0), top, Wc0.t())
+            g_Wr1 = torch.addmm(torch.outer(g["b_rgb"], brc), g["A"], Wrc.t())
+            zeros = torch.zeros(p0.numel() + p1.numel() + p2.numel() + p3.numel(), dtype=torch.float32,
+                                device=cw.device)
+            zs, o = [], 0
+            for p in (p0, p1, p2, p3):     # fc_p(points) * 0.0 of the reference: an exact zero gradient
+                zs.append(zeros[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+            return (g["wfp"][:, :KX].reshape(cw.shape).contiguous(), g["wfp"][:, KX].contiguous(),
+                    g_W0, g["c0"], W0.t().mm(top), W0.t().mv(g["c0"]), g["MW"][H:], g["bc1"], g["W1"], g["b1"],
+                    g_Wr1, g["b_rgb"], Wr1.t().mm(g["A"]), Wr1.t().mv(g["b_rgb"]), *zs)
+
+        ref = g_comp if g_comp is not None else inner[0]
+        if sidestream.active(ref) and all(sidestream.safe_leaf(p) for p in leaves):
+            grads = sidestream.fork(leaf_gradients, params_fn.reads + tuple(leaves))
+        else:
+            grads = leaf_gradients()
+        return (g_vol, g_inv_s, None, None) + tuple(grads)
 
 
 def field_render_folded(x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
@@ -473,6 +596,12 @@ def field_render_folded(x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1,
     """``field_render`` for a ``FoldedVolume`` (``x5, wfp = volume.rows()``)."""
     return _FieldRenderFolded.apply(x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A,
                                     b_rgb, inv_s, norm_pts, norm_div)
+
+
+def field_render_folded_leaves(x5, inv_s, cp, geom, *leaves):
+    """``field_render_folded`` with the collapse inside the node (``cp = _collapse_values(leaves)``):
+    the parameter gradients leave as the gradients of the modules' own parameters."""
+    return _FieldRenderFoldedLeaves.apply(x5, inv_s, cp, geom, *leaves)
 
 
 def field_render(vol5, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
@@ -545,14 +674,24 @@ def _render_outputs(model, ray_bundle, volume_feature):
     field, smp = model.field, model.sampler
     B = getattr(ray_bundle, "num_scenes", 1)
     folded = isinstance(volume_feature[0], FoldedVolume)
+    leaves = wfp = None
     if folded:
-        vol5, wfp = volume_feature[0].rows()
+        vol5 = volume_feature[0].x5()
+        if LEAVES_ENABLED and model.training and vol5.is_cuda and vol5.dtype == torch.float32:
+            leaves = _head_leaves(field, volume_feature[0].conv)
+        if leaves is None:
+            vol5, wfp = volume_feature[0].rows()
     else:
-        vol5, wfp = _vol5(volume_feature, B).float(), None
+        vol5 = _vol5(volume_feature, B).float()
     o, d = ray_bundle.origins.float(), ray_bundle.directions.float()
     R = o.shape[0]
     dev = o.device
-    cp = collapse(field)
+    if leaves is not None:
+        # the collapse inside the node, every parameter gradient a leaf gradient on the side stream
+        cp = _collapse_values(leaves)
+        wfp = cp["wfp"]
+    else:
+        cp = collapse(field)
     S0, n_imp = smp.num_samples, smp.num_samples_importance
     ini, pdf = smp.initial_sampler, smp.pdf_sampler
     t_rand = u_rand = None
@@ -573,7 +712,10 @@ def _render_outputs(model, ray_bundle, volume_feature):
     inv_s = field.deviation_network.get_variance()
     head = (o, d, starts, deltas, cp["MW"], cp["c0"], cp["bc1"], cp["W1"], cp["b1"], cp["A"],
             cp["b_rgb"], inv_s, field.norm_pts, 1.0 + field.norm_padding + 10e-4)
-    if folded:
+    if leaves is not None:
+        sdf, grad, weights, comp = field_render_folded_leaves(
+            vol5, inv_s, cp, (o, d, starts, deltas, field.norm_pts, 1.0 + field.norm_padding + 10e-4), *leaves)
+    elif folded:
         sdf, grad, weights, comp = field_render_folded(vol5, wfp, *head)
     else:
         sdf, grad, weights, comp = field_render(vol5, *head)

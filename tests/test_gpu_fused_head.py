@@ -187,6 +187,8 @@ def test_model_folds_the_final_convolution_by_default_and_unfolded_results_agree
     seen = []
     orig = fhd.field_render_folded
     monkeypatch.setattr(fhd, "field_render_folded", lambda *a: (seen.append(1), orig(*a))[1])
+    orig_leaves = fhd.field_render_folded_leaves      # the training route: collapse inside the node
+    monkeypatch.setattr(fhd, "field_render_folded_leaves", lambda *a: (seen.append(1), orig_leaves(*a))[1])
 
     def step(fold):
         monkeypatch.setattr(fhd, "FOLD_ENABLED", fold)
@@ -225,3 +227,42 @@ def test_model_folds_the_final_convolution_by_default_and_unfolded_results_agree
         den += float(d.pow(2).sum())
     assert not bad, bad
     assert (num / den) ** 0.5 <= max(5e-3, 6.0 * (num_floor / den) ** 0.5), (num, num_floor, den)
+
+
+def test_head_parameter_gradients_as_leaf_gradients_equal_the_collapse_graph(device, monkeypatch):
+    """The training route (``_FieldRenderFoldedLeaves``: the collapse inside the node, the 18 head
+    parameters' gradients computed on the side stream) against the torch-op collapse graph
+    (``PV2_HEAD_LEAVES=0``): the same losses, the same set of gradients, every tensor within the
+    step's own run-to-run noise."""
+    import golden_cases as gc
+    from ponderv2_amd import fused_head as fhd
+
+    def step(leaves):
+        monkeypatch.setattr(fhd, "LEAVES_ENABLED", leaves)
+        model, batch = gc.small_indoor(device)
+        torch.manual_seed(0)
+        out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v) for k, v in out.items()},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    ref_l, ref_g = step(False)
+    again_l, again_g = step(False)
+    new_l, new_g = step(True)
+    for k, v in ref_l.items():
+        assert abs(new_l[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, v, new_l[k])
+    assert ref_g.keys() == new_g.keys()
+    head = [n for n in ref_g if "field" in n or "proj" in n or "final" in n]
+    assert len(head) >= 16, head
+    bad = {}
+    for name, g0 in ref_g.items():
+        ref = g0.cpu().numpy()
+        if not float(g0.abs().max()):
+            assert not float(new_g[name].abs().max()), name      # the fc_p zeros stay exact zeros
+            continue
+        floor = gc.rel_err(again_g[name], ref)
+        err = gc.rel_err(new_g[name], ref)
+        if not err <= max(2e-2 if name not in head else 2e-3, 10.0 * floor):
+            bad[name] = (err, floor)
+    assert not bad, bad
