@@ -10,6 +10,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libponderv2_hip.so")
+if os.environ.get("PV2_PROBE_LIB"):   # timing probes only (tools/r06_fake_split.sh): another build of the same sources
+    LIB_PATH = os.path.join(_HERE, "lib", os.environ["PV2_PROBE_LIB"])
 
 PAIR_TILE = 32      # PV2_PAIR_TILE
 WGRAD_TILE = 512    # PV2_WGRAD_TILE

@@ -12,13 +12,25 @@ void set_error(const char* msg) {
 }  // namespace pv2
 
 namespace pv2 {
+// 16-byte stores over the aligned body, single words either side of it (round 6: the 134 MB volume gradient of
+// the render head took 96 us with one word per lane and trip - store-issue bound at 1.4 TB/s)
 __global__ void zero_words_kernel(uint32_t* p, int64_t n32) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += stride) p[i] = 0u;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t head = (int64_t)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) >> 2);
+  if (head > n32) head = n32;
+  if (tid < head) p[tid] = 0u;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  const int64_t n4 = (n32 - head) >> 2;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = tid; i < n4; i += stride) q[i] = z;
+  const int64_t done = head + 4 * n4;
+  if (tid < n32 - done) p[done + tid] = 0u;
 }
 int zero_words(void* p, int64_t n32, hipStream_t s) {
   if (n32 <= 0) return PV2_OK;
-  hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(n32, 256)), dim3(256), 0, s, (uint32_t*)p, n32);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for((n32 + 3) / 4 + 8, 256)), dim3(256), 0, s, (uint32_t*)p,
+                     n32);
   return check_launch("zero_words");
 }
 }  // namespace pv2

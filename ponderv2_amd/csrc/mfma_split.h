@@ -36,7 +36,11 @@ __device__ __forceinline__ unsigned pack_hi(float a, float b) {
 }
 // x minus its bf16 truncation (exact)
 __device__ __forceinline__ float bf16_rest(float x) {
+#ifdef PV2_FAKE_SPLIT   // timing probe only (tools/r06_fake_split.sh): what the kernels would cost with operands cut beforehand
+  return x;
+#else
   return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+#endif
 }
 
 struct Split8 {

@@ -133,11 +133,11 @@ __device__ __forceinline__ int entry_of(const RowState<TS>& st, int k) {
   }
 }
 
-// next (up to) four pair indices of the row, in ascending offset order; -1 past the end
-template <int TS>
-__device__ __forceinline__ void next4(RowState<TS>& st, int (&p)[4]) {
+// next (up to) U pair indices of the row, in ascending offset order; -1 past the end
+template <int TS, int U>
+__device__ __forceinline__ void next_entries(RowState<TS>& st, int (&p)[U]) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < U; ++u) {
     if (st.mask) {
       const int k = __builtin_ctz(st.mask);
       st.mask &= st.mask - 1;
@@ -153,6 +153,10 @@ __device__ __forceinline__ void next4(RowState<TS>& st, int (&p)[4]) {
 // g = out * (act > 0), xhat = (yprod - mean) * invstd - what col_partials_kernel<1> computes in a pass of
 // its own over three matrices.  `sy` = the producer's conv output, `so` = its activation (null: no ReLU),
 // `smi` = its {mean, invstd}.
+#ifndef PV2_REDUCE_AHEAD
+#define PV2_REDUCE_AHEAD 4
+#endif
+constexpr int kReduceAhead = PV2_REDUCE_AHEAD;
 template <int TS, int NJ, int STATS>
 __global__ __launch_bounds__(256) void row_reduce_kernel(
     const float* __restrict__ T, const int32_t* __restrict__ pos, int64_t pos_stride, int K, int c,
@@ -233,13 +237,17 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
       accA[j] = ia;
       accB[j] = ib;
     }
+    // U product rows per row and trip, all requested before the first is added.  (Round 6: U = 8 - most rows
+    // done in ONE trip, the longest in four instead of seven - measured 20.8 against 20.0 us per launch over
+    // the step's 116 reduces, 18.5 against 18.3 ms per step: the kernel is not bound by its trips.  4 stays.)
+    constexpr int U = NJ == 1 ? kReduceAhead : 4;
     while (sa.mask | sb.mask) {   // (uniform within the team; teams of a wave diverge)
-      int pa[4], pb[4];
-      next4<TS>(sa, pa);
-      next4<TS>(sb, pb);
-      float4 vA[4][NJ], vB[4][NJ];
+      int pa[U], pb[U];
+      next_entries<TS, U>(sa, pa);
+      next_entries<TS, U>(sb, pb);
+      float4 vA[U][NJ], vB[U][NJ];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int col = l + j * TS;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(
           vB[u][j] = (pb[u] >= 0 && col < c4n) ? T4[(int64_t)pb[u] * c4n + col] : zero;
         }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if (pa[u] >= 0) add4(accA[j], vA[u][j]);   // (adding +0 would turn a -0 sum into +0)

@@ -359,6 +359,7 @@ class _FieldRenderFolded(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x5, wfp, origins, dirs, starts, deltas, MW, c0, bc1, W1, b1, A, b_rgb, inv_s,
                 norm_pts, norm_div):
+        ctx.set_materialize_grads(False)   # (the non-differentiable weights output: no [R, S] of zeros per step)
         _require_device(x5, wfp, origins, dirs, starts, deltas, MW, W1, A)
         _check_dims()
         L = _lib.lib()
@@ -503,6 +504,9 @@ class _SavedProxy:
 
     def mark_non_differentiable(self, *tensors):
         self._real.mark_non_differentiable(*tensors)
+
+    def set_materialize_grads(self, value):
+        self._real.set_materialize_grads(value)
 
 
 LEAVES_ENABLED = os.environ.get("PV2_HEAD_LEAVES", "1") != "0"

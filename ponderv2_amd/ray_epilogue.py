@@ -108,6 +108,7 @@ class _RayLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, comp, sdf, grad, Wc, bc, Wl, bl, Wp, bp, starts, depth_gt, rgb_gt, sem_gt, cfg):
+        ctx.set_materialize_grads(False)   # (eight outputs, usually only the total carries a gradient: no zero fills)
         L = _lib.lib()
         dev = comp.device
         st = _stream(comp)

@@ -108,6 +108,17 @@ for e in events:
             key = chain(e)
             copies[key] += 1
             times[key] += k.duration
+# fills and device-to-device copies: every one is a launch on the training stream's chain
+small = collections.Counter()
+for e in events:
+    for k in e.kernels:
+        if "FillFunctor" in k.name or "Memcpy" in k.name or "Memset" in k.name or "copyBuffer" in k.name \
+                or "fillBuffer" in k.name:
+            small[("fill  " if ("Fill" in k.name or "Memset" in k.name or "fillBuffer" in k.name) else "copy  ")
+                  + chain(e)] += 1
+print("fills / copies by caller (count):")
+for key, n in small.most_common(60):
+    print("  %3d  %s" % (n, key[:250]))
 print("copy / gather / big elementwise kernels by caller (us, count):")
 for key, t in times.most_common(24):
     print("  %8.1f %3d  %s" % (t, copies[key], key[:230]))
