@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void field_fwd_kernel(
 constexpr int kSumC0 = 0, kSumBc1 = kH, kSumV1 = 2 * kH, kSumB1 = 3 * kH, kSumQ = 3 * kH + kGH,
               kSumRgb = kSumQ + kF, kSumInvS = kSumRgb + 4, kSumTotal = kSumInvS + 4;
 
-__global__ __launch_bounds__(64) void field_bwd_kernel(
+__global__ __launch_bounds__(64, 2) void field_bwd_kernel(
     Vol vol, Head P, const float* __restrict__ origins, const float* __restrict__ dirs,
     const float* __restrict__ starts, const float* __restrict__ deltas, int64_t n_total, int S,
     int norm_pts, float norm_div, const float* __restrict__ sdf_in, const float* __restrict__ vals,
@@ -461,8 +461,12 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
   // tile order by sums_reduce_kernel: 4 224 tiles x ~520 float atomics on the same ~520 addresses were 220 of
   // the kernel's 633 us, and made the sums depend on the order of arrival)
   float* sums = tile_sums + (int64_t)blockIdx.x * kSumTotal;
-  __shared__ __attribute__((aligned(16))) float bufA[32 * kLd];
-  __shared__ __attribute__((aligned(16))) float bufB[32 * kLd];
+  // ONE 32 x 132 tile buffer (round 6; there were two): with 17 KB + 2 KB of LDS and <= 256 registers TWO waves
+  // share a SIMD - the kernel is a chain of L2 trips (weight rows inside the product loops, row gathers, 2.6 KB
+  // of stores per sample) with 14 % of its time on the matrix pipe, and one wave per SIMD hides none of it.
+  // Columns 0..63 hold d geo and 64..127 gq for the first two products; the two operands of the last product
+  // pass through it one after the other (ga1 waits in its accumulator registers).
+  __shared__ __attribute__((aligned(16))) float buf[32 * kLd];
   __shared__ float s_pt[32 * 4];
   __shared__ float s_gg[32 * 4];
   __shared__ float s_coef[32 * 4];
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
         gfeat[n * kC + kF + lane] = gf2;
         gh[n * kGH + 1 + lane] = ggeo;
       }
-      bufA[s * kLd + lane] = ggeo;
+      buf[s * kLd + lane] = ggeo;
       geo_sum += ggeo;
     }
     *(sums + kSumB1 + 1 + lane) = geo_sum;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
         }
         *reinterpret_cast<float4*>(gq + n * kF + 4 * cq) = acc;
       }
-      *reinterpret_cast<float4*>(&bufB[s * kLd + 4 * cq]) = acc;
+      *reinterpret_cast<float4*>(&buf[s * kLd + kF2 + 4 * cq]) = acc;
       qsum.x += acc.x;
       qsum.y += acc.y;
       qsum.z += acc.z;
@@ -666,9 +670,9 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
   f32x16 gt[4], ga1[4];
   zero_acc(gt);
   zero_acc(ga1);
-  tile_gemm<4>(bufB, kLd, P.MW, kF, kF, gt, lane);
-  tile_gemm<4>(bufA, kLd, P.W1gt, kG, kG, ga1, lane);
-  __syncthreads();  // both tiles consumed: bufA / bufB are free again
+  tile_gemm<4>(buf + kF2, kLd, P.MW, kF, kF, gt, lane);
+  tile_gemm<4>(buf, kLd, P.W1gt, kG, kG, ga1, lane);
+  __syncthreads();  // both tiles consumed: the buffer is free again
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     const int col = nb * 32 + i;
@@ -686,8 +690,8 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
       s_c0 += g0;
       s_bc1 += valid ? a : 0.f;
       s_v1 += gt[nb][r] * d1;
-      bufB[row * kLd + col] = g0;
-      bufA[row * kLd + col] = valid ? a : 0.f;
+      buf[row * kLd + col] = g0;
+      ga1[nb][r] = valid ? a : 0.f;   // (the second operand of gf: into the buffer once gh0 . M has read it)
       if (valid) {
         gz[n * (2 * kH) + col] = g0;
         gz[n * (2 * kH) + kH + col] = a;
@@ -709,8 +713,14 @@ __global__ __launch_bounds__(64) void field_bwd_kernel(
   {
     f32x16 gf[2];
     zero_acc(gf);
-    tile_gemm<2>(bufB, kLd, P.Mt, kH, kH, gf, lane);
-    tile_gemm<2>(bufA, kLd, P.Wc1t, kH, kH, gf, lane);
+    tile_gemm<2>(buf, kLd, P.Mt, kH, kH, gf, lane);
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf[acc_row(r, h) * kLd + nb * 32 + i] = ga1[nb][r];
+    __syncthreads();
+    tile_gemm<2>(buf, kLd, P.Wc1t, kH, kH, gf, lane);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
