@@ -27,6 +27,7 @@
 // order: no zero-fill, no atomics, identical bits on every run - in the forward pass, the
 // grad-input pass (same two stages over the transposed pair roles, weights read in place) and the
 // weight gradient (partial slabs + ordered reduction, sparse_conv.hip).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -435,18 +436,31 @@ int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* 
                                      c_out, stats_ws, gsum, dy, dres_or_null, (pv2_stream_t)s)) {
     return e;
   }
-  if (dweight_or_null) {
-    if (side != s) {  // the weight gradient feeds nothing until the optimizer: off the critical chain
+  // The weight gradient feeds nothing until the optimizer: off the critical chain, on the side stream.  WHERE it
+  // forks decides what it shares the machine with: right behind the BatchNorm backward (PV2_WGRAD_LATE=0, rounds
+  // 4 - 5) it runs beside this unit's grad-input products - two MFMA kernels slowing each other -; behind the
+  // products launch (1, the default since round 6) it starts when the products end, beside the row reduce and
+  // the next unit's BatchNorm kernels, which leave the matrix pipe idle: 18.14 -> 17.88 ms per step; behind the
+  // row reduce (2) it meets the NEXT unit's products: 18.25.
+  static const int wgrad_late = [] {
+    const char* e = getenv("PV2_WGRAD_LATE");
+    return e ? atoi(e) : 1;
+  }();
+  const bool osm_dx = dx_or_null && pv2::use_osm(&g->osm_bwd, g->zero_row, g->K, g->n_in, g->n_out, c_out, c_in);
+  const bool late = wgrad_late && dweight_or_null && side != s && dx_or_null && !osm_dx;
+  auto weight_gradient = [&]() -> int {
+    if (side != s) {
       hipEvent_t ev = fork_event();
       if (int e = pv2::hip_status(hipEventRecord(ev, s))) return e;
       if (int e = pv2::hip_status(hipStreamWaitEvent(side, ev, 0))) return e;
     }
-    if (int e = pv2::spconv_wgrad(x, g->n_in, c_in, dy, g->n_out, c_out, g->K, g->pair_in,
-                                  g->pair_out, g->kstart, g->tile_start_w, g->tile_pairs_w,
-                                  g->n_tiles_w, dweight_or_null, part_ws, side))
-      return e;
-  }
-  if (dx_or_null && pv2::use_osm(&g->osm_bwd, g->zero_row, g->K, g->n_in, g->n_out, c_out, c_in)) {
+    return pv2::spconv_wgrad(x, g->n_in, c_in, dy, g->n_out, c_out, g->K, g->pair_in, g->pair_out,
+                             g->kstart, g->tile_start_w, g->tile_pairs_w, g->n_tiles_w, dweight_or_null,
+                             part_ws, side);
+  };
+  if (dweight_or_null && !late)
+    if (int e = weight_gradient()) return e;
+  if (osm_dx) {
     // grad-input, output-stationary over the INPUT rows (sparse_conv_osm.hip): one launch, the other
     // consumers' gradient added in its epilogue, forward weight read in place
     if (int e = pv2::spconv_osm(true, dy, c_out, weight, g->K, c_in, &g->osm_bwd, g->n_in, g->zero_row,
@@ -458,6 +472,8 @@ int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* 
     if (int e = pv2::spconv_products(true, dy, c_out, weight, g->K, c_in, g->pair_out, g->kstart,
                                      g->tile_start, g->n_tiles, prod_ws, s))
       return e;
+    if (late && wgrad_late == 1)
+      if (int e = weight_gradient()) return e;
     ReduceStats st;
     if (dx_producer && dx_producer->gsum && g->n_in >= 2) {
       st.mode = 2;
@@ -470,6 +486,8 @@ int convbn_backward(const pv2_conv_geom* g, const float* grad_out, const float* 
     if (int e = reduce_rows_stats(prod_ws, g->pos_in, g->pos_in_stride, g->K, c_in, g->n_in, nullptr,
                                   dx_accumulate ? dx_or_null : nullptr, dx_or_null, st, &blocks, s))
       return e;
+    if (late && wgrad_late != 1)   // (2: behind the row reduce)
+      if (int e = weight_gradient()) return e;
     if (st.mode == 2) {
       // (combined at once: the workspace serves the next unit's statistics)
       if (int e = pv2::bn_backward_combine(stats_ws, blocks, c_in, dx_producer->gsum, s)) return e;

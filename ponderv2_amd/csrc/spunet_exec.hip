@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -129,7 +130,14 @@ int convbn16_backward(const pv2_unet_op& u, float* stats_ws, hipStream_t s, hipS
                                     u.mean_invstd, u.bn_weight, u.n_out, u.c_out, stats_ws, u.gsum, u.dy,
                                     u.dres, (pv2_stream_t)s))
     return e;
-  if (u.dweight) {
+  // (where the weight gradient forks: in front of the grad-input launch by default - the fp32 units fork BEHIND
+  // it, see convbn_backward in sparse_conv_pr.hip, but the 16-bit step is bound by its host and measured
+  // 14.5 ms that way against 14.8; PV2_WGRAD_LATE16=1 for the other order)
+  static const int wgrad_late = [] {
+    const char* e = getenv("PV2_WGRAD_LATE16");
+    return e ? atoi(e) : 0;
+  }();
+  auto weight_gradient = [&]() -> int {
     if (side != s) {
       hipEvent_t ev = nullptr;
       if (int e = pv2::fork_event_for(&ev)) return e;
@@ -138,12 +146,13 @@ int convbn16_backward(const pv2_unet_op& u, float* stats_ws, hipStream_t s, hipS
     }
     // (the 16-bit weight gradient ADDS its chunks into dweight)
     if (int e = pv2::zero_words(u.dweight, (int64_t)u.c_out * u.K * u.c_in, side)) return e;
-    if (int e = pv2_spconv16_backward_weight(u.x, u.n_in, u.c_in, u.dy, u.n_out, u.c_out, u.dtype, u.K,
-                                             u.geom->pair_in, u.geom->pair_out, u.geom->kstart,
-                                             u.tile_start16, 512, u.n_tiles16, u.dweight,
-                                             (pv2_stream_t)side))
-      return e;
-  }
+    return pv2_spconv16_backward_weight(u.x, u.n_in, u.c_in, u.dy, u.n_out, u.c_out, u.dtype, u.K,
+                                        u.geom->pair_in, u.geom->pair_out, u.geom->kstart, u.tile_start16, 512,
+                                        u.n_tiles16, u.dweight, (pv2_stream_t)side);
+  };
+  const bool late = wgrad_late && u.dweight && u.dx && side != s;
+  if (u.dweight && !late)
+    if (int e = weight_gradient()) return e;
   if (u.dx) {
     void* target = u.dx_accumulate ? u.dx_tmp : (void*)u.dx;
     PV2_REQUIRE(target != nullptr, "pv2_unet_backward: 16-bit grad-input needs dx_tmp to accumulate");
@@ -151,6 +160,8 @@ int convbn16_backward(const pv2_unet_op& u, float* stats_ws, hipStream_t s, hipS
                                         u.nbr_t_stride, u.perm_t, u.kflip_t, nullptr, target, u.n_in,
                                         (pv2_stream_t)s))
       return e;
+    if (late)
+      if (int e = weight_gradient()) return e;
     if (u.dx_accumulate) {
       const int64_t n8 = u.n_in * u.c_in / 8;
       if (u.dtype == PV2_BF16)

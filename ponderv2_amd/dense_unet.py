@@ -226,15 +226,28 @@ class _DenseUNet(torch.autograd.Function):
         wjobs = []       # weight-gradient launches, issued in one batch at the end
         # every parameter gradient of the node in ONE flat buffer (64-float aligned pieces): the
         # gradient synchronisation then moves them with one copy (utils/grad_sync.py arena blocks)
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += (p.numel() + 63) // 64 * 64
+        # A BatchNorm's (weight, bias) pair shares one block laid out [bias | weight]: that is the {sum g, sum g xhat}
+        # row pv2_bn_backward writes, so it writes the pair's gradients IN PLACE (round 6: twelve small
+        # device-to-device copies per step on the training stream's chain before).
+        bn_pairs = [(3 * i, 3 * i + 1) for i in range(n_enc)] + \
+                   [(3 * n_enc + 5 * j + 2, 3 * n_enc + 5 * j + 3) for j in range(n_dec)]
+        pair_of_bias = {ib: iw for iw, ib in bn_pairs}
+        offs, total = [0] * len(params), 0
+        for i, p in enumerate(params):
+            if i in pair_of_bias:
+                continue                      # placed with its weight
+            if any(i == iw for iw, _ in bn_pairs):
+                c = p.numel()
+                offs[i + 1], offs[i] = total, total + c
+                total += (2 * c + 63) // 64 * 64
+            else:
+                offs[i] = total
+                total += (p.numel() + 63) // 64 * 64
         arena = torch.empty(total, dtype=torch.float32, device=dev)
         # (same strides as the parameter - the conv weights are channels_last_3d -, like empty_like)
         pviews = [arena[o:o + p.numel()].as_strided(p.shape, p.stride()) for o, p in zip(offs, params)]
 
-        def level_backward(g, x, stats, y, bn_w, w, slot, masked):
+        def level_backward(g, x, stats, y, bn_w, w, slot, masked, gsum):
             """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients.
             ``masked``: ``g`` already passed the ReLU backwards (its producer zeroed it where y <= 0);
             otherwise both consumers apply the mask while they stage it."""
@@ -245,12 +258,11 @@ class _DenseUNet(torch.autograd.Function):
             wjobs.append((0, x, base + 8 * c, base + 12 * c, g, m, w, slot))
             b, _, z, yy, xx = x.shape
             n = b * z * yy * xx
-            gsum = torch.empty(2 * c, dtype=torch.float32, device=dev)
             gx = _vol(b, c, z, yy, xx, dev)
             _lib.check(L.pv2_bn_backward(gxn.data_ptr(), x.data_ptr(), None, base, bn_w.data_ptr(), n, c,
                                          _ptr(rownorm._workspace(dev, c)), gsum.data_ptr(), gx.data_ptr(), None,
                                          st), "pv2_bn_backward")
-            return gx, gsum
+            return gx
 
         gskip = [None] * n_dec
         for j in reversed(range(n_dec)):
@@ -258,9 +270,11 @@ class _DenseUNet(torch.autograd.Function):
             up_w, up_b, bn_w, bn_b, w = dec_p[j]
             k = 3 * n_enc + 5 * j
             # (the node's incoming gradient is the only one that arrives unmasked)
-            gs, gsum = level_backward(g, s, stats, y, bn_w, w, k + 4, masked=j != n_dec - 1)
             c = s.shape[1]
-            grads[k + 2], grads[k + 3] = pviews[k + 2].copy_(gsum[c:]), pviews[k + 3].copy_(gsum[:c])
+            assert bn_w.numel() == c and offs[k + 2] == offs[k + 3] + c
+            gs = level_backward(g, s, stats, y, bn_w, w, k + 4, masked=j != n_dec - 1,
+                                gsum=arena[offs[k + 3]:offs[k + 3] + 2 * c])
+            grads[k + 2], grads[k + 3] = pviews[k + 2], pviews[k + 3]
             gskip[j] = gs
             x_in = enc[n_enc - 1][3] if j == 0 else dec[j - 1][2]
             wjobs.append((1, x_in, None, None, gs, None, up_w, k))
@@ -271,9 +285,11 @@ class _DenseUNet(torch.autograd.Function):
         for i in reversed(range(n_enc)):
             p, idx, stats, y = enc[i]
             bn_w, bn_b, w = enc_p[i]
-            gp, gsum = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2, masked=True)
             c = p.shape[1]
-            grads[3 * i], grads[3 * i + 1] = pviews[3 * i].copy_(gsum[c:]), pviews[3 * i + 1].copy_(gsum[:c])
+            assert bn_w.numel() == c and offs[3 * i] == offs[3 * i + 1] + c
+            gp = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2, masked=True,
+                                gsum=arena[offs[3 * i + 1]:offs[3 * i + 1] + 2 * c])
+            grads[3 * i], grads[3 * i + 1] = pviews[3 * i], pviews[3 * i + 1]
             b, _, z, yy, xx = p.shape
             add = gskip[n_enc - 1 - i]      # the pooled tensor is also that decoder level's skip
             g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
