@@ -214,6 +214,7 @@ class _DenseUNet(torch.autograd.Function):
         params = tensors[len(tensors) - ctx.n_params:]
         saved = tensors[:len(tensors) - ctx.n_params]
         g = dc._cl(g)
+        g0 = g
         st = _stream(g)
         dev = g.device
         n_enc, n_dec = len(spec.encoders), len(spec.decoders)
@@ -247,64 +248,10 @@ class _DenseUNet(torch.autograd.Function):
         # (same strides as the parameter - the conv weights are channels_last_3d -, like empty_like)
         pviews = [arena[o:o + p.numel()].as_strided(p.shape, p.stride()) for o, p in zip(offs, params)]
 
-        def level_backward(g, x, stats, y, bn_w, w, slot, masked, gsum):
-            """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients.
-            ``masked``: ``g`` already passed the ReLU backwards (its producer zeroed it where y <= 0);
-            otherwise both consumers apply the mask while they stage it."""
-            c = x.shape[1]
-            base = stats.data_ptr()
-            m = None if masked else y
-            gxn = _conv(L, st, g, _pack(L, st, w, 1, True), c, 0, mask=m)
-            wjobs.append((0, x, base + 8 * c, base + 12 * c, g, m, w, slot))
-            b, _, z, yy, xx = x.shape
-            n = b * z * yy * xx
-            gx = _vol(b, c, z, yy, xx, dev)
-            _lib.check(L.pv2_bn_backward(gxn.data_ptr(), x.data_ptr(), None, base, bn_w.data_ptr(), n, c,
-                                         _ptr(rownorm._workspace(dev, c)), gsum.data_ptr(), gx.data_ptr(), None,
-                                         st), "pv2_bn_backward")
-            return gx
-
-        gskip = [None] * n_dec
-        for j in reversed(range(n_dec)):
-            s, stats, y = dec[j]
-            up_w, up_b, bn_w, bn_b, w = dec_p[j]
-            k = 3 * n_enc + 5 * j
-            # (the node's incoming gradient is the only one that arrives unmasked)
-            c = s.shape[1]
-            assert bn_w.numel() == c and offs[k + 2] == offs[k + 3] + c
-            gs = level_backward(g, s, stats, y, bn_w, w, k + 4, masked=j != n_dec - 1,
-                                gsum=arena[offs[k + 3]:offs[k + 3] + 2 * c])
-            grads[k + 2], grads[k + 3] = pviews[k + 2], pviews[k + 3]
-            gskip[j] = gs
-            x_in = enc[n_enc - 1][3] if j == 0 else dec[j - 1][2]
-            wjobs.append((1, x_in, None, None, gs, None, up_w, k))
-            wjobs.append((2, None, None, None, gs, None, up_b, k + 1))
-            # grad-input of the transposed conv = the gradient of x_in, a ReLU's output (the level
-            # below): masked in this kernel's epilogue
-            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False, 2), up_w.shape[0], 2, out_mask=x_in)
-        for i in reversed(range(n_enc)):
-            p, idx, stats, y = enc[i]
-            bn_w, bn_b, w = enc_p[i]
-            c = p.shape[1]
-            assert bn_w.numel() == c and offs[3 * i] == offs[3 * i + 1] + c
-            gp = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2, masked=True,
-                                gsum=arena[offs[3 * i + 1]:offs[3 * i + 1] + 2 * c])
-            grads[3 * i], grads[3 * i + 1] = pviews[3 * i], pviews[3 * i + 1]
-            b, _, z, yy, xx = p.shape
-            add = gskip[n_enc - 1 - i]      # the pooled tensor is also that decoder level's skip
-            g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
-            # the pooled tensor: the previous encoder level's ReLU output (mask its gradient here), or
-            # the node's input x0 (whatever produced it owns its own backward)
-            below = (enc[i - 1][3].data_ptr() if i > 0
-                     else x0.data_ptr() if spec.premask_input else None)
-            _lib.check(L.pv2_maxpool3d_cl_backward_add(gp.data_ptr(), idx.data_ptr(), add.data_ptr(), below, b,
-                                                       2 * z, 2 * yy, 2 * xx, c, g.data_ptr(), st),
-                       "pv2_maxpool3d_cl_backward_add")
-
-        def weight_gradients():
-            stw = _stream(g)     # (the side stream when forked)
+        def weight_gradients(jobs):
+            stw = _stream(g0)    # (the side stream when forked)
             out = []
-            for kind, x, scale, shift, gy, mask, w, slot in wjobs:
+            for kind, x, scale, shift, gy, mask, w, slot in jobs:
                 if kind == 2:    # bias of the transposed conv: column sums of the gradient rows
                     rows = gy.permute(0, 2, 3, 4, 1).reshape(-1, gy.shape[1])
                     gb = pviews[slot]
@@ -326,16 +273,87 @@ class _DenseUNet(torch.autograd.Function):
                 out.append((slot, dw))
             return out
 
-        leaves = [job[6] for job in wjobs]
-        if sidestream.active(g) and all(sidestream.safe_leaf(w) for w in leaves):
+        # Weight gradients: on the backward side stream (sidestream.py), each level's forked right BEHIND the launch
+        # of that level's grad-input kernel - it then runs beside the BatchNorm backward / un-pooling passes that
+        # follow (memory-bound, the matrix pipe idle) instead of, all levels in one batch at the end of the node
+        # (rounds 4 - 5), beside the sparse backbone's first grad-input products.  PV2_DENSE_WGRAD_BATCH=1: one batch.
+        leaf_params = [p_[2] for p_ in enc_p] + [q for p_ in dec_p for q in (p_[0], p_[1], p_[4])]
+        forked = sidestream.active(g) and all(sidestream.safe_leaf(w_) for w_ in leaf_params)
+        per_level = forked and not WGRAD_ONE_BATCH
+        done = []
+
+        def run_jobs(jobs):
+            if per_level:
+                keep = tuple(t for job in jobs for t in job if torch.is_tensor(t)) + tuple(saved) + (arena,)
+                done.extend(sidestream.fork(lambda: weight_gradients(jobs), keep))
+            else:
+                wjobs.extend(jobs)
+
+        def level_backward(g, x, stats, y, bn_w, w, slot, masked, gsum):
+            """through relu(conv(bn(x))): returns d/dx; queues d/dw; fills the BatchNorm gradients.
+            ``masked``: ``g`` already passed the ReLU backwards (its producer zeroed it where y <= 0);
+            otherwise both consumers apply the mask while they stage it."""
+            c = x.shape[1]
+            base = stats.data_ptr()
+            m = None if masked else y
+            gxn = _conv(L, st, g, _pack(L, st, w, 1, True), c, 0, mask=m)
+            run_jobs([(0, x, base + 8 * c, base + 12 * c, g, m, w, slot)])
+            b, _, z, yy, xx = x.shape
+            n = b * z * yy * xx
+            gx = _vol(b, c, z, yy, xx, dev)
+            _lib.check(L.pv2_bn_backward(gxn.data_ptr(), x.data_ptr(), None, base, bn_w.data_ptr(), n, c,
+                                         _ptr(rownorm._workspace(dev, c)), gsum.data_ptr(), gx.data_ptr(), None,
+                                         st), "pv2_bn_backward")
+            return gx
+
+        gskip = [None] * n_dec
+        for j in reversed(range(n_dec)):
+            s, stats, y = dec[j]
+            up_w, up_b, bn_w, bn_b, w = dec_p[j]
+            k = 3 * n_enc + 5 * j
+            # (the node's incoming gradient is the only one that arrives unmasked)
+            c = s.shape[1]
+            assert bn_w.numel() == c and offs[k + 2] == offs[k + 3] + c
+            gs = level_backward(g, s, stats, y, bn_w, w, k + 4, masked=j != n_dec - 1,
+                                gsum=arena[offs[k + 3]:offs[k + 3] + 2 * c])
+            grads[k + 2], grads[k + 3] = pviews[k + 2], pviews[k + 3]
+            gskip[j] = gs
+            x_in = enc[n_enc - 1][3] if j == 0 else dec[j - 1][2]
+            # grad-input of the transposed conv = the gradient of x_in, a ReLU's output (the level
+            # below): masked in this kernel's epilogue
+            g = _conv(L, st, gs, _pack(L, st, up_w, 0, False, 2), up_w.shape[0], 2, out_mask=x_in)
+            run_jobs([(1, x_in, None, None, gs, None, up_w, k), (2, None, None, None, gs, None, up_b, k + 1)])
+        for i in reversed(range(n_enc)):
+            p, idx, stats, y = enc[i]
+            bn_w, bn_b, w = enc_p[i]
+            c = p.shape[1]
+            assert bn_w.numel() == c and offs[3 * i] == offs[3 * i + 1] + c
+            gp = level_backward(g, p, stats, y, bn_w, w, 3 * i + 2, masked=True,
+                                gsum=arena[offs[3 * i + 1]:offs[3 * i + 1] + 2 * c])
+            grads[3 * i], grads[3 * i + 1] = pviews[3 * i], pviews[3 * i + 1]
+            b, _, z, yy, xx = p.shape
+            add = gskip[n_enc - 1 - i]      # the pooled tensor is also that decoder level's skip
+            g = _vol(b, c, 2 * z, 2 * yy, 2 * xx, dev)
+            # the pooled tensor: the previous encoder level's ReLU output (mask its gradient here), or
+            # the node's input x0 (whatever produced it owns its own backward)
+            below = (enc[i - 1][3].data_ptr() if i > 0
+                     else x0.data_ptr() if spec.premask_input else None)
+            _lib.check(L.pv2_maxpool3d_cl_backward_add(gp.data_ptr(), idx.data_ptr(), add.data_ptr(), below, b,
+                                                       2 * z, 2 * yy, 2 * xx, c, g.data_ptr(), st),
+                       "pv2_maxpool3d_cl_backward_add")
+
+        if wjobs and forked:      # (one batch)
             keep = tuple(t for job in wjobs for t in job if torch.is_tensor(t)) + tuple(saved) + (arena,)
-            done = sidestream.fork(weight_gradients, keep)
-        else:
-            done = weight_gradients()
+            done.extend(sidestream.fork(lambda: weight_gradients(wjobs), keep))
+        elif wjobs:
+            done.extend(weight_gradients(wjobs))
         for slot, t in done:
             grads[slot] = t
         gx0 = g if ctx.needs_input_grad[0] else None
         return (gx0, None) + tuple(grads)
+
+
+WGRAD_ONE_BATCH = os.environ.get("PV2_DENSE_WGRAD_BATCH", "0") == "1"
 
 
 def forward(net, x0, premask_input=False):
