@@ -883,3 +883,16 @@ def test_gradient_slabs_partition_the_executor_arena_in_completion_order():
     # too few conv units, or a reducer that declines: no slabs
     assert sn._gradient_slabs(plan, tensors, type("No", (), {"slab_elems": 1, "wants": lambda s, t: False})(),
                               arena) is None
+
+
+def test_bench_reads_a_pmc_file_measured_on_these_kernel_sources():
+    """``roofline.traffic`` of the bench line is a read of the round's committed PMC file; bench.py refuses a
+    file measured on other kernel sources (traffic null).  This keeps the committed file and the sparse-conv
+    sources together: a kernel edit without fresh counter passes - or a file that never reached the repo - fails
+    here instead of silently dropping the figure from the driver's line."""
+    import bench
+
+    traffic, source = bench.pmc_traffic("spconv_fwd_lds_kernel<4")
+    assert traffic is not None, source
+    assert bench.kernel_source_hash() in source
+    assert 1e7 < traffic < 1e9, traffic      # bytes per launch of the 128-channel products kernel (~1e8)
