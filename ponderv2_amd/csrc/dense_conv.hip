@@ -432,16 +432,24 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
     int n_groups, int tiles_per_wg, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, const float* __restrict__ mask_src,
     const float* __restrict__ bias, const float* __restrict__ addend, int relu,
-    const float* __restrict__ out_mask_src, float* __restrict__ Y) {
+    const float* __restrict__ out_mask_src, float* __restrict__ Y, int ksplit, int64_t part_stride) {
   constexpr int CK = 16, QPR = 4;
   extern __shared__ __attribute__((aligned(16))) float sX[];
   unsigned* sU = reinterpret_cast<unsigned*>(sX);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-  const int grp = blockIdx.x % n_groups;
+  // ksplit > 1 (round 6, the coarse levels: 64 - 128 workgroups of 8 - 16 chunks each on 256 CUs): the channel
+  // chunks of a tile are dealt to `ksplit` workgroups; each writes its RAW partial sums to plane blockIdx.x %
+  // ksplit of Y (= a scratch of ksplit x part_stride floats) and dconv_splitk_finish_kernel adds the planes in
+  // order and applies the epilogue.
+  const int s_idx = ksplit > 1 ? blockIdx.x % ksplit : 0;
+  const int bid = ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x;
+  const int grp = bid % n_groups;
   const int n_tiles = g.B * g.nTZ * g.nTY * g.nTX;
-  const int tile_first = (blockIdx.x / n_groups) * tiles_per_wg;
+  const int tile_first = (bid / n_groups) * tiles_per_wg;
   const int tile_count = min(tiles_per_wg, n_tiles - tile_first);
-  const int nchunks = c_in / CK;
+  const int nchunks_all = c_in / CK;
+  const int nchunks = nchunks_all / ksplit;      // chunks of THIS workgroup: ckb .. ckb + nchunks - 1
+  const int ckb = s_idx * nchunks;
   const int n_items = tile_count * nchunks;
   const int Zi = g.Zi, Yi = g.Yi, Xi = g.Xi, HX = g.HX, HY = g.HY;
   const int in_off = g.in_off;
@@ -469,9 +477,9 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
       for (int r = 0; r < 16; ++r) acc[mt][nb][r] = 0.f;
 
   const int nbtot = c_out >> 5;
-  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane;
   const int64_t wc16 = (int64_t)nbtot * 3 * 64;       // fragments per 16-channel chunk
-  const int64_t wtap = (int64_t)nchunks * wc16;       // fragments per tap
+  const int64_t wtap = (int64_t)nchunks_all * wc16;   // fragments per tap
+  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane + (int64_t)ckb * wc16;
 
   auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % nTX;
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
     int b, z0, y0, x0;
     tile_origin(tile_first + tl, b, z0, y0, x0);
     const int hz0 = z0 + in_off, hy0 = y0 + in_off, hx0 = x0 + in_off;
-    const int c0 = ck * CK + quad * 4;
+    const int c0 = (ckb + ck) * CK + quad * 4;
     if (in_scale != nullptr) {
       psc = ld4g(in_scale + c0);
       psh = ld4g(in_shift + c0);
@@ -644,6 +652,10 @@ __global__ __launch_bounds__(256, 2) void dconv_split_kernel(
             float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
             if (cz >= eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
             const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+            if (ksplit > 1) {   // raw partial sums of this workgroup's chunks
+              *reinterpret_cast<float4*>(Y + (int64_t)s_idx * part_stride + off) = v;
+              continue;
+            }
             v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
             if (addend != nullptr) {
               const float4 a = ld4g(addend + off);
@@ -792,16 +804,21 @@ template <int NB, int PFN, bool MASKED, bool ONE>
 __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
     int n_groups, int tiles_per_wg, const float* __restrict__ mask_src,
-    const float* __restrict__ out_mask_src, float* __restrict__ Y) {
+    const float* __restrict__ out_mask_src, float* __restrict__ Y, int ksplit, int64_t part_stride) {
   constexpr int CK = 8, QPR = 2, NPAIR = 14;
   extern __shared__ __attribute__((aligned(16))) float sX[];
   unsigned* sU = reinterpret_cast<unsigned*>(sX);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-  const int grp = blockIdx.x % n_groups;
+  // (ksplit: as in dconv_split_kernel)
+  const int s_idx = ksplit > 1 ? blockIdx.x % ksplit : 0;
+  const int bid = ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x;
+  const int grp = bid % n_groups;
   const int n_tiles = g.B * g.nTZ * g.nTY * g.nTX;
-  const int tile_first = (blockIdx.x / n_groups) * tiles_per_wg;
+  const int tile_first = (bid / n_groups) * tiles_per_wg;
   const int tile_count = min(tiles_per_wg, n_tiles - tile_first);
-  const int nchunks = c_in / CK;
+  const int nchunks_all = c_in / CK;
+  const int nchunks = nchunks_all / ksplit;
+  const int ckb = s_idx * nchunks;
   const int n_items = tile_count * nchunks;
   const int Zi = g.Zi, Yi = g.Yi, Xi = g.Xi, HX = g.HX, HY = g.HY, HXr = g.HXr, HXh = g.HXh;
   const int nTX = g.nTX, nTY = g.nTY, nTZ = g.nTZ, eTZ = g.eTZ, TYs = g.TY, TXs = g.TX;
@@ -824,9 +841,9 @@ __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
   const int nbtot = c_out >> 5;
-  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane;
   const int64_t wc8 = (int64_t)nbtot * 3 * 64;        // fragments per 8-channel chunk
-  const int64_t wpair = (int64_t)nchunks * wc8;       // fragments per tap pair
+  const int64_t wpair = (int64_t)nchunks_all * wc8;   // fragments per tap pair
+  const pv2::bf16x8* __restrict__ Wl = Wq + (grp * NB) * 3 * 64 + lane + (int64_t)ckb * wc8;
 
   auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % nTX;
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
     int b, z0, y0, x0;
     tile_origin(tile_first + tl, b, z0, y0, x0);
     const int hz0 = 2 * z0 - 1, hy0 = 2 * y0 - 1, hx0 = 2 * x0 - 1;
-    const int c0 = ck * CK + quad * 4;
+    const int c0 = (ckb + ck) * CK + quad * 4;
     okbits = 0;
 #pragma unroll
     for (int u = 0; u < PFN; ++u) {
@@ -971,6 +988,10 @@ __global__ __launch_bounds__(256, 2) void dconv_strided_split_kernel(
           float4 v = *reinterpret_cast<const float4*>(&stage[m * kStagePad + 4 * c4]);
           if (cz >= eTZ || oz >= g.Zt || oy >= g.Yt || ox >= g.Xt) continue;
           const int64_t off = ((((int64_t)b * g.Zo + oz) * g.Yo + oy) * g.Xo + ox) * c_out + n;
+          if (ksplit > 1) {
+            *reinterpret_cast<float4*>(Y + (int64_t)s_idx * part_stride + off) = v;
+            continue;
+          }
           if (out_mask_src != nullptr) keep_positive(v, ld4g(out_mask_src + off));
           *reinterpret_cast<float4*>(Y + off) = v;
         }
@@ -1732,6 +1753,71 @@ int pv2_dconv3_pack_weights(const float* w, int n_out, int n_red, int64_t s_out,
 // mode 2: strided conv k3 s2 p1 (out = in / 2, in even): the grad-input of mode 1.
 }  // extern "C"
 
+// Split-K finish (dconv_split_kernel / dconv_strided_split_kernel with ksplit > 1): the partial planes added in
+// order, then the convolution's epilogue - bias, addend, ReLU, the ReLU mask of the tensor the result is a gradient of.
+__global__ __launch_bounds__(256) void dconv_splitk_finish_kernel(
+    const float4* __restrict__ part, int ksplit, int64_t n4, int c4, const float4* __restrict__ bias,
+    const float4* __restrict__ addend, int relu, const float4* __restrict__ out_mask, float4* __restrict__ Y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += stride) {
+    float4 v = part[e];
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 u = part[(int64_t)k * n4 + e];
+      v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
+    }
+    if (bias != nullptr) {
+      const float4 b = bias[e % c4];
+      v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+    }
+    if (addend != nullptr) {
+      const float4 a = addend[e];
+      v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    }
+    if (out_mask != nullptr) keep_positive(v, out_mask[e]);
+    Y[e] = v;
+  }
+}
+
+// Scratch of a stream for the split-K partial planes, grown on demand.
+static int splitk_workspace(hipStream_t s, int64_t floats, float** out) {
+  struct Entry {
+    int dev;
+    hipStream_t s;
+    float* p;
+    int64_t cap;
+  };
+  static Entry table[64];
+  static int used = 0;
+  int dev = 0;
+  if (int e = pv2::hip_status(hipGetDevice(&dev))) return e;
+  Entry* hit = nullptr;
+  for (int k = 0; k < used; ++k)
+    if (table[k].dev == dev && table[k].s == s) hit = &table[k];
+  if (hit == nullptr) {
+    if (used == 64) {
+      pv2::set_error("dconv3_forward: more than 64 (device, stream) pairs");
+      return PV2_E_UNSUPPORTED;
+    }
+    table[used] = Entry{dev, s, nullptr, 0};
+    hit = &table[used++];
+  }
+  if (hit->cap < floats) {
+    if (hit->p) {   // (kernels of this stream may still read the old buffer)
+      if (int e = pv2::hip_status(hipStreamSynchronize(s))) return e;
+      (void)hipFree(hit->p);
+      hit->p = nullptr;
+      hit->cap = 0;
+    }
+    if (int e = pv2::hip_status(hipMalloc(reinterpret_cast<void**>(&hit->p), sizeof(float) * floats))) return e;
+    hit->cap = floats;
+  }
+  *out = hit->p;
+  return PV2_OK;
+}
+
 template <bool ONE>
 static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_in, const float* packed_w,
                        int c_out, int mode, const float* in_scale, const float* in_shift,
@@ -1821,7 +1907,40 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
   static const int force_tpw = env_int("PV2_DCONV_TPW", 0);
   while (tpw < 8 && n_tiles * n_groups / (tpw * 2) >= 1024) tpw *= 2;
   if (force_tpw) tpw = force_tpw;
-  const dim3 grid((unsigned)(((n_tiles + tpw - 1) / tpw) * n_groups));
+  // Split-K for launches that would leave CUs empty (the coarse levels: 16 tiles x a few channel groups): the
+  // channel chunks of a tile go to `ksplit` workgroups, dconv_splitk_finish_kernel adds their planes in order.
+  // PV2_DCONV_KSPLIT: 1 = never, k > 1 = that split wherever it divides the chunks.
+  int ksplit = 1;
+  if (split && (mode == 0 || mode == 2) && mt == 1) {
+    static const int force_ks = env_int("PV2_DCONV_KSPLIT", 0);
+    const int nchunks = c_in / ck;
+    const int64_t wgs = ((n_tiles + tpw - 1) / tpw) * n_groups;
+    const int min_chunks = ck == 8 ? 4 : 2;
+    static const int split_below = env_int("PV2_DCONV_KSPLIT_WGS", 256);   // (launches of more workgroups stay whole)
+    if (force_ks == 0 && wgs <= split_below) {
+      for (int k : {8, 4, 2})
+        if (nchunks % k == 0 && nchunks / k >= min_chunks && wgs * k <= 1024) {
+          ksplit = k;
+          break;
+        }
+    } else if (force_ks > 1 && nchunks % force_ks == 0) {
+      ksplit = force_ks;
+    }
+  }
+  const int64_t out_floats = (int64_t)b * g.Zo * g.Yo * g.Xo * c_out;
+  float* planes = nullptr;
+  if (ksplit > 1)
+    if (int e = splitk_workspace(s, (int64_t)ksplit * out_floats, &planes)) return e;
+  auto finish = [&](const float* f_bias, const float* f_addend, int f_relu, const float* f_mask) -> int {
+    if (ksplit == 1) return PV2_OK;
+    const int64_t n4 = out_floats / 4;
+    hipLaunchKernelGGL(dconv_splitk_finish_kernel, dim3(pv2::grid_for(n4, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(planes), ksplit, n4, c_out / 4,
+                       reinterpret_cast<const float4*>(f_bias), reinterpret_cast<const float4*>(f_addend), f_relu,
+                       reinterpret_cast<const float4*>(f_mask), reinterpret_cast<float4*>(out));
+    return PV2_OK;
+  };
+  const dim3 grid((unsigned)(((n_tiles + tpw - 1) / tpw) * n_groups * ksplit));
   const int pfn = (g.HZ * g.HY * g.HX * (ck / 4) + 255) / 256;  // float4 of the box per thread
   const bool masked = in_mask_src != nullptr;
 #define PV2_DCONV_LAUNCH(NB_, MT_, CK_, PFN_, MASKED_)                                                  \
@@ -1845,7 +1964,8 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
   do {                                                                                                  \
     if (int e = set_lds(dconv_strided_split_kernel<NB_, 13, MASKED_, ONE>, lds)) return e;                   \
     hipLaunchKernelGGL((dconv_strided_split_kernel<NB_, 13, MASKED_, ONE>), grid, dim3(256), lds, s, x, g,   \
-                       c_in, wq, c_out, n_groups, tpw, in_mask_src, out_mask_src, out);                 \
+                       c_in, wq, c_out, n_groups, tpw, in_mask_src, out_mask_src,                       \
+                       ksplit > 1 ? planes : out, ksplit, out_floats);                                  \
   } while (0)
     if (nb == 2) {
       if (masked) PV2_DSTRIDE_LAUNCH(2, true);
@@ -1855,6 +1975,7 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
       else PV2_DSTRIDE_LAUNCH(1, false);
     }
 #undef PV2_DSTRIDE_LAUNCH
+    if (int e = finish(nullptr, nullptr, 0, out_mask_src)) return e;
     return pv2::check_launch("dconv3_forward(strided, split)");
   }
   if (split) {
@@ -1864,7 +1985,7 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
     if (int e = set_lds(dconv_split_kernel<NB_, MT_, PFN_, MASKED_, ONE>, lds)) return e;                     \
     hipLaunchKernelGGL((dconv_split_kernel<NB_, MT_, PFN_, MASKED_, ONE>), grid, dim3(256), lds, s, x, g, c_in, \
                        wq, c_out, n_groups, tpw, in_scale, in_shift, in_mask_src, bias, addend, relu,    \
-                       out_mask_src, out);                                                               \
+                       out_mask_src, ksplit > 1 ? planes : out, ksplit, out_floats);                     \
   } while (0)
 #define PV2_DSPLIT_LAUNCH(NB_, PFN_, MASKED_) PV2_DSPLIT_LAUNCH_MT(NB_, 1, PFN_, MASKED_)
     if (mt == 2) {
@@ -1886,6 +2007,7 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
 #undef PV2_DSPLIT_MASK
 #undef PV2_DSPLIT_LAUNCH
 #undef PV2_DSPLIT_LAUNCH_MT
+    if (int e = finish(bias, addend, relu, out_mask_src)) return e;
     return pv2::check_launch("dconv3_forward(split)");
   }
   if (mode == 2) {
