@@ -1012,13 +1012,17 @@ template <bool ONE>
 __global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
     const float* __restrict__ X, DGeom g, int c_in, const pv2::bf16x8* __restrict__ Wq, int c_out,
     int n_groups, const float* __restrict__ bias, const float* __restrict__ addend,
-    float* __restrict__ Y) {
+    float* __restrict__ Y, int ksplit, int64_t part_stride) {
   constexpr int CK = 16, QPR = 4;
   extern __shared__ __attribute__((aligned(16))) float sX[];
   unsigned* sU = reinterpret_cast<unsigned*>(sX);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-  const int grp = blockIdx.x % n_groups;
-  int tile = blockIdx.x / n_groups;
+  // (ksplit: as in dconv_split_kernel - the channel chunks of a tile dealt to ksplit workgroups, raw partial
+  // sums into plane s_idx, dconv_splitk_finish_kernel adds bias and the skip features)
+  const int s_idx = ksplit > 1 ? blockIdx.x % ksplit : 0;
+  const int bid = ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x;
+  const int grp = bid % n_groups;
+  int tile = bid / n_groups;
   const int tx = tile % g.nTX;
   tile /= g.nTX;
   const int ty = tile % g.nTY;
@@ -1048,8 +1052,10 @@ __global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
   const int total = g.HZ * HY * HX * QPR;
   const int quad = tid & 3;
 
-  for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck) __syncthreads();
+  const int nper = nchunks / ksplit, ckb = s_idx * nper;
+  for (int cki = 0; cki < nper; ++cki) {
+    const int ck = ckb + cki;
+    if (cki) __syncthreads();
     // the chunk's box -> three bf16 pieces per cell (four loads in flight per thread)
     for (int base = tid; base < total; base += 256 * 4) {
       float4 v[4];
@@ -1131,6 +1137,10 @@ __global__ __launch_bounds__(256, 2) void dconvT_split_kernel(
       if (cz >= g.eTZ || jz >= g.Zt || jy >= g.Yt || jx >= g.Xt) continue;
       const int64_t off =
           ((((int64_t)b * g.Zo + 2 * jz + pz) * g.Yo + 2 * jy + py) * g.Xo + 2 * jx + px) * c_out + n;
+      if (ksplit > 1) {
+        *reinterpret_cast<float4*>(Y + (int64_t)s_idx * part_stride + off) = v;
+        continue;
+      }
       v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
       if (addend != nullptr) {
         const float4 a = ld4g(addend + off);
@@ -1889,10 +1899,39 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
   PV2_REQUIRE(lds <= 160 * 1024, "dconv3_forward: halo tile does not fit the LDS");
   const int n_groups = nbtot / nb;
   if (mode == 1 && split) {
+    int ks = 1;   // split-K where the launch would leave CUs empty (see below)
+    {
+      static const int force_ks = env_int("PV2_DCONV_KSPLIT", 0);
+      static const int split_below = env_int("PV2_DCONV_KSPLIT_WGS", 256);
+      const int nchunks = c_in / 16;
+      const int64_t wgs = n_tiles * n_groups;
+      // (a transposed conv writes EIGHT fine cells per coarse one: at 256 workgroups the planes are 134 MB and the
+      // split loses, 69 -> 94 us; at 64 it wins, 92 -> 55)
+      if (force_ks == 0 && wgs <= split_below / 2) {
+        for (int k : {8, 4, 2})
+          if (nchunks % k == 0 && nchunks / k >= 2 && wgs * k <= 1024) {
+            ks = k;
+            break;
+          }
+      } else if (force_ks > 1 && nchunks % force_ks == 0) {
+        ks = force_ks;
+      }
+    }
+    const int64_t out_floats_t = (int64_t)b * g.Zo * g.Yo * g.Xo * c_out;
+    float* planes_t = nullptr;
+    if (ks > 1)
+      if (int e = splitk_workspace(s, (int64_t)ks * out_floats_t, &planes_t)) return e;
     if (int e = set_lds(dconvT_split_kernel<ONE>, lds)) return e;
-    hipLaunchKernelGGL(dconvT_split_kernel<ONE>, dim3((unsigned)(n_tiles * n_groups)), dim3(256), lds, s, x, g,
-                       c_in, reinterpret_cast<const pv2::bf16x8*>(packed_w), c_out, n_groups, bias, addend,
-                       out);
+    hipLaunchKernelGGL(dconvT_split_kernel<ONE>, dim3((unsigned)(n_tiles * n_groups * ks)), dim3(256), lds, s, x,
+                       g, c_in, reinterpret_cast<const pv2::bf16x8*>(packed_w), c_out, n_groups, bias, addend,
+                       ks > 1 ? planes_t : out, ks, out_floats_t);
+    if (ks > 1) {
+      const int64_t n4 = out_floats_t / 4;
+      hipLaunchKernelGGL(dconv_splitk_finish_kernel, dim3(pv2::grid_for(n4, 256)), dim3(256), 0, s,
+                         reinterpret_cast<const float4*>(planes_t), ks, n4, c_out / 4,
+                         reinterpret_cast<const float4*>(bias), reinterpret_cast<const float4*>(addend), 0,
+                         static_cast<const float4*>(nullptr), reinterpret_cast<float4*>(out));
+    }
     return pv2::check_launch("dconv3_forward(transposed, split)");
   }
   if (mode == 1) {
