@@ -1876,6 +1876,10 @@ static int dconv3_forward_t(const float* x, int b, int z, int y, int xx, int c_i
   g.nTZ = (g.Zt + g.eTZ - 1) / g.eTZ, g.nTY = (g.Yt + g.TY - 1) / g.TY, g.nTX = (g.Xt + g.TX - 1) / g.TX;
   const int64_t n_tiles = (int64_t)b * g.nTZ * g.nTY * g.nTX;
   if (mode != 1 && mt == 1 && nbtot % 2 == 0 && n_tiles * (nbtot / 2) >= 512) nb = 2;
+  // the strided form stages 8 channels of a 2x-per-axis box per round - most of its time -, and every channel
+  // group of a tile repeats that staging: two output blocks per workgroup wherever they exist (round 6: 158 -> 85
+  // and 66 -> 44 us on the two coarse levels, the library's 109 / 82)
+  if (mode == 2 && split && mt == 1 && nbtot % 2 == 0) nb = 2;
   if (mode != 1 && mt == 1 && (force_nb == 1 || force_nb == 2) && nbtot % force_nb == 0) nb = force_nb;
   g.xsplit = 0, g.HXh = 0;
   int ck = 16;
