@@ -23,6 +23,7 @@ def cl(t):
     ((2, 5, 7, 37), 32, 64),      # ragged in every axis, two channel chunks, two output blocks
     ((1, 4, 16, 16), 128, 32),    # the coarsest level's grid: X = 16 tiles
     ((1, 3, 6, 70), 16, 32),      # a single 16-channel chunk
+    ((2, 4, 16, 16), 256, 128),   # the coarsest level at the bench's widths: split-K over the chunks (8 planes)
     ((1, 8, 128, 256), 32, 32),   # >= 262144 cells: the two-M-tiles-per-wave variant
 ])
 def test_conv_forward_fused_paths(device, shape, c_in, c_out):
@@ -75,7 +76,8 @@ def test_conv_grad_input_is_the_flipped_conv(device, shape, c_in, c_out):
     assert rel(got, vol.grad) < TOL
 
 
-@pytest.mark.parametrize("shape,c_in,c_out", [((2, 3, 5, 19), 64, 32), ((1, 4, 16, 16), 32, 64)])
+@pytest.mark.parametrize("shape,c_in,c_out", [((2, 3, 5, 19), 64, 32), ((1, 4, 16, 16), 32, 64),
+                                              ((2, 4, 16, 16), 256, 128)])   # (split-K planes in both directions)
 def test_transposed_conv_forward_and_grad_input(device, shape, c_in, c_out):
     from ponderv2_amd import dense_conv as dc
 
