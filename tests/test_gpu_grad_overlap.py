@@ -56,6 +56,12 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
             return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
         local = step(None)
+        # the step's own run-to-run noise, per tensor (float atomics of the scatter-mean and of the sampler's volume
+        # gradient reorder between passes; on this tiny model a flipped ReLU moves a BatchNorm gradient by a few
+        # 1e-3 - one sample of it failed this test once in the round's ~15 runs of the suite)
+        again, third = step(None), step(None)
+        noise = {n: max((again[n] - local[n]).abs().max().item(), (third[n] - local[n]).abs().max().item())
+                 for n in local}
         # (small slabs: the tiny backbone's arena is ~3 MB; several slabs -> several event pairs)
         sync = FlatGradSync(model.parameters(), overlap=True, slab_mb=0.5).attach()
         try:
@@ -75,14 +81,15 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
         floor = 1e-6 * max(g.abs().max().item() for g in local.values())   # (parameters in front of a
         # BatchNorm have an exactly-zero true gradient: rounding noise ~1e-9 on either side)
 
-        def close(a, b):
-            return (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + floor
+        def close(a, b, n):
+            scale = b.abs().max().item()
+            return (a - b).abs().max().item() <= 1e-3 * scale + floor + 10.0 * noise[n] * (scale / (local[n].abs().max().item() + 1e-30))
 
         for n in local:
             # (BatchNorm running statistics moved between the passes; train-mode gradients do not see
             # them.  Not bitwise: the float atomics left on the path - scatter-mean, the sampler's volume
             # gradient - reorder between passes, see test_gpu_trainer.py)
-            assert close(first[n], local[n]) and close(second[n], local[n]), n
+            assert close(first[n], local[n], n) and close(second[n], local[n], n), n
         names = {id(p): n for n, p in model.named_parameters()}
         n_cov = 0
         for i, p in enumerate(sync.params):
@@ -91,9 +98,9 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
                 continue
             if i in sync._covered:
                 n_cov += 1
-                assert close(doubled[n], 2.0 * local[n]), ("slab reduced before its gradients were written", n)
+                assert close(doubled[n], 2.0 * local[n], n), ("slab reduced before its gradients were written", n)
             else:
-                assert close(doubled[n], local[n]), n
+                assert close(doubled[n], local[n], n), n
         assert n_cov > 40
         # the covered gradients are views of the executor's arena, reduced in place
         covered = [model_p for i, model_p in enumerate(sync.params) if i in sync._covered]
