@@ -140,3 +140,30 @@ def test_fused_dense_unet_under_autocast_uses_bf16_products(device):
         if g.numel() > 64 and ref[2][k].abs().max() > 1e-6 and not k.endswith("upsample.bias"):
             c = torch.nn.functional.cosine_similarity(g.flatten(), ref[2][k].flatten(), dim=0).item()
             assert c > 0.99, (k, c)
+
+
+def test_side_stream_is_bitwise_invisible_on_the_dense_node(device, monkeypatch):
+    """The node's weight gradients are forked to the backward side stream level by level (round 6), beside the
+    training stream's BatchNorm / un-pooling passes.  Every kernel of the node is deterministic, so its gradients
+    must be IDENTICAL with the side stream on and off and from run to run - a gradient read while still in flight,
+    a buffer reused too early or a fork in front of its operand shows up as a plain inequality (no noise floor)."""
+    from ponderv2_amd import sidestream
+
+    net = _net(4, device)
+    torch.manual_seed(11)
+    x0 = torch.relu(torch.randn(2, 32, 16, 64, 64, device=device)).contiguous(memory_format=torch.channels_last_3d)
+    probe = torch.randn(net(None, first=x0).shape, device=device)
+    import copy as _copy
+
+    def run(side):
+        monkeypatch.setattr(sidestream, "ENABLED", side)
+        return _step(_copy.deepcopy(net), x0, probe)
+
+    want = run(False)
+    atomics = lambda k: k.endswith("upsample.bias") or k.startswith("final_conv")   # noqa: E731 (see above)
+    for trial in range(8):
+        got = run(True)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), trial
+        for k in want[2]:
+            if not atomics(k):
+                assert torch.equal(got[2][k], want[2][k]), (trial, k)

@@ -60,8 +60,11 @@ def test_side_stream_does_not_change_the_step(device, monkeypatch):
         floor = max(gc.rel_err(f[name], ref) for f in floors)
         err = gc.rel_err(new_g[name], ref)
         # (a gradient read while still in flight on the side stream is off by FACTORS; the bound only has
-        # to stay clear of the step's noise - three samples of a heavy-tailed quantity - so it is generous)
-        if not err <= max(1e-3, 10.0 * floor):
+        # to stay clear of the step's noise - three samples of a heavy-tailed quantity: a scatter atomic that
+        # flips a max-pool / ReLU decision moves the deepest dense conv's weight gradient by 2e-3 - 7e-3, one
+        # run in ~12 (round 6) - so it is generous.  The STRICT statements are the bitwise tests: the backbone
+        # below, the dense node in test_gpu_dense_unet.py - neither has atomics)
+        if not err <= max(2e-2, 10.0 * floor):
             bad[name] = (err, floor)
     assert not bad, bad
 
