@@ -56,12 +56,6 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
             return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
         local = step(None)
-        # the step's own run-to-run noise, per tensor (float atomics of the scatter-mean and of the sampler's volume
-        # gradient reorder between passes; on this tiny model a flipped ReLU moves a BatchNorm gradient by a few
-        # 1e-3 - one sample of it failed this test once in the round's ~15 runs of the suite)
-        again, third = step(None), step(None)
-        noise = {n: max((again[n] - local[n]).abs().max().item(), (third[n] - local[n]).abs().max().item())
-                 for n in local}
         # (small slabs: the tiny backbone's arena is ~3 MB; several slabs -> several event pairs)
         sync = FlatGradSync(model.parameters(), overlap=True, slab_mb=0.5).attach()
         try:
@@ -81,9 +75,14 @@ def test_one_rank_overlapped_reduction_leaves_the_local_gradients(device):
         floor = 1e-6 * max(g.abs().max().item() for g in local.values())   # (parameters in front of a
         # BatchNorm have an exactly-zero true gradient: rounding noise ~1e-9 on either side)
 
-        def close(a, b, n):
-            scale = b.abs().max().item()
-            return (a - b).abs().max().item() <= 1e-3 * scale + floor + 10.0 * noise[n] * (scale / (local[n].abs().max().item() + 1e-30))
+        # The step has TWO outcomes on this tiny model (tools/r06_overlap_probe.py): a last-bit difference of the
+        # forward's float atomics (scatter-mean, the sampler's volume gradient) flips one ReLU / max-pool decision
+        # and ~20 gradients move by 2e-3 ... 7.5e-3 of their maximum - in plain steps as in synchronised ones, one
+        # step in ~7 on the round-6 tree (round 5's rounding happened to sit away from the tie).  The statements
+        # below are about factors - a slab reduced before its gradients were written holds the UN-doubled values or
+        # garbage - so the bound only has to stay clear of that: 2e-2.
+        def close(a, b, n=None):
+            return (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + floor
 
         for n in local:
             # (BatchNorm running statistics moved between the passes; train-mode gradients do not see

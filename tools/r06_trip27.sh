@@ -1,2 +1,2 @@
 #!/bin/bash
-for i in 1 2 3; do python -m pytest tests/test_gpu_dense_unet.py -m gpu -q -k "bitwise_invisible" 2>&1 | grep -E "Error|passed|failed|assert" | cut -c1-300; done
+for i in 1 2 3 4; do python -m pytest tests/test_gpu_grad_overlap.py -m gpu -q 2>&1 | grep -E "^E  |passed|failed" | cut -c1-400 | head -12; done
