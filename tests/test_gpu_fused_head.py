@@ -263,6 +263,8 @@ def test_head_parameter_gradients_as_leaf_gradients_equal_the_collapse_graph(dev
             continue
         floor = gc.rel_err(again_g[name], ref)
         err = gc.rel_err(new_g[name], ref)
-        if not err <= max(2e-2 if name not in head else 2e-3, 10.0 * floor):
+        # (one sample of the step's noise per tensor: the bound stays clear of its tail - a flipped ReLU moves a
+        # gradient by up to ~1e-2 -; a wrong formula in the leaf-gradient chain is off by O(1))
+        if not err <= max(2e-2, 10.0 * floor):
             bad[name] = (err, floor)
     assert not bad, bad
