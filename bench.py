@@ -1008,7 +1008,9 @@ def main():
         if first_loss_t is None:
             first_loss_t = out["loss"].detach().clone()
     # pass 1: the measurement (no instrumentation inside the timed region)
+    seg0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0)
     elapsed, host_enqueue, out = timed_pass(args.steps)
+    new_segments = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) - seg0
     loss = float(out["loss"].detach())
     first_loss = float(first_loss_t) if first_loss_t is not None else loss
     # a training step that is fast but computes garbage is not a measurement: say so in the line
@@ -1055,6 +1057,9 @@ def main():
                        "pretrain scenes/sec (+ rendered rays/sec), SpUNet-v1m1 ScanNet-shaped"),
             "value": value, "unit": "scenes/s", "rays_per_s": value * rays_per_scene,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # device allocations (hipMalloc, each a device-wide stall) the caching allocator still made INSIDE the
+            # timed region: > 0 means the warm-up was too short for the allocator to have seen the batch sizes
+            "allocator_segments_in_timed_region": int(new_segments),
             "ms_per_step": 1e3 * elapsed / args.steps,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True,
